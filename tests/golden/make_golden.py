@@ -1,0 +1,383 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by RUNNING THE REFERENCE (read-only at /root/reference).
+
+Runs only in the build container (the reference never travels to the GPU box).
+Nothing from the reference is copied: this script imports
+quant/gptq/src/{gptq,quant_utils,packing_utils,quantizer}.py, feeds them seeded
+inputs and stores inputs + outputs as small .npz fixtures next to this file.
+
+Two environment shims, both recorded in every fixture's `meta`:
+
+1. `gguf` stub.  The reference imports gguf-py 0.17.1 (not installed, not
+   vendored) for three constants only: QK_K = 256, the GGMLQuantizationType ids
+   10..14 and GGML_QUANT_SIZES[Qn_K] = (256, {84,110,144,176,210}).
+
+2. IEEE sqrt.  torch.sqrt on CPU goes through MKL VML `vsSqrt` (VML_HA), which is
+   NOT correctly rounded: 0.6 % of results are 1 ulp below sqrtf (measured here,
+   deterministic per value).  The reference's CUDA path, the oracle and the HIP
+   kernels all use the IEEE-754 correctly rounded sqrt.  The "ieee" fixtures are
+   produced with `src.quant_utils.torch.sqrt` routed through numpy's correctly
+   rounded sqrt (module-local proxy; the reference source is untouched); the
+   "mkl" fixtures are produced with stock torch and are used by the tests only
+   to REPORT the resulting flip rate (make_k_quants near-ties), never as the
+   bit-exact anchor.
+
+Usage:  python tests/golden/make_golden.py   (rewrites tests/golden/*.npz)
+"""
+import enum
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference/quant/gptq"
+
+
+def _install_gguf_stub():
+    g = types.ModuleType("gguf")
+    c = types.ModuleType("gguf.constants")
+
+    class GGMLQuantizationType(enum.IntEnum):
+        Q2_K = 10
+        Q3_K = 11
+        Q4_K = 12
+        Q5_K = 13
+        Q6_K = 14
+
+    c.QK_K = 256
+    c.GGMLQuantizationType = GGMLQuantizationType
+    c.GGML_QUANT_SIZES = {
+        GGMLQuantizationType.Q2_K: (256, 84), GGMLQuantizationType.Q3_K: (256, 110),
+        GGMLQuantizationType.Q4_K: (256, 144), GGMLQuantizationType.Q5_K: (256, 176),
+        GGMLQuantizationType.Q6_K: (256, 210)}
+    g.constants = c
+    g.GGMLQuantizationType = GGMLQuantizationType
+    sys.modules["gguf"] = g
+    sys.modules["gguf.constants"] = c
+    sys.path.insert(0, REF)
+
+
+_install_gguf_stub()
+import src.quant_utils as ref_qu  # noqa: E402
+import src.packing_utils as ref_pk  # noqa: E402
+from src.gptq import GPTQ as RefGPTQ  # noqa: E402
+from src.quantizer import Quantizer as RefDriver  # noqa: E402
+
+T = ref_qu.GGMLQuantizationType
+
+
+class _TorchIEEE:
+    """torch proxy: sqrt is correctly rounded (numpy), everything else is torch."""
+
+    def __getattr__(self, k):
+        return getattr(torch, k)
+
+    @staticmethod
+    def sqrt(t):
+        if t.dtype not in (torch.float32, torch.float64):
+            return torch.sqrt(t)  # reduced floats never reach MKL VML (Vectorized<float>::sqrt is IEEE)
+        return torch.from_numpy(np.sqrt(t.detach().cpu().numpy())).to(t.device)
+
+
+def set_sqrt(mode):
+    ref_qu.torch = _TorchIEEE() if mode == "ieee" else torch
+
+
+META = dict(torch=torch.__version__, cpu_capability=torch.backends.cpu.get_cpu_capability(),
+            reference="IST-DASLab/gptq-gguf-toolkit @ 2025-09-19", numpy=np.__version__)
+
+
+def save(name, **arrs):
+    arrs["meta"] = np.array(repr(META))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **arrs)
+    sz = os.path.getsize(os.path.join(HERE, name + ".npz"))
+    print(f"  wrote {name}.npz ({sz / 1024:.0f} KiB)")
+
+
+def u16(t):
+    return t.contiguous().view(torch.int16).numpy().view(np.uint16)
+
+
+def configured(qt, **kw):
+    bits, _, smq, G, SG, sdt, _ = ref_qu.GGML_QUANT_SIZES[qt]
+    q = ref_qu.Quantizer()
+    q.configure(bits=bits, scale_maxq=smq, super_group_size=SG, group_size=G, group_type=sdt, **kw)
+    return q, bits, G
+
+
+def edge_rows(x, G):
+    """rows 0..9 of x[n,G] get the edge cases of SURVEY 8c/G1."""
+    x[0] = 0.01                       # all equal, positive
+    x[1] = 0.0                        # all zero
+    x[2] = x[2].abs()                 # all positive (min clamps to 0)
+    x[3, 5] = 3.0                     # one outlier
+    x[4] = 1e-41                      # fp32 denormals
+    x[5] = -x[5].abs()                # all negative
+    x[6] = 1e-7 * torch.randn(G)      # tiny magnitudes (D <= eps region)
+    x[7] = -0.02                      # all equal, negative
+    x[8, : G // 2] = 0.0              # half zeros
+    x[9] = torch.linspace(-0.05, 0.05, G)
+    return x
+
+
+def g1_make_quants():
+    out = {}
+    for mode in ("ieee", "mkl"):
+        set_sqrt(mode)
+        for qt in T:
+            torch.manual_seed(100 + int(qt))
+            q, bits, G = configured(qt)
+            x = edge_rows(torch.randn(512, G) * 0.02, G)
+            fn = q.make_k_quants if qt in (T.Q2_K, T.Q4_K, T.Q5_K) else q.make_quants
+            sc, ze = fn(x.clone())
+            if mode == "ieee":
+                out[f"{qt.name}_x"] = x.numpy()
+            out[f"{qt.name}_{mode}_scale"] = sc.flatten().numpy()
+            out[f"{qt.name}_{mode}_zero"] = ze.flatten().numpy()
+        # non-default search parameters (ieee only)
+    set_sqrt("ieee")
+    torch.manual_seed(7)
+    q, bits, G = configured(T.Q4_K, rmin=-0.5, rdelta=0.05, nstep=10)
+    x = torch.randn(256, G) * 0.05
+    sc, ze = q.make_k_quants(x.clone())
+    out["Q4_K_alt_x"], out["Q4_K_alt_scale"], out["Q4_K_alt_zero"] = x.numpy(), sc.numpy(), ze.numpy()
+    q, bits, G = configured(T.Q4_K, nstep=0)
+    sc, ze = q.make_k_quants(x.clone())
+    out["Q4_K_nstep0_scale"], out["Q4_K_nstep0_zero"] = sc.numpy(), ze.numpy()
+    save("g1_make_quants", **out)
+
+
+def g2_scale_search():
+    out = {}
+    for mode in ("ieee", "mkl"):
+        set_sqrt(mode)
+        for qt in T:
+            torch.manual_seed(200 + int(qt))
+            q, bits, G = configured(qt)
+            x = torch.randn(64, 256) * 0.02
+            x[0] = 0.0
+            x[1] = x[1].abs()           # all-positive super-group: dmin = -0.0 candidates
+            x[2, :64] *= 40.0           # one loud group
+            x[3] = 0.5
+            d, s, dmin, m = q.get_scale_and_zero(x.clone(), qt)
+            if mode == "ieee":
+                out[f"{qt.name}_x"] = x.numpy()
+            out[f"{qt.name}_{mode}_d"], out[f"{qt.name}_{mode}_dmin"] = u16(d), u16(dmin)
+            out[f"{qt.name}_{mode}_s"], out[f"{qt.name}_{mode}_m"] = s.numpy(), m.numpy()
+    save("g2_scale_search", **out)
+
+
+def g3_elementwise():
+    set_sqrt("ieee")
+    out = {}
+    torch.manual_seed(3)
+    n = 4096
+    for qt in T:
+        _, clamp, smq, G, _, sdt, _ = ref_qu.GGML_QUANT_SIZES[qt]
+        d = (torch.rand(n) * 2e-3).half()
+        dmin = (torch.rand(n) * 2e-3).half() if qt in (T.Q2_K, T.Q4_K, T.Q5_K) else torch.zeros(n).half()
+        s = torch.randint(0, smq + 1, (n,)).to(sdt)
+        m = torch.randint(0, smq + 1, (n,)).to(sdt) if qt in (T.Q2_K, T.Q4_K, T.Q5_K) else torch.zeros(n).to(sdt)
+        s[:64] = 0                                    # d*s == 0 -> eps clamp
+        x = torch.randn(n) * 0.05
+        # exact .5 ties: x = (k + 0.5) * d*s - dmin*m  (where representable)
+        ds = d.float() * s
+        x[64:512] = (torch.randint(-3, 8, (448,)).float() + 0.5) * ds[64:512] - dmin.float()[64:512] * m[64:512]
+        q = ref_qu.quantize(x, d, s, dmin, m, clamp)
+        w = ref_qu.dequantize(q, d, s, dmin, m)
+        out[f"{qt.name}_x"], out[f"{qt.name}_d"], out[f"{qt.name}_dmin"] = x.numpy(), u16(d), u16(dmin)
+        out[f"{qt.name}_s"], out[f"{qt.name}_m"] = s.numpy(), m.numpy()
+        out[f"{qt.name}_q"], out[f"{qt.name}_w"] = q.numpy(), w.numpy()
+    save("g3_elementwise", **out)
+
+
+def _mk_layer(R, C, seed):
+    torch.manual_seed(seed)
+    layer = nn.Linear(C, R, bias=False)
+    layer.weight.data = (torch.randn(R, C) * 0.02).half().float()
+    return layer
+
+
+def _calib(C, n_batches, L, seed, dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    sig = torch.exp(torch.randn(C, generator=g) * 0.5)
+    sig[:: max(C // 4, 1)] *= 20.0  # a few loud channels
+    return [(torch.randn(1, L, C, generator=g) * sig).to(dtype) for _ in range(n_batches)]
+
+
+def _triu_pack(U):
+    iu = np.triu_indices(U.shape[0])
+    assert np.all(np.tril(U, -1) == 0)
+    return U[iu].astype(np.float32)
+
+
+def g4_g5_hessian():
+    set_sqrt("ieee")
+    out = {}
+    C, R = 256, 32
+    layer = _mk_layer(R, C, 40)
+    for dt, tag in ((torch.float32, "f32"), (torch.float16, "f16"), (torch.bfloat16, "bf16")):
+        g = RefGPTQ(layer, rel_damp=0.01, block_size=128)
+        xs = _calib(C, 3, 64, 41, dt)
+        for x in xs:
+            g.update(x)
+        out[f"X_{tag}"] = np.stack([x[0].float().numpy() for x in xs])  # values exactly representable
+        out[f"H_{tag}"] = g.H.numpy().copy()
+    # 2-D input (MoE expert style): num_samples counts tokens (gptq.py:88)
+    g = RefGPTQ(layer)
+    x2 = _calib(C, 2, 48, 42)
+    for x in x2:
+        g.update(x[0])
+    out["X_2d"] = np.stack([x[0].numpy() for x in x2])
+    out["H_2d"] = g.H.numpy().copy()
+    out["n_2d"] = np.array(g.num_samples)
+
+    # G5: pre_step + _prepare, with a dead input channel and an all-zero weight column
+    layer = _mk_layer(R, C, 43)
+    layer.weight.data[:, 17] = 0.0
+    g = RefGPTQ(layer, rel_damp=0.01, block_size=128)
+    xs = _calib(C, 3, 256, 44)
+    for x in xs:
+        x[..., 5] = 0.0  # dead channel: H[5,5] == 0
+        g.update(x)
+    out["prep_H_in"] = g.H.numpy().copy()
+    out["prep_W_in"] = layer.weight.data.numpy().copy()
+    g.quantization_pre_step()
+    out["prep_W_after_prestep"] = g.W.numpy().copy()
+    U = g._prepare()
+    out["prep_U_triu"] = _triu_pack(U.numpy())
+    out["prep_H_after_diag"] = np.diag(g.H.numpy()).copy()
+    out["prep_H_after_row5"] = g.H.numpy()[5].copy()
+    out["prep_H_after_row17"] = g.H.numpy()[17].copy()
+    # singular H -> identity fallback (rel_damp = 0, rank-deficient H)
+    layer = _mk_layer(8, 256, 45)
+    g = RefGPTQ(layer, rel_damp=0.0)
+    xs = torch.randn(1, 16, 256)
+    g.update(xs)  # rank 16 < 256
+    out["sing_X"] = xs[0].numpy()
+    g.quantization_pre_step()
+    U = g._prepare()
+    out["sing_U_is_identity"] = np.array(bool(torch.equal(U, torch.eye(256))))
+    out["sing_flag"] = np.array(bool(getattr(g, "issue_non_invertible", False)))
+    save("g4_g5_hessian", **out)
+
+
+def _run_step(layer, xs, qt, block, static, mode):
+    set_sqrt(mode)
+    g = RefGPTQ(layer, rel_damp=0.01, block_size=block, static_groups=static)
+    for x in xs:
+        g.update(x)
+    g.quantization_pre_step()
+    W0 = g.W.numpy().copy()
+    cap = {}
+    orig = g._prepare
+
+    def prep():
+        u = orig()
+        cap["U"] = u.clone()
+        return u
+
+    g._prepare = prep
+    q, d, s, dmin, m = g.step(qt)
+    return W0, cap["U"].numpy(), (q.numpy(), u16(d), s.numpy(), u16(dmin), m.numpy(), g.W.numpy().copy())
+
+
+def _pack_ref(qt, q, d, s, dmin, m):
+    a = [torch.from_numpy(np.array(v)) for v in (q, d, s, dmin, m)]
+    a[1] = a[1].view(torch.float16) if a[1].dtype != torch.float16 else a[1]
+    a[3] = a[3].view(torch.float16) if a[3].dtype != torch.float16 else a[3]
+    if qt == T.Q2_K:
+        return ref_pk.pack_Q2K(*a)
+    if qt == T.Q3_K:
+        return ref_pk.pack_Q3K(a[0], a[1], a[2])
+    if qt == T.Q4_K:
+        return ref_pk.pack_Q4K(*a)
+    if qt == T.Q5_K:
+        return ref_pk.pack_Q5K(*a)
+    return ref_pk.pack_Q6K(a[0], a[1], a[2])
+
+
+def g6_g7_step_and_pack():
+    out = {}
+    # case A: 64 x 512, every type, block 128 (+ variants), one shared (W, U)
+    R, C = 64, 512
+    layer = _mk_layer(R, C, 60)
+    xs = _calib(C, 4, 256, 61)
+    cases = [(qt, 128, False) for qt in T] + [(T.Q4_K, 64, False), (T.Q4_K, 128, True), (T.Q2_K, 128, True),
+                                              (T.Q5_K, None, False), (T.Q6_K, 256, False)]
+    for qt, block, static in cases:
+        tag = f"A_{qt.name}_b{block}_s{int(static)}"
+        W0, U, res = _run_step(layer, xs, qt, block, static, "ieee")
+        if "A_W0" not in out:
+            out["A_W0"], out["A_U_triu"] = W0, _triu_pack(U)
+        else:
+            assert np.array_equal(out["A_W0"], W0) and np.array_equal(out["A_U_triu"], _triu_pack(U))
+        for k, v in zip(("q", "d", "s", "dmin", "m", "Wdeq"), res):
+            if k == "Wdeq":
+                # Wdeq is exactly dequantize(q,...) (gptq.py:266) -- store a checksum only
+                out[f"{tag}_Wdeq_sum"] = np.array(v.astype(np.float64).sum())
+                out[f"{tag}_Wdeq_head"] = v[:4, :64].copy()
+            else:
+                out[f"{tag}_{k}"] = v
+        if block == 128 and not static:
+            out[f"{tag}_packed"] = _pack_ref(qt, *res[:5])  # G7
+            # flip rate vs stock-MKL sqrt, for the record
+            _, _, res_mkl = _run_step(layer, xs, qt, block, static, "mkl")
+            out[f"{tag}_mklsqrt_q"] = res_mkl[0]
+            out[f"{tag}_mklsqrt_s"] = res_mkl[2]
+    # case B: 96 x 768 Q4_K / Q3_K block 128
+    R, C = 96, 768
+    layer = _mk_layer(R, C, 62)
+    xs = _calib(C, 4, 384, 63)
+    for qt in (T.Q4_K, T.Q3_K):
+        tag = f"B_{qt.name}_b128_s0"
+        W0, U, res = _run_step(layer, xs, qt, 128, False, "ieee")
+        if "B_W0" not in out:
+            out["B_W0"], out["B_U_triu"] = W0, _triu_pack(U)
+        for k, v in zip(("q", "d", "s", "dmin", "m"), res[:5]):
+            out[f"{tag}_{k}"] = v
+        out[f"{tag}_packed"] = _pack_ref(qt, *res[:5])
+    save("g6_g7_step_and_pack", **out)
+
+
+def g8_g9_rtn_dequant():
+    set_sqrt("ieee")
+    out = {}
+    R, C = 48, 768
+    torch.manual_seed(90)
+    W = torch.randn(R, C) * 0.02
+    W[:, 5] = W[:, 5].abs() * 30
+    W[3, :256] = W[3, :256].abs()
+    W[4] = 0.0
+    out["W"] = W.numpy()
+    drv = RefDriver.__new__(RefDriver)
+    drv.quantizer_kwargs = {}
+    for qt in T:
+        q, d, s, dmin, m = drv._quant_non_block_module(W.clone(), qt)
+        deq = ref_qu.dequantize_linear_weight(qt, q, d, s, dmin, m)
+        out[f"{qt.name}_q"], out[f"{qt.name}_d"], out[f"{qt.name}_dmin"] = q.numpy(), u16(d), u16(dmin)
+        out[f"{qt.name}_s"], out[f"{qt.name}_m"] = s.numpy(), m.numpy()
+        out[f"{qt.name}_deq"] = deq.numpy()
+        out[f"{qt.name}_packed"] = _pack_ref(qt, q.numpy(), u16(d), s.numpy(), u16(dmin), m.numpy())
+    # model-dtype RTN (quantizer.py:109,195 pass module.weight un-cast): bf16 / fp16
+    for dt, tag in ((torch.float16, "f16"), (torch.bfloat16, "bf16")):
+        Wl = W.to(dt)
+        out[f"W_{tag}"] = Wl.float().numpy()
+        for qt in (T.Q4_K, T.Q6_K):
+            q, d, s, dmin, m = drv._quant_non_block_module(Wl.clone(), qt)
+            out[f"{tag}_{qt.name}_q"] = q.numpy()
+            out[f"{tag}_{qt.name}_d"], out[f"{tag}_{qt.name}_dmin"] = u16(d), u16(dmin)
+            out[f"{tag}_{qt.name}_s"], out[f"{tag}_{qt.name}_m"] = s.numpy(), m.numpy()
+    save("g8_g9_rtn_dequant", **out)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    for fn in (g1_make_quants, g2_scale_search, g3_elementwise, g4_g5_hessian, g6_g7_step_and_pack,
+               g8_g9_rtn_dequant):
+        print(fn.__name__)
+        fn()

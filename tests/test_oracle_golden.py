@@ -1,0 +1,193 @@
+"""CPU oracle (oracle/gq_oracle.c) pinned against outputs of the reference itself.
+
+Fixtures: tests/golden/*.npz, produced by tests/golden/make_golden.py which imports
+/root/reference in the build container.  Bit-exact everywhere except the two
+fp32 linear-algebra stages (H accumulate, Cholesky chain) which are tolerance-class
+(SURVEY 7 "hard parts": the reference is not bit-stable there between its own CPU
+and CUDA runs either).
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden, triu_unpack
+
+TYPES = {"Q2_K": 10, "Q3_K": 11, "Q4_K": 12, "Q5_K": 13, "Q6_K": 14}
+K_TYPES = ("Q2_K", "Q4_K", "Q5_K")
+
+
+def bits_eq(a, b):
+    return np.array_equal(np.ascontiguousarray(a, np.float32).view(np.uint32),
+                          np.ascontiguousarray(b, np.float32).view(np.uint32))
+
+
+def test_type_table(oracle):
+    # reference quant_utils.py:19-26
+    exp = {10: (2, 0, 3, 15, 16, 0, 84), 11: (3, -4, 3, 31, 16, 1, 110), 12: (4, 0, 15, 63, 32, 0, 144),
+           13: (5, 0, 31, 63, 32, 0, 176), 14: (6, -32, 31, 63, 16, 1, 210)}
+    for t, e in exp.items():
+        ti = oracle.type_info(t)
+        assert (ti["bits"], ti["qmin"], ti["qmax"], ti["scale_maxq"], ti["group"], ti["is_signed"],
+                ti["type_size"]) == e
+    with pytest.raises(ValueError):
+        oracle.type_info(2)
+
+
+def test_f16_roundtrip(oracle):
+    L = oracle.lib()
+    rng = np.random.default_rng(0)
+    f = np.concatenate([rng.standard_normal(20000).astype(np.float32) * s for s in (1e-8, 1e-5, 1e-3, 1, 1e3, 1e5)]
+                       + [np.array([0.0, -0.0, 65504.0, 65520.0, 65519.99, 5.96e-8, 2.98e-8, 2.9802322e-8,
+                                    6.1e-5, np.inf, -np.inf], np.float32)])
+    with np.errstate(over="ignore"):
+        want = f.astype(np.float16).view(np.uint16)
+    got = np.array([L.gqo_f32_to_f16(float(v)) for v in f], np.uint16)
+    assert np.array_equal(want, got)
+
+
+@pytest.mark.parametrize("name", list(TYPES))
+def test_g1_make_quants(oracle, name):
+    g = load_golden("g1_make_quants")
+    x = g[f"{name}_x"]
+    bits = oracle.type_info(TYPES[name])["bits"]
+    sc, ze = (oracle.make_k_quants if name in K_TYPES else oracle.make_quants)(x, bits)
+    assert bits_eq(sc, g[f"{name}_ieee_scale"]), "group scales differ from the reference"
+    assert bits_eq(ze, g[f"{name}_ieee_zero"]), "group zeros differ from the reference (incl. -0.0)"
+    # for the record: the stock-MKL-sqrt reference run differs only through 1-ulp av_x
+    flips = (sc.view(np.uint32) != g[f"{name}_mkl_scale"].view(np.uint32)).mean()
+    assert flips < 0.02, f"{name}: {flips:.3%} of group scales differ vs the MKL-sqrt run"
+
+
+def test_g1_search_params(oracle):
+    g = load_golden("g1_make_quants")
+    sc, ze = oracle.make_k_quants(g["Q4_K_alt_x"], 4, rmin=-0.5, rdelta=0.05, nstep=10)
+    assert bits_eq(sc, g["Q4_K_alt_scale"]) and bits_eq(ze, g["Q4_K_alt_zero"])
+    sc, ze = oracle.make_k_quants(g["Q4_K_alt_x"], 4, nstep=0)
+    assert bits_eq(sc, g["Q4_K_nstep0_scale"]) and bits_eq(ze, g["Q4_K_nstep0_zero"])
+
+
+@pytest.mark.parametrize("name", list(TYPES))
+def test_g2_scale_search(oracle, name):
+    g = load_golden("g2_scale_search")
+    d, s, dmin, m = oracle.scale_search(g[f"{name}_x"], TYPES[name])
+    assert np.array_equal(d, g[f"{name}_ieee_d"])
+    assert np.array_equal(dmin, g[f"{name}_ieee_dmin"])
+    assert np.array_equal(s, g[f"{name}_ieee_s"]) and s.dtype == g[f"{name}_ieee_s"].dtype
+    assert np.array_equal(m, g[f"{name}_ieee_m"])
+
+
+@pytest.mark.parametrize("name", list(TYPES))
+def test_g3_elementwise(oracle, name):
+    g = load_golden("g3_elementwise")
+    L = oracle.lib()
+    ti = oracle.type_info(TYPES[name])
+    x, d, dmin, s, m = (g[f"{name}_{k}"] for k in ("x", "d", "dmin", "s", "m"))
+    L.gqo_quantize1.restype = L.gqo_dequantize1.restype = __import__("ctypes").c_float
+    import ctypes
+    L.gqo_quantize1.argtypes = [ctypes.c_float, ctypes.c_uint16, ctypes.c_int, ctypes.c_uint16, ctypes.c_int,
+                                ctypes.c_int, ctypes.c_int]
+    L.gqo_dequantize1.argtypes = [ctypes.c_float, ctypes.c_uint16, ctypes.c_int, ctypes.c_uint16, ctypes.c_int]
+    q = np.array([L.gqo_quantize1(float(x[i]), int(d[i]), int(s[i]), int(dmin[i]), int(m[i]), ti["qmin"], ti["qmax"])
+                  for i in range(len(x))], np.float32)
+    assert np.array_equal(q, g[f"{name}_q"])
+    w = np.array([L.gqo_dequantize1(float(q[i]), int(d[i]), int(s[i]), int(dmin[i]), int(m[i]))
+                  for i in range(len(x))], np.float32)
+    assert bits_eq(w, g[f"{name}_w"])
+
+
+def test_g4_h_accumulate(oracle):
+    g = load_golden("g4_g5_hessian")
+    for tag in ("f32", "f16", "bf16"):
+        X = g[f"X_{tag}"]  # [3, L, C], b = 1 per update (3-D input: gptq.py:88)
+        C = X.shape[-1]
+        H = np.zeros((C, C), np.float32)
+        n = 0
+        for xb in X:
+            H = oracle.h_accumulate(H, xb, n / (n + 1), 2.0 / (n + 1))
+            n += 1
+        ref = g[f"H_{tag}"]
+        assert np.abs(H - ref).max() <= 2e-6 * np.abs(ref).max()
+    X = g["X_2d"]
+    H = np.zeros((X.shape[-1],) * 2, np.float32)
+    n = 0
+    for xb in X:  # 2-D input: b = #tokens
+        b = xb.shape[0]
+        H = oracle.h_accumulate(H, xb, n / (n + b), 2.0 / (n + b))
+        n += b
+    assert n == int(g["n_2d"])
+    assert np.abs(H - g["H_2d"]).max() <= 2e-6 * np.abs(g["H_2d"]).max()
+
+
+def test_g5_h_prepare(oracle):
+    g = load_golden("g4_g5_hessian")
+    H, W = g["prep_H_in"], g["prep_W_in"]
+    C = H.shape[0]
+    U, H2, W2, bad = oracle.h_prepare(H, W, 0.01)
+    assert not bad
+    assert np.array_equal(W2, g["prep_W_after_prestep"])  # dead channel 5 zeroed
+    assert np.allclose(np.diag(H2), g["prep_H_after_diag"], rtol=1e-6)
+    for r in (5, 17):  # dead channel / zero weight column: row zeroed, diag 1 + damp
+        assert np.allclose(H2[r], g[f"prep_H_after_row{r}"], rtol=1e-6, atol=0)
+    Uref = triu_unpack(g["prep_U_triu"], C)
+    assert np.all(np.tril(U, -1) == 0)
+    assert np.abs(U - Uref).max() <= 1e-4 * np.abs(Uref).max()
+    # singular H (rank 16 of 256, no damping) -> identity fallback, like the reference
+    X = g["sing_X"]
+    Hs = oracle.h_accumulate(np.zeros((256, 256), np.float32), X, 0.0, 2.0)
+    U, _, _, bad = oracle.h_prepare(Hs, np.ones((8, 256), np.float32), 0.0)
+    assert bool(g["sing_U_is_identity"]) and bool(g["sing_flag"])
+    assert bad and np.array_equal(U, np.eye(256, dtype=np.float32))
+
+
+def _g6_cases():
+    g = load_golden("g6_g7_step_and_pack")
+    tags = sorted({k.rsplit("_", 1)[0] for k in g.files if k.endswith("_q") and "mklsqrt" not in k})
+    return tags
+
+
+@pytest.mark.parametrize("tag", _g6_cases())
+def test_g6_step(oracle, tag):
+    g = load_golden("g6_g7_step_and_pack")
+    case, name1, name2, b, s = tag.split("_")
+    name = f"{name1}_{name2}"
+    block = None if b == "bNone" else int(b[1:])
+    static = s == "s1"
+    W0 = g[f"{case}_W0"]
+    U = triu_unpack(g[f"{case}_U_triu"], W0.shape[1])
+    Wd, q, d, sc, dmin, m = oracle.gptq_step(W0, U, TYPES[name], block_size=block, static_groups=static)
+    assert np.array_equal(q, g[f"{tag}_q"]), f"{(q != g[f'{tag}_q']).mean():.4%} ints differ"
+    assert np.array_equal(d, g[f"{tag}_d"]) and np.array_equal(dmin, g[f"{tag}_dmin"])
+    assert np.array_equal(sc, g[f"{tag}_s"]) and np.array_equal(m, g[f"{tag}_m"])
+    if f"{tag}_Wdeq_head" in g.files:
+        assert bits_eq(Wd[:4, :64], g[f"{tag}_Wdeq_head"])
+        assert float(Wd.astype(np.float64).sum()) == float(g[f"{tag}_Wdeq_sum"])
+    # gptq.py:266: the final working copy IS the dequantized matrix (up to the sign of
+    # zero: q = rint(tiny negative) = -0.0 dequantizes to -0.0, the stored uint8 0 to +0.0)
+    assert np.array_equal(Wd, oracle.dequantize(TYPES[name], q, d, sc, dmin, m))
+    if f"{tag}_packed" in g.files:  # G7
+        assert np.array_equal(oracle.pack(TYPES[name], q, d, sc, dmin, m), g[f"{tag}_packed"])
+    if f"{tag}_mklsqrt_q" in g.files:
+        flips = (q != g[f"{tag}_mklsqrt_q"]).mean()
+        assert flips < 0.05, f"{flips:.3%} ints differ vs the stock-MKL-sqrt reference run"
+
+
+@pytest.mark.parametrize("name", list(TYPES))
+def test_g8_g9_rtn_dequant_pack(oracle, name):
+    g = load_golden("g8_g9_rtn_dequant")
+    t = TYPES[name]
+    q, d, s, dmin, m = oracle.rtn_quantize(g["W"], t)
+    assert np.array_equal(q, g[f"{name}_q"]) and q.dtype == g[f"{name}_q"].dtype
+    assert np.array_equal(d, g[f"{name}_d"]) and np.array_equal(dmin, g[f"{name}_dmin"])
+    assert np.array_equal(s, g[f"{name}_s"]) and np.array_equal(m, g[f"{name}_m"])
+    assert bits_eq(oracle.dequantize(t, q, d, s, dmin, m), g[f"{name}_deq"])
+    packed = oracle.pack(t, q, d, s, dmin, m)
+    assert packed.shape == g[f"{name}_packed"].shape and np.array_equal(packed, g[f"{name}_packed"])
+
+
+def test_pack_does_not_mutate_inputs(oracle):
+    # reference pack_Q3K / pack_Q6K offset their inputs in place (packing_utils.py:94-95, 279)
+    g = load_golden("g8_g9_rtn_dequant")
+    for name in ("Q3_K", "Q6_K"):
+        q, d, s = g[f"{name}_q"].copy(), g[f"{name}_d"], g[f"{name}_s"].copy()
+        q0, s0 = q.copy(), s.copy()
+        oracle.pack(TYPES[name], q, d, s)
+        assert np.array_equal(q, q0) and np.array_equal(s, s0)
