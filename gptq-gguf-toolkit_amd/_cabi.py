@@ -1,0 +1,87 @@
+"""ctypes binding of libgptqgguf_hip.so (include/gptq_gguf.h).
+
+This is the ONLY compute backend of the package: there is no CPU or torch fallback.
+If the shared library is missing or a call fails, the error is raised to the caller.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+SO_PATH = os.path.join(CSRC, "libgptqgguf_hip.so")
+
+F32, F16, BF16 = 0, 1, 2
+WS_H_ACCUMULATE, WS_H_PREPARE, WS_GPTQ_QUANTIZE = 1, 2, 3
+
+EXPORTS = (
+    "gq_abi_version", "gq_last_error", "gq_type_info", "gq_workspace_bytes", "gq_h_accumulate", "gq_h_prepare",
+    "gq_scale_search", "gq_gptq_quantize", "gq_rtn_quantize", "gq_dequantize", "gq_pack", "gq_trailing_update",
+)
+
+
+class GQError(RuntimeError):
+    pass
+
+
+class TypeInfo(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int) for n in
+                ("bits", "qmin", "qmax", "scale_maxq", "group", "is_signed", "k_search", "type_size")]
+
+
+class Search(ctypes.Structure):
+    _fields_ = [("rmin", ctypes.c_double), ("rdelta", ctypes.c_double), ("nstep", ctypes.c_int)]
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP sources for gfx950 (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-C", CSRC, "-s", "-j8"]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args)
+    return SO_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise GQError(
+            f"{SO_PATH} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` (or `make -C {CSRC}`). There is no CPU fallback.")
+    L = ctypes.CDLL(SO_PATH)
+    vp, i64, ci, cf, sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+    sp = ctypes.POINTER(Search)
+    L.gq_abi_version.restype = ci
+    L.gq_last_error.restype = ctypes.c_char_p
+    L.gq_type_info.argtypes = [ci, ctypes.POINTER(TypeInfo)]
+    L.gq_workspace_bytes.argtypes = [ci, i64, i64, i64, ci]
+    L.gq_workspace_bytes.restype = sz
+    L.gq_h_accumulate.argtypes = [vp, vp, ci, i64, i64, cf, cf, vp, sz, vp]
+    L.gq_h_prepare.argtypes = [vp, vp, i64, i64, cf, vp, vp, vp, sz, vp]
+    L.gq_scale_search.argtypes = [vp, i64, i64, ci, sp, vp, i64, vp, i64, vp, i64, vp, i64, vp]
+    L.gq_gptq_quantize.argtypes = [vp, vp, i64, i64, ci, ci, ci, sp, vp, vp, vp, vp, vp, vp, sz, vp]
+    L.gq_rtn_quantize.argtypes = [vp, ci, i64, i64, ci, sp, vp, vp, vp, vp, vp, vp]
+    L.gq_dequantize.argtypes = [ci, vp, vp, vp, vp, vp, i64, i64, vp, ci, vp]
+    L.gq_pack.argtypes = [ci, vp, vp, vp, vp, vp, i64, i64, vp, vp]
+    L.gq_trailing_update.argtypes = [vp, i64, vp, i64, vp, i64, i64, i64, i64, vp]
+    for name in EXPORTS:
+        getattr(L, name)  # raises AttributeError if the .so lacks a declared symbol
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().gq_last_error().decode(errors="replace")
+        raise GQError(f"{what} failed (status {rc}): {msg}")
+
+
+def type_info(q_type: int) -> dict:
+    t = TypeInfo()
+    check(lib().gq_type_info(int(q_type), ctypes.byref(t)), "gq_type_info")
+    return {n: getattr(t, n) for n, _ in TypeInfo._fields_}

@@ -1,0 +1,118 @@
+// gq_api.hip -- extern "C" surface of libgptqgguf_hip.so (see include/gptq_gguf.h).
+#include "gq_common.hpp"
+
+namespace gq {
+thread_local char g_err[512] = "";
+
+int launch_scale_search(const float*, int64_t, int64_t, int, const gq_search_t*, uint16_t*, int64_t, uint8_t*, int64_t,
+                        uint16_t*, int64_t, uint8_t*, int64_t, hipStream_t);
+int launch_dequantize(int, const uint8_t*, const uint16_t*, const uint8_t*, const uint16_t*, const uint8_t*, int64_t,
+                      int64_t, void*, int, hipStream_t);
+int launch_rtn_elementwise(const void*, int, const uint16_t*, const uint8_t*, const uint16_t*, const uint8_t*, int64_t,
+                           int64_t, const TypeInfo&, uint8_t*, hipStream_t);
+int launch_rtn_scale_search(const void*, int, int64_t, int64_t, int, const gq_search_t*, uint16_t*, uint8_t*, uint16_t*,
+                            uint8_t*, hipStream_t);
+int launch_pack(int, const uint8_t*, const uint16_t*, const uint8_t*, const uint16_t*, const uint8_t*, int64_t, int64_t,
+                uint8_t*, hipStream_t);
+int launch_trailing_update(float*, int64_t, const float*, int64_t, const float*, int64_t, int64_t, int64_t, int64_t,
+                           hipStream_t);
+size_t gptq_workspace_bytes(int64_t, int64_t, int);
+int gptq_quantize(float*, const float*, int64_t, int64_t, int, int, int, const gq_search_t*, uint8_t*, uint16_t*,
+                  uint8_t*, uint16_t*, uint8_t*, void*, size_t, hipStream_t);
+size_t h_accumulate_workspace_bytes(int64_t, int64_t);
+int h_accumulate(float*, const void*, int, int64_t, int64_t, float, float, void*, size_t, hipStream_t);
+size_t h_prepare_workspace_bytes(int64_t, int64_t);
+int h_prepare(float*, float*, int64_t, int64_t, float, float*, int*, void*, size_t, hipStream_t);
+}  // namespace gq
+
+using namespace gq;
+
+extern "C" {
+
+int gq_abi_version(void) { return GQ_ABI_VERSION; }
+const char* gq_last_error(void) { return g_err; }
+
+int gq_type_info(int q_type, gq_type_info_t* out) {
+    TypeInfo t;
+    if (!out) GQ_FAIL(GQ_E_NULL, "gq_type_info: null out");
+    if (!type_info(q_type, t)) GQ_FAIL(GQ_E_BAD_TYPE, "gq_type_info: unknown q_type %d", q_type);
+    out->bits = t.bits; out->qmin = t.qmin; out->qmax = t.qmax; out->scale_maxq = t.scale_maxq;
+    out->group = t.group; out->is_signed = t.is_signed; out->k_search = t.k_search; out->type_size = t.type_size;
+    return GQ_OK;
+}
+
+size_t gq_workspace_bytes(int op, int64_t R, int64_t C, int64_t T, int block_size) {
+    switch (op) {
+    case GQ_WS_H_ACCUMULATE: return h_accumulate_workspace_bytes(T, C);
+    case GQ_WS_H_PREPARE: return h_prepare_workspace_bytes(R, C);
+    case GQ_WS_GPTQ_QUANTIZE: return gptq_workspace_bytes(R, C, block_size);
+    default: return 0;
+    }
+}
+
+int gq_h_accumulate(float* H, const void* X, int x_dtype, int64_t T, int64_t C, float beta, float alpha, void* ws,
+                    size_t ws_bytes, void* stream) {
+    return h_accumulate(H, X, x_dtype, T, C, beta, alpha, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int gq_h_prepare(float* H, float* W, int64_t R, int64_t C, float rel_damp, float* U, int* not_invertible, void* ws,
+                 size_t ws_bytes, void* stream) {
+    return h_prepare(H, W, R, C, rel_damp, U, not_invertible, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int gq_scale_search(const float* x, int64_t rows, int64_t ld, int q_type, const gq_search_t* p, uint16_t* d,
+                    int64_t d_stride, uint8_t* s, int64_t s_ld, uint16_t* dmin, int64_t dmin_stride, uint8_t* m,
+                    int64_t m_ld, void* stream) {
+    if (!x || !d || !s || !dmin || !m) GQ_FAIL(GQ_E_NULL, "gq_scale_search: null pointer");
+    return launch_scale_search(x, rows, ld, q_type, p, d, d_stride, s, s_ld, dmin, dmin_stride, m, m_ld,
+                               (hipStream_t)stream);
+}
+
+int gq_gptq_quantize(float* W, const float* U, int64_t R, int64_t C, int q_type, int block_size, int static_groups,
+                     const gq_search_t* p, uint8_t* qweight, uint16_t* d, uint8_t* s, uint16_t* dmin, uint8_t* m,
+                     void* ws, size_t ws_bytes, void* stream) {
+    return gptq_quantize(W, U, R, C, q_type, block_size, static_groups, p, qweight, d, s, dmin, m, ws, ws_bytes,
+                         (hipStream_t)stream);
+}
+
+int gq_rtn_quantize(const void* W, int w_dtype, int64_t R, int64_t C, int q_type, const gq_search_t* p,
+                    uint8_t* qweight, uint16_t* d, uint8_t* s, uint16_t* dmin, uint8_t* m, void* stream) {
+    TypeInfo ti;
+    if (!type_info(q_type, ti)) GQ_FAIL(GQ_E_BAD_TYPE, "gq_rtn_quantize: unknown q_type %d", q_type);
+    if (R <= 0 || C <= 0 || C % 256) GQ_FAIL(GQ_E_BAD_SHAPE, "gq_rtn_quantize: R=%ld C=%ld", (long)R, (long)C);
+    if (!W || !qweight || !d || !s || !dmin || !m) GQ_FAIL(GQ_E_NULL, "gq_rtn_quantize: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if (w_dtype == GQ_F32) {
+        const float* Wf = (const float*)W;
+        const int64_t ng = C / ti.group, nsg = C / 256;
+        const int gps = 256 / ti.group;
+        for (int64_t c = 0; c < C; c += 256)  // quantizer.py:300-310
+            if ((rc = launch_scale_search(Wf + c, R, C, q_type, p, d + c / 256, nsg, s + (c / 256) * gps, ng,
+                                          dmin + c / 256, nsg, m + (c / 256) * gps, ng, st)))
+                return rc;
+    } else {
+        // the reference runs make_*quants in the model dtype (quantizer.py:109,195)
+        if ((rc = launch_rtn_scale_search(W, w_dtype, R, C, q_type, p, d, s, dmin, m, st))) return rc;
+    }
+    return launch_rtn_elementwise(W, w_dtype, d, s, dmin, m, R, C, ti, qweight, st);
+}
+
+int gq_dequantize(int q_type, const uint8_t* qweight, const uint16_t* d, const uint8_t* s, const uint16_t* dmin,
+                  const uint8_t* m, int64_t R, int64_t C, void* out, int out_dtype, void* stream) {
+    if (!qweight || !d || !s || !dmin || !m || !out) GQ_FAIL(GQ_E_NULL, "gq_dequantize: null pointer");
+    return launch_dequantize(q_type, qweight, d, s, dmin, m, R, C, out, out_dtype, (hipStream_t)stream);
+}
+
+int gq_pack(int q_type, const uint8_t* qweight, const uint16_t* d, const uint8_t* s, const uint16_t* dmin,
+            const uint8_t* m, int64_t R, int64_t C, uint8_t* out, void* stream) {
+    return launch_pack(q_type, qweight, d, s, dmin, m, R, C, out, (hipStream_t)stream);
+}
+
+int gq_trailing_update(float* Cmat, int64_t ldc, const float* A, int64_t lda, const float* B, int64_t ldb, int64_t M,
+                       int64_t N, int64_t K, void* stream) {
+    if (!Cmat || !A || !B) GQ_FAIL(GQ_E_NULL, "gq_trailing_update: null pointer");
+    return launch_trailing_update(Cmat, ldc, A, lda, B, ldb, M, N, K, (hipStream_t)stream);
+}
+
+}  // extern "C"

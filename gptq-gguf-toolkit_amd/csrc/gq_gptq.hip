@@ -1,0 +1,224 @@
+// gq_gptq.hip -- K5 (per-column quantize + in-block error feedback), K6 (blocked
+// trailing update) and the per-Linear orchestration of GPTQ.step.
+//
+// Reference: gptq.py:145-276.  Rows of W are independent given U, so K5 gives one
+// LANE to a row (a wave = 64 rows) and walks the columns of a block in program
+// order; U is wave-uniform and arrives through the scalar cache.  K6 is the
+// GEMM W[:, c2:] -= Err[R,B] @ U[c1:c2, c2:] on the fp32 matrix cores
+// (v_mfma_f32_32x32x2_f32 == a k-ordered fmaf chain, which is what the reference's
+// sgemm computes per element -- verified bit-for-bit in tests/golden G6).
+#include "gq_common.hpp"
+#include "gq_gemm32.hpp"
+
+namespace gq {
+
+int launch_scale_search(const float* x, int64_t rows, int64_t ld, int q_type, const gq_search_t* p,
+                        uint16_t* d, int64_t d_stride, uint8_t* s, int64_t s_ld, uint16_t* dmin,
+                        int64_t dmin_stride, uint8_t* m, int64_t m_ld, hipStream_t st);
+
+// ---------------------------------------------------------------- K5 segment
+// Processes columns [a, a+len) (len <= 128, a % 16 == 0, len % 16 == 0) of the
+// current block for 64 rows per wave.
+//   src   : working values of these columns (W itself when the block is a single
+//           segment, else the block scratch), row stride ld_src, already offset to
+//           column a
+//   W     : receives the dequantized column (gptq.py:266), row stride C
+//   Err   : receives err (gptq.py:268) at column (a - c1) + i, row stride ld_err
+//   qparams d/dmin [R, C/256], s/m [R, C/G] already hold the super-group of `a`
+constexpr int SEG = 128;
+constexpr int SB = 16;  // register sub-block
+
+__global__ __launch_bounds__(64) void gptq_segment_kernel(
+    float* W, int64_t C, const float* src, int64_t ld_src,  // may alias (single-segment blocks)
+    const float* __restrict__ U, int64_t a, int len, int64_t R,
+    const uint16_t* __restrict__ d, const uint8_t* __restrict__ s, const uint16_t* __restrict__ dmin,
+    const uint8_t* __restrict__ m, int G, int is_signed, float qmin, float qmax,
+    uint8_t* __restrict__ qweight, float* __restrict__ Err, int64_t ld_err, int64_t err_col0) {
+    __shared__ float wl[SEG * 64];  // wl[j*64 + lane]: working copy, column-major per wave
+    const int lane = threadIdx.x;
+    const int64_t row = (int64_t)blockIdx.x * 64 + lane;
+    const bool live = row < R;
+    const int64_t r = live ? row : 0;
+
+    // gptq.py:225 w_blk = w[:, c1:c2].clone()
+    {
+        const float* sp = src + r * ld_src;
+        for (int j = 0; j < len; j += 4) {
+            float4 v = *reinterpret_cast<const float4*>(sp + j);
+            wl[(j + 0) * 64 + lane] = v.x;
+            wl[(j + 1) * 64 + lane] = v.y;
+            wl[(j + 2) * 64 + lane] = v.z;
+            wl[(j + 3) * 64 + lane] = v.w;
+        }
+    }
+    const int64_t nsg = C / 256, ng = C / G;
+
+    for (int i0 = 0; i0 < len; i0 += SB) {
+        const int64_t col0 = a + i0;
+        // group parameters are constant over a 16-aligned run of 16 columns
+        const float ds = h2f(d[r * nsg + col0 / 256]) * ival(s[r * ng + col0 / G], is_signed);
+        const float dm = h2f(dmin[r * nsg + col0 / 256]) * ival(m[r * ng + col0 / G], is_signed);
+        float wr[SB], nerr[SB], wq[SB];
+        uint32_t qpack[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < SB; ++k) wr[k] = wl[(i0 + k) * 64 + lane];
+#pragma unroll
+        for (int k = 0; k < SB; ++k) {
+            const float* urow = U + (col0 + k) * C + col0;  // wave-uniform -> scalar loads
+            const float dii = urow[k];
+            const float q = quantize1(wr[k], ds, dm, qmin, qmax);  // gptq.py:247-254
+            wq[k] = dequantize1(q, ds, dm);                        // :255-261
+            const float err = (wr[k] - wq[k]) / dii;               // :264
+            const uint8_t qb = is_signed ? (uint8_t)(int8_t)q : (uint8_t)q;
+            qpack[k >> 2] |= (uint32_t)qb << (8 * (k & 3));
+            // :267 addr_(err, U[i, i:], alpha=-1): self + (alpha*err)*u, two roundings
+            const float ne = -err;
+            nerr[k] = ne;
+#pragma unroll
+            for (int kk = k; kk < SB; ++kk) wr[kk] = wr[kk] + ne * urow[kk];
+        }
+        if (live) {
+            *reinterpret_cast<uint4*>(qweight + row * C + col0) = make_uint4(qpack[0], qpack[1], qpack[2], qpack[3]);
+            float* wp = W + row * C + col0;
+            float* ep = Err + row * ld_err + err_col0 + i0;
+#pragma unroll
+            for (int k = 0; k < SB; k += 4) {
+                *reinterpret_cast<float4*>(wp + k) = make_float4(wq[k], wq[k + 1], wq[k + 2], wq[k + 3]);
+                *reinterpret_cast<float4*>(ep + k) = make_float4(-nerr[k], -nerr[k + 1], -nerr[k + 2], -nerr[k + 3]);
+            }
+        }
+        // rank-1 updates of the later columns of this segment, 16 columns at a time;
+        // each element sees the same sequence of (mul, add) pairs, in the same
+        // order of i, as the reference's 16 successive addr_ calls.
+        for (int j0 = i0 + SB; j0 < len; j0 += SB) {
+            float wt[SB];
+#pragma unroll
+            for (int jj = 0; jj < SB; ++jj) wt[jj] = wl[(j0 + jj) * 64 + lane];
+#pragma unroll
+            for (int k = 0; k < SB; ++k) {
+                const float* urow = U + (col0 + k) * C + a + j0;
+#pragma unroll
+                for (int jj = 0; jj < SB; ++jj) wt[jj] = wt[jj] + nerr[k] * urow[jj];
+            }
+#pragma unroll
+            for (int jj = 0; jj < SB; ++jj) wl[(j0 + jj) * 64 + lane] = wt[jj];
+        }
+    }
+}
+
+// Block scratch maintenance for block_size > 128 (generic path, VALU):
+//   Wblk[r, j] = Wblk[r, j] + (-Err[r, e0+i]) * U[a+i, cj0+j]   for i = 0..n_i-1, in order.
+__global__ __launch_bounds__(256) void block_far_update_kernel(float* __restrict__ Wblk, int64_t ld_blk,
+                                                               int64_t ncols, int64_t R,
+                                                               const float* __restrict__ Err, int64_t ld_err,
+                                                               int64_t e0, int n_i, const float* __restrict__ U,
+                                                               int64_t C, int64_t a, int64_t cj0) {
+    const int64_t total = R * ncols;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = t / ncols, j = t % ncols;
+        float w = Wblk[r * ld_blk + j];
+        const float* e = Err + r * ld_err + e0;
+        for (int i = 0; i < n_i; ++i) w = w + (-e[i]) * U[(a + i) * C + cj0 + j];
+        Wblk[r * ld_blk + j] = w;
+    }
+}
+
+__global__ __launch_bounds__(256) void copy2d_kernel(float* __restrict__ dst, int64_t ld_dst,
+                                                     const float* __restrict__ src, int64_t ld_src, int64_t R,
+                                                     int64_t ncols) {
+    const int64_t total = R * ncols;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = t / ncols, j = t % ncols;
+        dst[r * ld_dst + j] = src[r * ld_src + j];
+    }
+}
+
+// ------------------------------------------------------------- K6 trailing update
+// W[:, c2:] -= Err[R,B] @ U[c1:c2, c2:]  (gptq.py:270) on the fp32 matrix cores: see
+// gq_gemm32.hpp (MODE 0: k-ordered fma chain from 0, then one subtraction).
+int launch_trailing_update(float* Cmat, int64_t ldc, const float* A, int64_t lda, const float* B, int64_t ldb,
+                           int64_t M, int64_t N, int64_t K, hipStream_t st) {
+    return launch_gemm32<false, 0, false>(Cmat, ldc, A, lda, B, ldb, M, N, K, st);
+}
+
+// ------------------------------------------------------------- orchestration
+size_t gptq_workspace_bytes(int64_t R, int64_t C, int block_size) {
+    int64_t B = block_size <= 0 || block_size > C ? C : block_size;
+    size_t err = (size_t)R * (size_t)B * sizeof(float);
+    size_t blk = B > SEG ? (size_t)R * (size_t)B * sizeof(float) : 0;
+    return err + blk + 256;
+}
+
+int gptq_quantize(float* W, const float* U, int64_t R, int64_t C, int q_type, int block_size, int static_groups,
+                  const gq_search_t* p, uint8_t* qweight, uint16_t* d, uint8_t* s, uint16_t* dmin, uint8_t* m,
+                  void* ws, size_t ws_bytes, hipStream_t st) {
+    TypeInfo ti;
+    if (!type_info(q_type, ti)) GQ_FAIL(GQ_E_BAD_TYPE, "gq_gptq_quantize: unknown q_type %d", q_type);
+    if (R <= 0 || C <= 0 || C % 256) GQ_FAIL(GQ_E_BAD_SHAPE, "gq_gptq_quantize: R=%ld C=%ld (C %% 256 != 0)", (long)R, (long)C);
+    if (!W || !U || !qweight || !d || !s || !dmin || !m) GQ_FAIL(GQ_E_NULL, "gq_gptq_quantize: null pointer");
+    const int64_t B = block_size <= 0 || block_size > C ? C : block_size;  // gptq.py:54
+    if (B % SB) GQ_FAIL(GQ_E_UNSUPPORTED, "gq_gptq_quantize: block_size %ld is not a multiple of 16", (long)B);
+    if (q_type == GQ_Q3_K) static_groups = 0;  // gptq.py:204-206
+    const size_t need = gptq_workspace_bytes(R, C, (int)B);
+    if (!ws || ws_bytes < need) GQ_FAIL(GQ_E_WORKSPACE, "gq_gptq_quantize: workspace %zu < %zu bytes", ws_bytes, need);
+    float* Err = reinterpret_cast<float*>(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+    float* Wblk = Err + (size_t)R * B;
+    const int64_t ng = C / ti.group, nsg = C / 256;
+    const int gps = 256 / ti.group;
+    int rc;
+
+    if (static_groups) {  // gptq.py:184-196: all scales from the ORIGINAL W
+        for (int64_t c = 0; c < C; c += 256)
+            if ((rc = launch_scale_search(W + c, R, C, q_type, p, d + c / 256, nsg, s + (c / 256) * gps, ng,
+                                          dmin + c / 256, nsg, m + (c / 256) * gps, ng, st)))
+                return rc;
+    }
+    const dim3 seg_grid((unsigned)((R + 63) / 64)), seg_block(64);
+    for (int64_t c1 = 0; c1 < C; c1 += B) {  // gptq.py:222
+        const int64_t c2 = c1 + B < C ? c1 + B : C;
+        // one segment iff the block fits in LDS and stays inside one 256-column super-group
+        const bool single = (c2 - c1) <= SEG && (c1 / 256 == (c2 - 1) / 256);
+        const int64_t ncols = c2 - c1;
+        if (!single) {  // w_blk lives in scratch
+            hipLaunchKernelGGL(copy2d_kernel, dim3(2048), dim3(256), 0, st, Wblk, B, W + c1, C, R, ncols);
+            GQ_LAUNCH_CHECK();
+        }
+        int64_t a = c1;
+        while (a < c2) {
+            // a segment never crosses a 256-column super-group boundary: the lazy
+            // scale search (gptq.py:240-245) must see W as it is at that column.
+            int64_t e = a + SEG < c2 ? a + SEG : c2;
+            const int64_t next_sg = (a / 256 + 1) * 256;
+            if (e > next_sg) e = next_sg;
+            const int len = (int)(e - a);
+            if (!static_groups && (a % 256) == 0) {
+                // reads w (global), NOT w_blk: with block_size > 256 these columns
+                // are stale by design
+                const int64_t sg = a / 256;
+                if ((rc = launch_scale_search(W + a, R, C, q_type, p, d + sg, nsg, s + sg * gps, ng, dmin + sg, nsg,
+                                              m + sg * gps, ng, st)))
+                    return rc;
+            }
+            const float* srcp = single ? (W + a) : (Wblk + (a - c1));
+            const int64_t ld_src = single ? C : B;
+            hipLaunchKernelGGL(gptq_segment_kernel, seg_grid, seg_block, 0, st, W, C, srcp, ld_src, U, a, len, R, d, s,
+                               dmin, m, ti.group, ti.is_signed, (float)ti.qmin, (float)ti.qmax, qweight, Err, B,
+                               a - c1);
+            GQ_LAUNCH_CHECK();
+            if (e < c2) {  // push this segment's rank-1 updates into the rest of the block
+                hipLaunchKernelGGL(block_far_update_kernel, dim3(2048), dim3(256), 0, st, Wblk + (e - c1), B,
+                                   c2 - e, R, Err, B, a - c1, len, U, C, a, e);
+                GQ_LAUNCH_CHECK();
+            }
+            a = e;
+        }
+        // gptq.py:270
+        if (c2 < C)
+            if ((rc = launch_trailing_update(W + c2, C, Err, B, U + c1 * C + c2, C, R, C - c2, ncols, st))) return rc;
+    }
+    return GQ_OK;
+}
+
+}  // namespace gq

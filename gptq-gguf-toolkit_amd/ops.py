@@ -1,0 +1,169 @@
+"""Tensor-level entry points: torch CUDA(ROCm) tensors in, C-ABI calls out.
+
+torch is plumbing here (device memory + the current HIP stream); every computation is
+a kernel of libgptqgguf_hip.so.  All functions enqueue on torch's current stream and
+return without synchronising.
+"""
+import ctypes
+from typing import Optional, Tuple
+
+import torch
+
+from . import _cabi
+from ._cabi import F16, F32, BF16, Search, check, lib, type_info
+
+_DT = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
+
+
+def _stream(t: torch.Tensor):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _cabi.GQError("gptq_gguf_toolkit_amd ops need GPU tensors (no CPU fallback); got a CPU tensor")
+
+
+def _search(rmin=-1.0, rdelta=0.1, nstep=20):
+    return ctypes.byref(Search(float(rmin), float(rdelta), int(nstep)))
+
+
+def _idt(q_type):
+    return torch.int8 if type_info(q_type)["is_signed"] else torch.uint8
+
+
+def _u8(t):
+    return t.view(torch.uint8) if t.dtype != torch.uint8 else t
+
+
+def _u16view(t):
+    """fp16 tensor -> same storage seen as int16 (bit pattern carrier)."""
+    return t.view(torch.int16) if t.dtype == torch.float16 else t
+
+
+def _ws(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def workspace_bytes(op: int, R=0, C=0, T=0, block_size=0) -> int:
+    return int(lib().gq_workspace_bytes(op, R, C, T, block_size))
+
+
+def h_accumulate(H: torch.Tensor, X: torch.Tensor, beta: float, alpha: float, ws: Optional[torch.Tensor] = None):
+    """H = beta*H + alpha * X^T X in place.  X: [T, C] fp16/bf16/fp32 contiguous."""
+    _need_cuda(H, X)
+    assert H.dtype == torch.float32 and H.is_contiguous() and X.is_contiguous() and X.dim() == 2
+    T, C = X.shape
+    assert H.shape == (C, C)
+    need = workspace_bytes(_cabi.WS_H_ACCUMULATE, 0, C, T)
+    if ws is None or ws.numel() < need:
+        ws = _ws(need, X.device)
+    check(lib().gq_h_accumulate(_ptr(H), _ptr(X), _DT[X.dtype], T, C, beta, alpha, _ptr(ws), ws.numel(), _stream(X)),
+          "gq_h_accumulate")
+    return H
+
+
+def h_prepare(H: torch.Tensor, W: torch.Tensor, rel_damp: float) -> Tuple[torch.Tensor, torch.Tensor]:
+    """In-place dead-channel fix / masking / damping of (H, W); returns (U, not_invertible[int32 tensor])."""
+    _need_cuda(H, W)
+    assert H.dtype == torch.float32 and W.dtype == torch.float32 and H.is_contiguous() and W.is_contiguous()
+    R, C = W.shape
+    U = torch.empty_like(H)
+    flag = torch.zeros(1, dtype=torch.int32, device=H.device)
+    ws = _ws(workspace_bytes(_cabi.WS_H_PREPARE, R, C), H.device)
+    check(lib().gq_h_prepare(_ptr(H), _ptr(W), R, C, rel_damp, _ptr(U), _ptr(flag), _ptr(ws), ws.numel(), _stream(H)),
+          "gq_h_prepare")
+    return U, flag
+
+
+def scale_search(x: torch.Tensor, q_type: int, rmin=-1.0, rdelta=0.1, nstep=20):
+    """get_scale_and_zero on x[rows,256] (row stride free).  Returns (d f16[rows], s[rows,ng], dmin f16[rows], m)."""
+    _need_cuda(x)
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] == 256 and x.stride(1) == 1
+    rows = x.shape[0]
+    ng = 256 // type_info(q_type)["group"]
+    dev = x.device
+    d = torch.empty(rows, dtype=torch.float16, device=dev)
+    dmin = torch.empty(rows, dtype=torch.float16, device=dev)
+    s = torch.empty(rows, ng, dtype=torch.uint8, device=dev)
+    m = torch.empty(rows, ng, dtype=torch.uint8, device=dev)
+    check(lib().gq_scale_search(_ptr(x), rows, x.stride(0), int(q_type), _search(rmin, rdelta, nstep), _ptr(d), 1,
+                                _ptr(s), ng, _ptr(dmin), 1, _ptr(m), ng, _stream(x)), "gq_scale_search")
+    t = _idt(q_type)
+    return d, s.view(t), dmin, m.view(t)
+
+
+def _alloc_outs(R, C, q_type, dev):
+    G = type_info(q_type)["group"]
+    return (torch.empty(R, C, dtype=torch.uint8, device=dev), torch.empty(R, C // 256, dtype=torch.float16, device=dev),
+            torch.empty(R, C // G, dtype=torch.uint8, device=dev),
+            torch.empty(R, C // 256, dtype=torch.float16, device=dev),
+            torch.empty(R, C // G, dtype=torch.uint8, device=dev))
+
+
+def gptq_quantize(W: torch.Tensor, U: torch.Tensor, q_type: int, block_size=128, static_groups=False, rmin=-1.0,
+                  rdelta=0.1, nstep=20, ws: Optional[torch.Tensor] = None):
+    """GPTQ.step body.  W (fp32, contiguous) is updated IN PLACE to the dequantized matrix.
+    Returns (qweight, d, s, dmin, m)."""
+    _need_cuda(W, U)
+    assert W.dtype == torch.float32 and U.dtype == torch.float32 and W.is_contiguous() and U.is_contiguous()
+    R, C = W.shape
+    q, d, s, dmin, m = _alloc_outs(R, C, q_type, W.device)
+    bs = int(block_size or 0)
+    need = workspace_bytes(_cabi.WS_GPTQ_QUANTIZE, R, C, 0, bs)
+    if ws is None or ws.numel() < need:
+        ws = _ws(need, W.device)
+    check(lib().gq_gptq_quantize(_ptr(W), _ptr(U), R, C, int(q_type), bs, int(bool(static_groups)),
+                                 _search(rmin, rdelta, nstep), _ptr(q), _ptr(d), _ptr(s), _ptr(dmin), _ptr(m),
+                                 _ptr(ws), ws.numel(), _stream(W)), "gq_gptq_quantize")
+    t = _idt(q_type)
+    return q.view(t), d, s.view(t), dmin, m.view(t)
+
+
+def rtn_quantize(W: torch.Tensor, q_type: int, rmin=-1.0, rdelta=0.1, nstep=20):
+    _need_cuda(W)
+    assert W.is_contiguous() and W.dim() == 2 and W.dtype in _DT
+    R, C = W.shape
+    q, d, s, dmin, m = _alloc_outs(R, C, q_type, W.device)
+    check(lib().gq_rtn_quantize(_ptr(W), _DT[W.dtype], R, C, int(q_type), _search(rmin, rdelta, nstep), _ptr(q),
+                                _ptr(d), _ptr(s), _ptr(dmin), _ptr(m), _stream(W)), "gq_rtn_quantize")
+    t = _idt(q_type)
+    return q.view(t), d, s.view(t), dmin, m.view(t)
+
+
+def dequantize(q_type: int, q, d, s, dmin, m, out_dtype=torch.float32) -> torch.Tensor:
+    _need_cuda(q, d, s, dmin, m)
+    R, C = q.shape
+    out = torch.empty(R, C, dtype=out_dtype, device=q.device)
+    check(lib().gq_dequantize(int(q_type), _ptr(q.contiguous()), _ptr(d.contiguous()), _ptr(s.contiguous()),
+                              _ptr(dmin.contiguous()), _ptr(m.contiguous()), R, C, _ptr(out), _DT[out_dtype],
+                              _stream(q)), "gq_dequantize")
+    return out
+
+
+def pack(q_type: int, q, d, s, dmin=None, m=None) -> torch.Tensor:
+    """-> uint8 [R, C/256*type_size] on the device.  Inputs are not modified."""
+    _need_cuda(q, d, s, dmin, m)
+    R, C = q.shape
+    ts = type_info(q_type)["type_size"]
+    out = torch.empty(R, C // 256 * ts, dtype=torch.uint8, device=q.device)
+    check(lib().gq_pack(int(q_type), _ptr(q.contiguous()), _ptr(d.contiguous()), _ptr(s.contiguous()),
+                        _ptr(dmin.contiguous() if dmin is not None else None),
+                        _ptr(m.contiguous() if m is not None else None), R, C, _ptr(out), _stream(q)), "gq_pack")
+    return out
+
+
+def trailing_update(Cm: torch.Tensor, A: torch.Tensor, B: torch.Tensor):
+    """Cm -= A @ B (fp32; k-ordered fma chain then one subtraction per element)."""
+    _need_cuda(Cm, A, B)
+    M, K = A.shape
+    K2, N = B.shape
+    assert K == K2 and Cm.shape == (M, N) and Cm.stride(1) == 1 and A.stride(1) == 1 and B.stride(1) == 1
+    check(lib().gq_trailing_update(_ptr(Cm), Cm.stride(0), _ptr(A), A.stride(0), _ptr(B), B.stride(0), M, N, K,
+                                   _stream(Cm)), "gq_trailing_update")
+    return Cm

@@ -1,0 +1,143 @@
+/*
+ * gptq_gguf.h -- C ABI of libgptqgguf_hip.so: the MI355X (gfx950) GPTQ -> GGUF
+ * K-quant hot path.
+ *
+ * The reference (IST-DASLab/gptq-gguf-toolkit) has no FFI seam: its hot path is a
+ * Python class protocol (quant/gptq/src/gptq.py GPTQ.update/quantize) over chains
+ * of torch ops.  Each entry point below replaces one such chain; the citation
+ * after "replaces" is the reference file:line (relative to quant/gptq/src/).
+ * A maintainer of the reference would bind these with ctypes (see
+ * INTEGRATION.md); gptq-gguf-toolkit_amd/_cabi.py is that binding.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer (hipMalloc'd / torch.cuda storage) unless
+ *    the parameter name ends in _host;
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream); every
+ *    call only ENQUEUES work on that stream and returns; nothing is freed or
+ *    allocated for the caller, scratch comes from the caller's `ws` buffer
+ *    (size it with gq_workspace_bytes);
+ *  - return value: 0 on success, negative gq_status on error (gq_last_error()
+ *    returns a thread-local message);
+ *  - fp16 fields (super-group scale d / min dmin) are raw IEEE binary16 bits;
+ *  - integer outputs are one byte per value: uint8 for Q2_K/Q4_K/Q5_K, int8
+ *    (two's complement in the same byte) for Q3_K/Q6_K, exactly the tensors the
+ *    reference stores in data.pth (quantizer.py:268-275);
+ *  - matrices are dense row-major: W[R,C] (nn.Linear weight, R = out features,
+ *    C = in features, C % 256 == 0), H[C,C], U[C,C];
+ *    qweight[R,C], d/dmin[R,C/256], s/m[R,C/G]  (G = 16 or 32).
+ */
+#ifndef GPTQ_GGUF_H
+#define GPTQ_GGUF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GQ_ABI_VERSION 1
+
+/* ggml type ids (quant_utils.py:11-16) */
+enum { GQ_Q2_K = 10, GQ_Q3_K = 11, GQ_Q4_K = 12, GQ_Q5_K = 13, GQ_Q6_K = 14 };
+
+/* element types of activations / weights / dequantized outputs */
+enum { GQ_F32 = 0, GQ_F16 = 1, GQ_BF16 = 2 };
+
+typedef enum {
+    GQ_OK = 0,
+    GQ_E_BAD_TYPE = -1,    /* unknown q_type / dtype */
+    GQ_E_BAD_SHAPE = -2,   /* C % 256 != 0, R <= 0, ld too small, ... */
+    GQ_E_WORKSPACE = -3,   /* ws == NULL or ws_bytes too small */
+    GQ_E_UNSUPPORTED = -4, /* a reference option this build does not implement */
+    GQ_E_HIP = -5,         /* a HIP runtime call failed (see gq_last_error) */
+    GQ_E_NULL = -6
+} gq_status;
+
+/* quant_utils.py:19-26 + gguf.constants.GGML_QUANT_SIZES */
+typedef struct {
+    int bits;       /* 2..6 */
+    int qmin, qmax; /* clamp range of the stored ints */
+    int scale_maxq; /* 15 / 31 / 63 */
+    int group;      /* 16 / 32 */
+    int is_signed;  /* 1: int8 tensors (Q3_K, Q6_K) */
+    int k_search;   /* 1: make_k_quants (Q2/Q4/Q5), 0: make_quants (Q3/Q6) */
+    int type_size;  /* bytes per 256-value GGUF block: 84/110/144/176/210 */
+} gq_type_info_t;
+
+/* scale-search hyper-parameters (quant.py:94-111; python floats -> double) */
+typedef struct {
+    double rmin;   /* -1.0 */
+    double rdelta; /*  0.1 */
+    int nstep;     /*  20  */
+} gq_search_t;
+
+int gq_abi_version(void);
+const char* gq_last_error(void);
+int gq_type_info(int q_type, gq_type_info_t* out_host);
+
+/* Scratch bytes needed by an entry point.  op: one of GQ_WS_*; unused dims = 0. */
+enum { GQ_WS_H_ACCUMULATE = 1, GQ_WS_H_PREPARE = 2, GQ_WS_GPTQ_QUANTIZE = 3 };
+size_t gq_workspace_bytes(int op, int64_t R, int64_t C, int64_t T, int block_size);
+
+/* replaces gptq.py:96,108-112 (GPTQ.update):  H = beta*H + alpha * X^T X.
+   X[T,C] row-major in x_dtype (fp16/bf16 products are exact in fp32; accumulated
+   in fp32 on the matrix cores).  H is fp32 [C,C], full square, updated in place. */
+int gq_h_accumulate(float* H, const void* X, int x_dtype, int64_t T, int64_t C,
+                    float beta, float alpha, void* ws, size_t ws_bytes, void* stream);
+
+/* replaces gptq.py:134-135,141 (dead channels) + gptq.py:304-324 (_prepare) +
+   linalg_utils.py:8-12: zero-column masking, damping, U = chol_upper(inv(H)).
+   H and W are mutated exactly as in the reference (damping persists in H).
+   *not_invertible (device int) is set to 1 and U to the identity when H is not
+   positive definite (gptq.py:321-323), else 0. */
+int gq_h_prepare(float* H, float* W, int64_t R, int64_t C, float rel_damp, float* U,
+                 int* not_invertible, void* ws, size_t ws_bytes, void* stream);
+
+/* replaces quant_utils.py:90-145 (Quantizer.get_scale_and_zero) incl.
+   make_k_quants :199-274 / make_quants :147-197, on one [rows,256] panel with row
+   stride ld (elements).  d/dmin element r at d[r*d_stride]; s/m row r at s + r*s_ld. */
+int gq_scale_search(const float* x, int64_t rows, int64_t ld, int q_type, const gq_search_t* p_host,
+                    uint16_t* d, int64_t d_stride, uint8_t* s, int64_t s_ld,
+                    uint16_t* dmin, int64_t dmin_stride, uint8_t* m, int64_t m_ld, void* stream);
+
+/* replaces gptq.py:145-276 (the rank-0 body of GPTQ.step): blocked column-wise
+   quantize + error feedback + trailing update.  W (fp32 working copy) becomes the
+   dequantized matrix; U is chol_upper(H^-1).  block_size <= 0 means C.
+   Requires block_size % 16 == 0.  act_order (gptq.py:211-216) is a host-side
+   permutation of W/H/qweight and is done by the caller. */
+int gq_gptq_quantize(float* W, const float* U, int64_t R, int64_t C, int q_type,
+                     int block_size, int static_groups, const gq_search_t* p_host,
+                     uint8_t* qweight, uint16_t* d, uint8_t* s, uint16_t* dmin, uint8_t* m,
+                     void* ws, size_t ws_bytes, void* stream);
+
+/* replaces quantizer.py:278-330 (_quant_non_block_module, RTN for embed/lm_head).
+   W in w_dtype; GQ_F32 follows the fp32 arithmetic of the reference run with
+   --dtype float32. */
+int gq_rtn_quantize(const void* W, int w_dtype, int64_t R, int64_t C, int q_type,
+                    const gq_search_t* p_host,
+                    uint8_t* qweight, uint16_t* d, uint8_t* s, uint16_t* dmin, uint8_t* m,
+                    void* stream);
+
+/* replaces quant_utils.py:277-310 (dequantize_linear_weight) + the caller's cast
+   to the model dtype (quantizer.py:264). */
+int gq_dequantize(int q_type, const uint8_t* qweight, const uint16_t* d, const uint8_t* s,
+                  const uint16_t* dmin, const uint8_t* m, int64_t R, int64_t C,
+                  void* out, int out_dtype, void* stream);
+
+/* replaces packing_utils.py:33-326 (pack_Q2K .. pack_Q6K, pack_scale_min_torch).
+   Inputs are const: the +4/+32 offsets of Q3_K/Q6_K are applied on the fly.
+   dmin/m may be NULL for Q3_K/Q6_K.  out: [R, C/256*type_size] bytes. */
+int gq_pack(int q_type, const uint8_t* qweight, const uint16_t* d, const uint8_t* s,
+            const uint16_t* dmin, const uint8_t* m, int64_t R, int64_t C, uint8_t* out, void* stream);
+
+/* C[M,N] (ldc) -= A[M,K] (lda) @ B[K,N] (ldb), fp32, each output a k-ordered fma
+   chain from 0 followed by one subtraction: the trailing update of gptq.py:270,
+   exposed for tests and benchmarks. */
+int gq_trailing_update(float* Cmat, int64_t ldc, const float* A, int64_t lda, const float* B, int64_t ldb,
+                       int64_t M, int64_t N, int64_t K, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,73 @@
+"""pack -> (independent llama.cpp-spec decoder) round trip on the oracle packers, and
+C-ABI load/export checks.  No GPU needed."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden
+from ggml_spec import unpack
+
+TYPES = {"Q2_K": 10, "Q3_K": 11, "Q4_K": 12, "Q5_K": 13, "Q6_K": 14}
+
+
+@pytest.mark.parametrize("name", list(TYPES))
+def test_pack_roundtrip_against_ggml_layout(oracle, name):
+    g = load_golden("g8_g9_rtn_dequant")
+    t = TYPES[name]
+    q, d, s, dmin, m = (g[f"{name}_{k}"] for k in ("q", "d", "s", "dmin", "m"))
+    packed = oracle.pack(t, q, d, s, dmin, m)
+    codes, d2, sc2, dmin2, mn2 = unpack(t, packed)
+    assert np.array_equal(codes, q.astype(np.int32))
+    assert np.array_equal(d2, d) and np.array_equal(sc2, s.astype(np.int32))
+    if name in ("Q2_K", "Q4_K", "Q5_K"):
+        assert np.array_equal(dmin2, dmin) and np.array_equal(mn2, m.astype(np.int32))
+    # the reference's own packed bytes decode to the same thing
+    codes_r, *_ = unpack(t, g[f"{name}_packed"])
+    assert np.array_equal(codes_r, codes)
+
+
+def test_cabi_exports_every_declared_symbol():
+    """include/gptq_gguf.h <-> libgptqgguf_hip.so (no compute calls: there is no GPU here)."""
+    hdr = open(os.path.join(ROOT, "include", "gptq_gguf.h")).read()
+    declared = set(re.findall(r"\b(gq_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"gq_last_error"} - {"gq_last_error"}
+    assert len(declared) >= 12
+    from gptq_gguf_toolkit_amd import _cabi
+    if not os.path.exists(_cabi.SO_PATH):
+        _cabi.build()
+    L = ctypes.CDLL(_cabi.SO_PATH)
+    for sym in sorted(declared):
+        assert hasattr(L, sym), f"{sym} declared in gptq_gguf.h but not exported"
+    assert set(_cabi.EXPORTS) == declared
+    lib = _cabi.lib()
+    assert lib.gq_abi_version() == 1
+    for t, ts in ((10, 84), (11, 110), (12, 144), (13, 176), (14, 210)):
+        assert _cabi.type_info(t)["type_size"] == ts
+    with pytest.raises(_cabi.GQError):
+        _cabi.type_info(3)
+    # host-side argument validation does not need a device
+    assert lib.gq_workspace_bytes(_cabi.WS_GPTQ_QUANTIZE, 4096, 4096, 0, 128) >= 4096 * 128 * 4
+    rc = lib.gq_pack(12, None, None, None, None, None, 16, 300, None, None)
+    assert rc == -2 and b"256" in lib.gq_last_error()
+
+
+def test_no_cpu_fallback():
+    """Product ops refuse CPU tensors instead of silently computing elsewhere."""
+    import torch
+    from gptq_gguf_toolkit_amd import ops, GQError
+    with pytest.raises(GQError):
+        ops.pack(12, torch.zeros(4, 256, dtype=torch.uint8), torch.zeros(4, 1, dtype=torch.float16),
+                 torch.zeros(4, 8, dtype=torch.uint8), torch.zeros(4, 1, dtype=torch.float16),
+                 torch.zeros(4, 8, dtype=torch.uint8))
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "gptq-gguf-toolkit_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                src = open(os.path.join(dp, f)).read()
+                assert "oracle" not in src.replace("# oracle", "") or f == "README.md", f"{f} mentions the oracle"

@@ -1,0 +1,297 @@
+"""-m gpu: the HIP path (through the C ABI) against the CPU oracle and the golden
+fixtures.  Bit-exact for every integer/byte/fp16 output; the two fp32 linear-algebra
+stages (H accumulate, Cholesky chain) carry their tolerance in the test.
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden, triu_unpack
+from ggml_spec import unpack
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+TYPES = {"Q2_K": 10, "Q3_K": 11, "Q4_K": 12, "Q5_K": 13, "Q6_K": 14}
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need a MI355X"
+    from gptq_gguf_toolkit_amd import ops as _ops
+    return _ops
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def u16(t):
+    return t.cpu().contiguous().view(torch.int16).numpy().view(np.uint16)
+
+
+def npy(t):
+    return t.cpu().numpy()
+
+
+def f16t(bits):
+    return torch.from_numpy(np.ascontiguousarray(bits).view(np.int16)).view(torch.float16).cuda()
+
+
+# ----------------------------------------------------------------- K4 scale search
+@pytest.mark.parametrize("name", list(TYPES))
+def test_scale_search_golden(ops, name):
+    g = load_golden("g2_scale_search")
+    d, s, dmin, m = ops.scale_search(dev(g[f"{name}_x"]), TYPES[name])
+    assert np.array_equal(u16(d), g[f"{name}_ieee_d"]) and np.array_equal(u16(dmin), g[f"{name}_ieee_dmin"])
+    assert np.array_equal(npy(s), g[f"{name}_ieee_s"]) and np.array_equal(npy(m), g[f"{name}_ieee_m"])
+
+
+@pytest.mark.parametrize("name", list(TYPES))
+@pytest.mark.parametrize("rows", [1, 5, 1003])
+def test_scale_search_vs_oracle_ragged(ops, oracle, name, rows):
+    rng = np.random.default_rng(rows * 31 + TYPES[name])
+    x = (rng.standard_normal((rows, 256)) * 0.02).astype(np.float32)
+    x[0, :40] = 0.0
+    if rows > 4:
+        x[3] = np.abs(x[3])
+        x[4] *= 1e-3
+    # strided view: panel inside a wider matrix
+    wide = np.zeros((rows, 768), np.float32)
+    wide[:, 256:512] = x
+    xt = dev(wide)[:, 256:512]
+    d, s, dmin, m = ops.scale_search(xt, TYPES[name])
+    od, os_, odm, om = oracle.scale_search(x, TYPES[name])
+    assert np.array_equal(u16(d), od) and np.array_equal(u16(dmin), odm)
+    assert np.array_equal(npy(s), os_) and np.array_equal(npy(m), om)
+
+
+def test_scale_search_params(ops, oracle):
+    rng = np.random.default_rng(5)
+    x = (rng.standard_normal((64, 256)) * 0.05).astype(np.float32)
+    for kw in (dict(rmin=-0.5, rdelta=0.05, nstep=10), dict(nstep=0), dict(rmin=-2.0, rdelta=0.2, nstep=23)):
+        d, s, dmin, m = ops.scale_search(dev(x), 12, **kw)
+        od, os_, odm, om = oracle.scale_search(x, 12, **kw)
+        assert np.array_equal(u16(d), od) and np.array_equal(npy(s), os_)
+        assert np.array_equal(u16(dmin), odm) and np.array_equal(npy(m), om)
+
+
+# ------------------------------------------------------------- K5/K6 GPTQ step
+def _g6_tags():
+    g = load_golden("g6_g7_step_and_pack")
+    return sorted({k.rsplit("_", 1)[0] for k in g.files if k.endswith("_q") and "mklsqrt" not in k})
+
+
+@pytest.mark.parametrize("tag", _g6_tags())
+def test_gptq_step_golden(ops, tag):
+    """(W, U) -> 5-tuple, bit-identical to what the reference produced (G6) + packed bytes (G7)."""
+    g = load_golden("g6_g7_step_and_pack")
+    case, n1, n2, b, s_ = tag.split("_")
+    name = f"{n1}_{n2}"
+    block = None if b == "bNone" else int(b[1:])
+    W0 = g[f"{case}_W0"]
+    U = triu_unpack(g[f"{case}_U_triu"], W0.shape[1])
+    W = dev(W0)
+    q, d, s, dmin, m = ops.gptq_quantize(W, dev(U), TYPES[name], block_size=block, static_groups=(s_ == "s1"))
+    assert np.array_equal(npy(q), g[f"{tag}_q"]), f"{(npy(q) != g[f'{tag}_q']).mean():.4%} ints differ"
+    assert np.array_equal(u16(d), g[f"{tag}_d"]) and np.array_equal(u16(dmin), g[f"{tag}_dmin"])
+    assert np.array_equal(npy(s), g[f"{tag}_s"]) and np.array_equal(npy(m), g[f"{tag}_m"])
+    # gptq.py:266: W now holds the dequantized matrix
+    deq = ops.dequantize(TYPES[name], q, d, s, dmin, m)
+    assert torch.equal(W, deq) or np.array_equal(npy(W), npy(deq))
+    if f"{tag}_packed" in g.files:
+        assert np.array_equal(npy(ops.pack(TYPES[name], q, d, s, dmin, m)), g[f"{tag}_packed"])
+
+
+@pytest.mark.parametrize("name,R,C,block", [("Q4_K", 96, 1024, 128), ("Q2_K", 200, 512, 128), ("Q3_K", 64, 768, 64),
+                                            ("Q5_K", 130, 512, 256), ("Q6_K", 64, 512, 96), ("Q4_K", 64, 768, 32)])
+def test_gptq_step_vs_oracle(ops, oracle, name, R, C, block):
+    rng = np.random.default_rng(R + C)
+    W0 = (rng.standard_normal((R, C)) * 0.02).astype(np.float16).astype(np.float32)
+    X = (rng.standard_normal((2 * C, C)) * np.exp(rng.standard_normal(C) * 0.5)).astype(np.float32)
+    H = oracle.h_accumulate(np.zeros((C, C), np.float32), X, 0.0, 2.0 / 4)
+    U, _, W1, bad = oracle.h_prepare(H, W0, 0.01)
+    assert not bad
+    W = dev(W1)
+    q, d, s, dmin, m = ops.gptq_quantize(W, dev(U), TYPES[name], block_size=block)
+    Wd, oq, od, os_, odm, om = oracle.gptq_step(W1, U, TYPES[name], block_size=block)
+    assert np.array_equal(npy(q), oq), f"{(npy(q) != oq).mean():.4%} ints differ"
+    assert np.array_equal(u16(d), od) and np.array_equal(u16(dmin), odm)
+    assert np.array_equal(npy(s), os_) and np.array_equal(npy(m), om)
+    assert np.array_equal(npy(W), Wd)
+
+
+def test_gptq_bad_args(ops):
+    from gptq_gguf_toolkit_amd import GQError
+    W = torch.zeros(64, 300, device="cuda")
+    with pytest.raises(GQError, match="256"):
+        ops.gptq_quantize(W, torch.eye(300, device="cuda"), 12)
+    W = torch.zeros(64, 512, device="cuda")
+    with pytest.raises(GQError, match="multiple of 16"):
+        ops.gptq_quantize(W, torch.eye(512, device="cuda"), 12, block_size=100)
+    with pytest.raises(GQError):
+        ops.gptq_quantize(W, torch.eye(512, device="cuda"), 99)
+
+
+def test_trailing_update(ops):
+    torch.manual_seed(0)
+    for M, N, K in ((128, 384, 128), (200, 130, 64), (64, 1, 128), (33, 257, 96)):
+        A = torch.randn(M, K, device="cuda")
+        B = torch.randn(K, N, device="cuda")
+        C0 = torch.randn(M, N, device="cuda")
+        C = C0.clone()
+        ops.trailing_update(C, A, B)
+        ref = C0.double() - A.double() @ B.double()
+        assert (C.double() - ref).abs().max().item() < 1e-4 * K ** 0.5
+
+
+# --------------------------------------------------------- K7/K8/K9-13 codecs
+@pytest.mark.parametrize("name", list(TYPES))
+def test_rtn_dequant_pack_golden(ops, name):
+    g = load_golden("g8_g9_rtn_dequant")
+    t = TYPES[name]
+    q, d, s, dmin, m = ops.rtn_quantize(dev(g["W"]), t)
+    assert np.array_equal(npy(q), g[f"{name}_q"]) and npy(q).dtype == g[f"{name}_q"].dtype
+    assert np.array_equal(u16(d), g[f"{name}_d"]) and np.array_equal(u16(dmin), g[f"{name}_dmin"])
+    assert np.array_equal(npy(s), g[f"{name}_s"]) and np.array_equal(npy(m), g[f"{name}_m"])
+    deq = ops.dequantize(t, q, d, s, dmin, m)
+    assert np.array_equal(npy(deq).view(np.uint32), g[f"{name}_deq"].view(np.uint32))
+    for dt in (torch.float16, torch.bfloat16):  # the caller's cast (quantizer.py:264)
+        assert torch.equal(ops.dequantize(t, q, d, s, dmin, m, out_dtype=dt), deq.to(dt))
+    q0, s0 = q.clone(), s.clone()
+    packed = ops.pack(t, q, d, s, dmin, m)
+    assert np.array_equal(npy(packed), g[f"{name}_packed"])
+    assert torch.equal(q, q0) and torch.equal(s, s0)  # inputs untouched (unlike pack_Q3K/pack_Q6K)
+
+
+@pytest.mark.parametrize("name", list(TYPES))
+def test_pack_ragged_and_roundtrip(ops, oracle, name):
+    """block counts that are not multiples of the 8-block staging unit + ggml-spec round trip."""
+    t = TYPES[name]
+    ti = oracle.type_info(t)
+    rng = np.random.default_rng(t)
+    for R, C in ((1, 256), (3, 768), (37, 512)):
+        q = rng.integers(ti["qmin"], ti["qmax"] + 1, (R, C)).astype(np.int8 if ti["is_signed"] else np.uint8)
+        sdt = np.int8 if ti["is_signed"] else np.uint8
+        s = rng.integers(0, ti["scale_maxq"] + 1, (R, C // ti["group"])).astype(sdt)
+        m = (rng.integers(0, ti["scale_maxq"] + 1, (R, C // ti["group"])) * ti["k_search"]).astype(sdt)
+        d = rng.integers(0, 0x7BFF, (R, C // 256)).astype(np.uint16)
+        dmin = (rng.integers(0, 0x7BFF, (R, C // 256)) * ti["k_search"]).astype(np.uint16)
+        packed = npy(ops.pack(t, dev(q), f16t(d), dev(s), f16t(dmin), dev(m)))
+        assert np.array_equal(packed, oracle.pack(t, q, d, s, dmin, m))
+        codes, d2, sc2, dm2, mn2 = unpack(t, packed)
+        assert np.array_equal(codes, q.astype(np.int32)) and np.array_equal(sc2, s.astype(np.int32))
+        assert np.array_equal(d2, d) and np.array_equal(dm2, dmin) and np.array_equal(mn2, m.astype(np.int32))
+
+
+def test_rtn_reduced_precision_is_loud(ops):
+    from gptq_gguf_toolkit_amd import GQError
+    with pytest.raises(GQError, match="not implemented"):
+        ops.rtn_quantize(torch.zeros(8, 256, device="cuda", dtype=torch.bfloat16), 12)
+
+
+# ------------------------------------------------------------------ K1 Hessian
+def test_h_accumulate_golden(ops):
+    g = load_golden("g4_g5_hessian")
+    for tag, dt in (("f32", torch.float32), ("f16", torch.float16), ("bf16", torch.bfloat16)):
+        X = g[f"X_{tag}"]
+        C = X.shape[-1]
+        H = torch.zeros(C, C, device="cuda")
+        n = 0
+        for xb in X:  # b = 1 per 3-D update (gptq.py:88,106-112)
+            ops.h_accumulate(H, dev(xb).to(dt), n / (n + 1), 2.0 / (n + 1))
+            n += 1
+        ref = g[f"H_{tag}"]
+        err = np.abs(npy(H) - ref).max()
+        assert err <= 3e-6 * np.abs(ref).max(), (tag, err)  # fp32 accumulation-order tolerance
+        assert np.array_equal(npy(H), npy(H).T)  # exactly symmetric
+
+
+def test_h_accumulate_shapes(ops):
+    torch.manual_seed(1)
+    for T, C in ((100, 256), (2048, 1024), (37, 384)):
+        X = torch.randn(T, C, device="cuda").half()
+        H = torch.zeros(C, C, device="cuda")
+        ops.h_accumulate(H, X, 0.0, 2.0)
+        ref = 2.0 * (X.double().T @ X.double())
+        assert (H.double() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item() * max(1, T / 512)
+
+
+# --------------------------------------------------------------- K2/K3 prepare
+def test_h_prepare_golden(ops):
+    g = load_golden("g4_g5_hessian")
+    H, W = dev(g["prep_H_in"]), dev(g["prep_W_in"])
+    C = H.shape[0]
+    U, flag = ops.h_prepare(H, W, 0.01)
+    assert int(flag.item()) == 0
+    assert np.array_equal(npy(W), g["prep_W_after_prestep"])
+    assert np.allclose(np.diag(npy(H)), g["prep_H_after_diag"], rtol=1e-6)
+    for r in (5, 17):
+        assert np.allclose(npy(H)[r], g[f"prep_H_after_row{r}"], rtol=1e-6, atol=0)
+    Uref = triu_unpack(g["prep_U_triu"], C)
+    Un = npy(U)
+    assert np.all(np.tril(Un, -1) == 0)
+    assert np.abs(Un - Uref).max() <= 2e-4 * np.abs(Uref).max()  # fp32 factorisation tolerance
+    # definition check in fp64: U^T U == inv(H_damped)
+    Hd = npy(H).astype(np.float64)
+    assert np.abs(Un.astype(np.float64).T @ Un.astype(np.float64) @ Hd - np.eye(C)).max() < 5e-3
+
+
+def test_h_prepare_singular_falls_back_to_identity(ops):
+    g = load_golden("g4_g5_hessian")
+    X = dev(g["sing_X"])
+    H = torch.zeros(256, 256, device="cuda")
+    ops.h_accumulate(H, X, 0.0, 2.0)
+    U, flag = ops.h_prepare(H, torch.ones(8, 256, device="cuda"), 0.0)
+    assert int(flag.item()) == 1 and torch.equal(U, torch.eye(256, device="cuda"))
+
+
+def test_h_prepare_larger(ops):
+    torch.manual_seed(3)
+    C = 1536
+    X = (torch.randn(4096, C, device="cuda") * torch.exp(torch.randn(C, device="cuda") * 0.5)).half()
+    H = torch.zeros(C, C, device="cuda")
+    ops.h_accumulate(H, X, 0.0, 2.0 / 4096)
+    W = torch.randn(64, C, device="cuda")
+    U, flag = ops.h_prepare(H, W, 0.01)
+    assert int(flag.item()) == 0
+    Ud = U.double()
+    resid = (Ud.T @ Ud @ H.double() - torch.eye(C, device="cuda", dtype=torch.float64)).abs().max().item()
+    assert resid < 2e-2, resid
+    ref = torch.linalg.cholesky(torch.cholesky_inverse(torch.linalg.cholesky(H.double())), upper=True)
+    assert (Ud - ref).abs().max().item() <= 1e-3 * ref.abs().max().item()
+
+
+# ------------------------------------------- full-size properties (BASELINE shapes)
+@pytest.mark.parametrize("name", ["Q4_K", "Q3_K"])
+def test_full_size_properties(ops, name):
+    """4096 x 4096 (Llama-3-8B q/o_proj shape): size-independent invariants."""
+    t = TYPES[name]
+    torch.manual_seed(11)
+    R = C = 4096
+    W0 = (torch.randn(R, C, device="cuda") * 0.02).half().float()
+    X = (torch.randn(8192, C, device="cuda") * torch.exp(torch.randn(C, device="cuda") * 0.5)).half()
+    H = torch.zeros(C, C, device="cuda")
+    for i in range(4):
+        ops.h_accumulate(H, X[i * 2048:(i + 1) * 2048], i / (i + 1), 2.0 / (i + 1))
+    W = W0.clone()
+    U, flag = ops.h_prepare(H, W, 0.01)
+    assert int(flag.item()) == 0
+    q, d, s, dmin, m = ops.gptq_quantize(W, U, t, block_size=128)
+    deq = ops.dequantize(t, q, d, s, dmin, m)
+    assert bool((W == deq).all()), "W after step must be the dequantized matrix (gptq.py:266)"
+    ti_min, ti_max = {"Q4_K": (0, 15), "Q3_K": (-4, 3)}[name]
+    assert int(q.min()) >= ti_min and int(q.max()) <= ti_max
+    # GPTQ must beat RTN on the Hessian-weighted error it minimises
+    q2, d2, s2, dm2, m2 = ops.rtn_quantize(W0, t)
+    rtn = ops.dequantize(t, q2, d2, s2, dm2, m2)
+    def herr(Wq):
+        E = (Wq - W0)[:256].double()
+        return float(((E @ H.double()) * E).sum())
+    assert herr(deq) < herr(rtn)
+    # packed bytes decode (independent ggml-layout decoder) to exactly the stored tensors
+    packed = ops.pack(t, q, d, s, dmin, m)
+    codes, dd, sc, dmn, mn = unpack(t, npy(packed[:64]))
+    assert np.array_equal(codes, npy(q[:64]).astype(np.int32)) and np.array_equal(dd, u16(d[:64]))
+    assert np.array_equal(sc, npy(s[:64]).astype(np.int32))
+    # idempotence: quantizing the dequantized matrix with static groups of itself is stable in the ints' range
+    assert packed.shape == (R, C // 256 * {"Q4_K": 144, "Q3_K": 110}[name])
