@@ -1,0 +1,140 @@
+"""GPTQ per-Linear handle: drop-in for the reference's quant/gptq/src/gptq.py class.
+
+Same constructor, same `update / quantize / reset` protocol and return order
+(gptq.py:29-72, :79-114, :297-302, :295); the numerical body is HIP:
+  update                -> gq_h_accumulate   (K1, MFMA SYRK)
+  quantization_pre_step -> all-reduce of H over RCCL (gptq.py:131-132) + fp32 working copy
+  _prepare              -> gq_h_prepare      (K2 + K3)
+  step                  -> gq_gptq_quantize  (K4 + K5 + K6)
+"""
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+from torch import Tensor
+from torch.nn.modules.conv import _ConvNd
+
+from . import dist_utils, model_utils
+from . import ops as _ops
+from .quant_utils import GGML_QUANT_SIZES, GGMLQuantizationType, _check_scale
+
+
+class GPTQ:
+    def __init__(self, layer: nn.Module, rel_damp: float = 1e-2, block_size: Optional[int] = None,
+                 act_order: bool = False, quant_scale: str = "absmax", rmin: float = -1.0, rdelta: float = 0.1,
+                 nstep: int = 20, grid: int = 100, static_groups: bool = False, verbose: bool = False):
+        if act_order:
+            assert static_groups  # reference gptq.py:45-46
+        assert isinstance(layer, (nn.Linear, _ConvNd)), "OBC supports only linear and convolutional layers."
+        self.layer = layer
+        self.W = layer.weight
+        self.d_row, self.d_col = model_utils.get_number_of_rows_and_cols(layer)
+        self.rel_damp = rel_damp
+        self.block_size = block_size or self.d_col
+        self.act_order = act_order
+        self.quant_scale = _check_scale(quant_scale)
+        self.static_groups = static_groups
+        self.grid, self.rmin, self.rdelta, self.nstep = grid, rmin, rdelta, nstep
+        self.W_device, self.W_dtype, self.W_shape = self.W.device, self.W.dtype, self.W.shape
+        self.H: Optional[Tensor] = None
+        self.num_samples = 0
+        self.verbose = verbose
+        # --- beyond the reference ---
+        self.owner_rank = 0            # rank that runs step(); the reference hard-codes rank 0 (gptq.py:158)
+        self.shared_H_with = None      # another handle fed by the SAME input tensor (q/k/v, gate/up)
+        self._flag = None
+        self._ws = None
+
+    # ------------------------------------------------------------------ Hessian
+    @torch.no_grad()
+    def update(self, input: Tensor) -> None:
+        """H <- n/(n+b) H + 2/(n+b) X^T X  (reference gptq.py:79-114)."""
+        batch_size = input.shape[0]
+        if self.shared_H_with is not None:  # this handle's H is the other handle's H (same input)
+            self.num_samples += batch_size
+            return
+        if self.H is None:
+            self.H = torch.zeros((self.d_col, self.d_col), device=input.device, dtype=torch.float32)
+        if isinstance(self.layer, nn.Linear):
+            x = input.reshape(-1, input.shape[-1])
+        else:
+            unfold = nn.Unfold(self.layer.kernel_size, dilation=self.layer.dilation, padding=self.layer.padding,
+                               stride=self.layer.stride)
+            x = unfold(input).transpose(1, 2).flatten(0, 1)
+        if x.dtype not in (torch.float16, torch.bfloat16, torch.float32):
+            x = x.float()
+        beta = self.num_samples / (self.num_samples + batch_size)
+        alpha = 2.0 / (self.num_samples + batch_size)
+        _ops.h_accumulate(self.H, x.contiguous(), beta, alpha)
+        self.num_samples += batch_size
+
+    def reset(self) -> None:
+        self.W = self.layer.weight
+        self.H = None
+        self.num_samples = 0
+        self._ws = None
+
+    # ------------------------------------------------------------------- quantize
+    @torch.no_grad()
+    def quantization_pre_step(self) -> None:
+        """All-reduce of H + fp32 working copy (reference gptq.py:122-143).  The dead-channel
+        fix of :134-135,141 happens inside gq_h_prepare together with _prepare's masking."""
+        if self.shared_H_with is not None:
+            self.H = self.shared_H_with.H
+        assert self.H is not None, "One has to process at least one sample of calibration data to run pruning"
+        if self.shared_H_with is None or not getattr(self.shared_H_with, "_reduced", False):
+            dist_utils.allreduce_hessian(self.H)
+            self._reduced = True
+        W = self.W.detach().clone().float()
+        if isinstance(self.layer, _ConvNd):
+            W = W.flatten(1, -1)
+        self.W = W.contiguous()
+        self.pre_step_completed = True
+
+    @torch.no_grad()
+    def _prepare(self) -> Tensor:
+        """-> U = chol_upper(H^-1); mutates H (damping) and W (dead columns) like the reference (:304-324)."""
+        H = self.H
+        if self.shared_H_with is not None:
+            H = self.H.clone()  # each reference handle damps its own copy of the (identical) H
+        U, self._flag = _ops.h_prepare(H, self.W, self.rel_damp)
+        if self.shared_H_with is None:
+            self.H = H
+        return U
+
+    @property
+    def issue_non_invertible(self) -> bool:
+        return bool(self._flag is not None and int(self._flag.item()) != 0)
+
+    @torch.no_grad()
+    def step(self, q_type: GGMLQuantizationType) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor]:
+        bits, clamp, scale_maxq, group_size, supergroup_size, sz_dtype, q_dtype = GGML_QUANT_SIZES[q_type]
+        d_row, d_col = self.d_row, self.d_col
+        dev = self.W_device
+        ng, nsg = d_col // group_size, d_col // supergroup_size
+        if dist_utils.get_rank() == self.owner_rank:
+            if q_type == GGMLQuantizationType.Q3_K:  # reference gptq.py:204-206 mutates the handle
+                self.act_order = False
+                self.static_groups = False
+            if self.act_order:
+                raise NotImplementedError("act_order (gptq.py:211-216, off in run_quant.sh) is not implemented")
+            U = self._prepare()
+            qweight, d, s, dmin, m = _ops.gptq_quantize(
+                self.W, U, int(q_type), self.block_size, self.static_groups, self.rmin, self.rdelta, self.nstep)
+            del U
+        else:
+            qweight = torch.empty(d_row, d_col, device=dev, dtype=q_dtype)
+            d = torch.empty(d_row, nsg, device=dev, dtype=torch.float16)
+            dmin = torch.empty(d_row, nsg, device=dev, dtype=torch.float16)
+            s = torch.empty(d_row, ng, device=dev, dtype=sz_dtype)
+            m = torch.empty(d_row, ng, device=dev, dtype=sz_dtype)
+        if dist_utils.is_dist_available_and_initialized() and dist_utils.get_world_size() > 1:
+            for t in (qweight, d, dmin, s, m):  # reference gptq.py:287-293 (src = owner instead of 0)
+                dist.broadcast(t, src=self.owner_rank)
+        # reference return order (gptq.py:295)
+        return qweight, d, s, dmin, m
+
+    def quantize(self, q_type: GGMLQuantizationType):
+        self.quantization_pre_step()
+        return self.step(q_type)
