@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""bench.py -- Mparams/s GPTQ-quantized on synthetic Llama-shaped Linears (BASELINE.json metric).
+
+One "step" = one pass of the hot path over ONE Llama-3-8B transformer block
+(configs[1]: Llama-3-8B -> Q4_K, 128 x 2048-token calibration): 218.1 M parameters in 7
+Linears.  Inside the timed region, per step:
+  * H accumulation from the calibration activations of the 4 distinct Linear inputs
+    (attn-in feeds q/k/v, o-in, mlp-in feeds gate/up, down-in), one gq_h_accumulate per
+    sequence exactly like the reference's forward hook (gptq.py:79-114);
+  * [N>1] one RCCL all-reduce (AVG) per distinct Hessian (gptq.py:131-132);
+  * per Linear, on its owner rank: fp32 working copy, gq_h_prepare (damping + Cholesky
+    chain), gq_gptq_quantize (scale search + column loop + trailing update),
+    gq_dequantize to fp16 (the write-back of quantizer.py:257-264) and gq_pack
+    (GGUF block bytes);
+  * [N>1] broadcast of the dequantized fp16 weight from the owner (needed by every rank
+    for the block's second forward).
+Inputs (weights, activations) are resident in HBM before the timed region starts.
+There is no model forward here (synthetic Linears), so this is the GPTQ.quantize region
+of quantizer.py:248-265 plus the hook-side H updates.
+
+Prints ONE JSON line on rank 0 (see the driver contract).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from gptq_gguf_toolkit_amd import _cabi, dist_utils, ops  # noqa: E402
+
+Q4_K = 12
+# Llama-3-8B block: name -> (R, C, input group)
+LLAMA3_8B = {
+    "q_proj": (4096, 4096, "attn_in"), "k_proj": (1024, 4096, "attn_in"), "v_proj": (1024, 4096, "attn_in"),
+    "o_proj": (4096, 4096, "o_in"), "gate_proj": (14336, 4096, "mlp_in"), "up_proj": (14336, 4096, "mlp_in"),
+    "down_proj": (4096, 14336, "down_in"),
+}
+TINY = {  # TinyLlama-1.1B block (configs[0] shapes) for quick runs
+    "q_proj": (2048, 2048, "attn_in"), "k_proj": (256, 2048, "attn_in"), "v_proj": (256, 2048, "attn_in"),
+    "o_proj": (2048, 2048, "o_in"), "gate_proj": (5632, 2048, "mlp_in"), "up_proj": (5632, 2048, "mlp_in"),
+    "down_proj": (2048, 5632, "down_in"),
+}
+PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X dense fp16/bf16 MFMA (MI355X_MICROARCH.md)
+
+
+def make_inputs(shapes, nseq, L, dev, seed=1):
+    """X ~ N(0,1) * sigma_c, sigma_c log-normal, 0.1 % outlier channels x20, fp16."""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    X = {}
+    for name, (R, C, inp) in shapes.items():
+        if inp in X:
+            continue
+        sig = torch.exp(torch.randn(C, device=dev, generator=g) * 0.5)
+        nout = max(1, C // 1000)
+        sig[torch.randperm(C, device=dev, generator=g)[:nout]] *= 20.0
+        x = torch.empty(nseq, L, C, device=dev, dtype=torch.float16)
+        for s in range(nseq):
+            x[s] = (torch.randn(L, C, device=dev, generator=g) * sig).half()
+        X[inp] = x
+    return X
+
+
+def make_weights(shapes, dev, seed=0):
+    W = {}
+    for i, (name, (R, C, _)) in enumerate(shapes.items()):
+        g = torch.Generator(device=dev).manual_seed(seed + i)
+        W[name] = (torch.randn(R, C, device=dev, generator=g) * 0.02).half()
+    return W
+
+
+def quantize_block(shapes, W16, X, owners, rank, world, q_type=Q4_K, block_size=128, rel_damp=0.01, keep=None):
+    dev = next(iter(W16.values())).device
+    # ---- Hessians: one per distinct input, one update per (local) sequence
+    H = {}
+    for inp, x in X.items():
+        C = x.shape[-1]
+        h = torch.zeros(C, C, device=dev, dtype=torch.float32)
+        ws = torch.empty(ops.workspace_bytes(_cabi.WS_H_ACCUMULATE, 0, C, x.shape[1]), dtype=torch.uint8, device=dev)
+        n = 0
+        for s in range(x.shape[0]):
+            ops.h_accumulate(h, x[s], n / (n + 1), 2.0 / (n + 1), ws)  # b = 1 per 3-D sample (gptq.py:88)
+            n += 1
+        H[inp] = h
+    if world > 1:
+        for inp in sorted(H):
+            dist.all_reduce(H[inp], op=dist.ReduceOp.AVG)  # RCCL over xGMI
+    # ---- per Linear on its owner
+    out = {}
+    for name, (R, C, inp) in shapes.items():
+        deq = None
+        if owners[name] == rank:
+            Wf = W16[name].float()
+            Hc = H[inp].clone()  # each reference handle damps its own H
+            U, flag = ops.h_prepare(Hc, Wf, rel_damp)
+            q, d, s, dmin, m = ops.gptq_quantize(Wf, U, q_type, block_size)
+            deq = ops.dequantize(q_type, q, d, s, dmin, m, torch.float16)
+            packed = ops.pack(q_type, q, d, s, dmin, m)
+            if keep is not None:
+                keep[name] = (q, d, s, dmin, m, packed, flag, U if name == "k_proj" else None)
+            del U, Hc, Wf
+        if world > 1:
+            if deq is None:
+                deq = torch.empty(R, C, device=dev, dtype=torch.float16)
+            dist.broadcast(deq, src=owners[name])
+        out[name] = deq
+    return out
+
+
+def cpu_baseline(shapes, W16, keep):
+    """Oracle (C restatement of the reference, OpenMP) on the host cores: GPTQ.step of the
+    k_proj-shaped Linear given the same U the GPU used.  ~10-30 s of CPU work."""
+    try:
+        from oracle import oracle as O
+        R, C, _ = shapes["k_proj"]
+        U = keep["k_proj"][7].cpu().numpy()
+        W = W16["k_proj"].float().cpu().numpy()
+        threads = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+        t0 = time.perf_counter()
+        _, oq, *_ = O.gptq_step(W, U, Q4_K, block_size=128)
+        dt = time.perf_counter() - t0
+        same = float((oq == keep["k_proj"][0].cpu().numpy()).mean())
+        return {"value": round(R * C / dt / 1e6, 3), "unit": "Mparams/s", "cores": threads, "kind": "port",
+                "sample": f"GPTQ.step (scale search + column loop + trailing update, given U) of one {R}x{C} "
+                          f"Q4_K Linear (k_proj), {dt:.1f} s; ints equal to the GPU's: {same:.6f}"}
+    except Exception as e:  # the bench line must still print
+        return {"value": None, "unit": "Mparams/s", "cores": 0, "kind": "port", "sample": f"failed: {e!r}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="llama3-8b-block-q4k", choices=["llama3-8b-block-q4k", "tinyllama-block-q4k"])
+    ap.add_argument("--calib-seqs", type=int, default=None)
+    ap.add_argument("--seq-len", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", action="store_true", help="one extra profiled step: per-kernel ms to stderr")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP extension has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    if args.workload == "llama3-8b-block-q4k":
+        shapes, nseq, L = LLAMA3_8B, args.calib_seqs or 128, args.seq_len or 2048
+    else:
+        shapes, nseq, L = TINY, args.calib_seqs or 32, args.seq_len or 512
+    nseq_local = nseq // world  # contiguous shard, remainder dropped (quant.py:177-179)
+    params = sum(R * C for R, C, _ in shapes.values())
+    costs = {n: float(R) * C * (C + 128) for n, (R, C, _) in shapes.items()}
+    owners = dist_utils.assign_owners(costs, world)
+
+    W16 = make_weights(shapes, dev)
+    X = make_inputs(shapes, nseq_local, L, dev, seed=1 + rank)
+    torch.cuda.synchronize()
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        quantize_block(shapes, W16, X, owners, rank, world)
+    sync()
+    # dominant kernel (the fp16 MFMA SYRK of the Hessian accumulation) timed live with HIP
+    # events on its launch stream, inside the timed region
+    _cabi.prof_enable(["syrk"])
+    keep = {}
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        quantize_block(shapes, W16, X, owners, rank, world, keep=keep if i == args.steps - 1 else None)
+    sync()
+    dt = time.perf_counter() - t0
+    prof = _cabi.prof_collect()
+    _cabi.prof_enable([])
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    if args.breakdown and rank == 0:
+        _cabi.prof_enable(None)
+        quantize_block(shapes, W16, X, owners, rank, world)
+        torch.cuda.synchronize()
+        bd = _cabi.prof_collect()
+        _cabi.prof_enable([])
+        tot = sum(v[0] for v in bd.values())
+        for k, (ms, n) in sorted(bd.items(), key=lambda kv: -kv[1][0]):
+            print(f"  {k:22s} {ms:10.2f} ms  {n:6d} launches  {100 * ms / tot:5.1f} %", file=sys.stderr)
+
+    if rank == 0:
+        # roofline of the dominant kernel: executed MFMA flops per launch of the upper-triangular
+        # 128x128-tile SYRK = 2 * T * 128*128 * ntiles, over the live average duration
+        syrk_ms, syrk_n = prof.get("syrk", (0.0, 0))
+        flops = 0.0
+        for inp, x in X.items():
+            C = x.shape[-1]
+            nt = C // 128
+            flops += x.shape[0] * args.steps * 2.0 * L * 128 * 128 * (nt * (nt + 1) // 2)
+        ach = flops / (syrk_ms * 1e-3) / 1e12 if syrk_ms > 0 else None
+        roof = {"bound": "mfma", "kernel": "syrk16_kernel<f16> (gq_h_accumulate)",
+                "achieved": round(ach, 2) if ach else None, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_F16_MFMA_TFLOPS, 4) if ach else None, "traffic": None,
+                "launches": syrk_n, "avg_launch_ms": round(syrk_ms / max(syrk_n, 1), 4),
+                "share_of_step": round(syrk_ms / 1e3 / dt, 3)}
+        line = {
+            "metric": "Mparams/s GPTQ-quantized", "value": round(params * args.steps / dt / 1e6, 2),
+            "unit": "Mparams/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: 7 Linears of one block ({params / 1e6:.1f} M params), "
+                                   f"{nseq}x{L}-token calibration, block_size 128, rel_damp 0.01, nstep 20",
+                       "calib_seqs_per_rank": nseq_local, "parallelism": f"calib-dp{world}+matrix-fanout",
+                       "owners": owners if world > 1 else "rank0"},
+            "wall_s_llama3_8b_32_blocks_extrapolated": round(dt / args.steps * 32, 2)
+            if args.workload.startswith("llama3") else None,
+            "roofline": roof,
+            "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline(shapes, W16, keep),
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -17,6 +17,7 @@ WS_H_ACCUMULATE, WS_H_PREPARE, WS_GPTQ_QUANTIZE = 1, 2, 3
 EXPORTS = (
     "gq_abi_version", "gq_last_error", "gq_type_info", "gq_workspace_bytes", "gq_h_accumulate", "gq_h_prepare",
     "gq_scale_search", "gq_gptq_quantize", "gq_rtn_quantize", "gq_dequantize", "gq_pack", "gq_trailing_update",
+    "gq_prof_enable", "gq_prof_ntags", "gq_prof_name", "gq_prof_collect",
 )
 
 
@@ -69,6 +70,11 @@ def lib():
     L.gq_dequantize.argtypes = [ci, vp, vp, vp, vp, vp, i64, i64, vp, ci, vp]
     L.gq_pack.argtypes = [ci, vp, vp, vp, vp, vp, i64, i64, vp, vp]
     L.gq_trailing_update.argtypes = [vp, i64, vp, i64, vp, i64, i64, i64, i64, vp]
+    L.gq_prof_enable.argtypes = [ctypes.c_uint]
+    L.gq_prof_enable.restype = None
+    L.gq_prof_name.argtypes = [ci]
+    L.gq_prof_name.restype = ctypes.c_char_p
+    L.gq_prof_collect.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long)]
     for name in EXPORTS:
         getattr(L, name)  # raises AttributeError if the .so lacks a declared symbol
     _lib = L
@@ -85,3 +91,25 @@ def type_info(q_type: int) -> dict:
     t = TypeInfo()
     check(lib().gq_type_info(int(q_type), ctypes.byref(t)), "gq_type_info")
     return {n: getattr(t, n) for n, _ in TypeInfo._fields_}
+
+
+def prof_enable(tags=None):
+    """Enable HIP-event timing for the named kernel tags (None = all, [] = off)."""
+    L = lib()
+    names = [L.gq_prof_name(i).decode() for i in range(L.gq_prof_ntags())]
+    mask = 0
+    for i, n in enumerate(names):
+        if tags is None or n in tags:
+            mask |= 1 << i
+    L.gq_prof_enable(mask)
+    return names
+
+
+def prof_collect() -> dict:
+    """{tag: (total_ms, launches)} since the last collect (synchronises the recorded events)."""
+    L = lib()
+    n = L.gq_prof_ntags()
+    ms = (ctypes.c_double * n)()
+    cnt = (ctypes.c_long * n)()
+    check(L.gq_prof_collect(ms, cnt), "gq_prof_collect")
+    return {L.gq_prof_name(i).decode(): (ms[i], cnt[i]) for i in range(n) if cnt[i]}

@@ -25,6 +25,36 @@ size_t h_prepare_workspace_bytes(int64_t, int64_t);
 int h_prepare(float*, float*, int64_t, int64_t, float, float*, int*, void*, size_t, hipStream_t);
 }  // namespace gq
 
+#include <mutex>
+#include <vector>
+
+namespace gq {
+unsigned g_prof_mask = 0;
+namespace {
+struct Rec { hipEvent_t a, b; int tag; };
+std::vector<Rec> g_recs;
+std::vector<hipEvent_t> g_pool;
+std::mutex g_mu;
+hipEvent_t get_event() {
+    if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+    hipEvent_t e;
+    hipEventCreate(&e);
+    return e;
+}
+}  // namespace
+void prof_begin(int tag, hipStream_t st) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    Rec r{get_event(), get_event(), tag};
+    hipEventRecord(r.a, st);
+    g_recs.push_back(r);
+}
+void prof_end(int tag, hipStream_t st) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (size_t i = g_recs.size(); i-- > 0;)
+        if (g_recs[i].tag == tag) { hipEventRecord(g_recs[i].b, st); break; }
+}
+}  // namespace gq
+
 using namespace gq;
 
 extern "C" {
@@ -113,6 +143,31 @@ int gq_trailing_update(float* Cmat, int64_t ldc, const float* A, int64_t lda, co
                        int64_t N, int64_t K, void* stream) {
     if (!Cmat || !A || !B) GQ_FAIL(GQ_E_NULL, "gq_trailing_update: null pointer");
     return launch_trailing_update(Cmat, ldc, A, lda, B, ldb, M, N, K, (hipStream_t)stream);
+}
+
+// ---- profiling (bench.py): HIP-event timing of selected kernels on their launch stream ----
+void gq_prof_enable(unsigned tag_mask) { g_prof_mask = tag_mask; }
+int gq_prof_ntags(void) { return PT_COUNT; }
+const char* gq_prof_name(int tag) {
+    static const char* names[PT_COUNT] = {"transpose16", "syrk", "prepare_elementwise", "diag_potrf_inv", "potrf_gemm32",
+                                          "trtri_gemm32", "scale_search", "gptq_segment", "trailing_gemm32",
+                                          "block_far_update", "dequantize", "rtn_quantize", "pack"};
+    return (tag >= 0 && tag < PT_COUNT) ? names[tag] : "?";
+}
+/* synchronises the recorded events; ms[tag], n[tag] accumulate; records are recycled */
+int gq_prof_collect(double* ms_host, long* n_host) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto& r : g_recs) {
+        float t = 0.f;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) {
+            ms_host[r.tag] += t;
+            n_host[r.tag] += 1;
+        }
+        g_pool.push_back(r.a);
+        g_pool.push_back(r.b);
+    }
+    g_recs.clear();
+    return GQ_OK;
 }
 
 }  // extern "C"

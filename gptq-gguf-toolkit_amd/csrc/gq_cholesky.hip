@@ -195,6 +195,8 @@ int h_prepare(float* H, float* W, int64_t R, int64_t C, float rel_damp, float* U
     int rc;
 
     GQ_HIP(hipMemsetAsync(not_invertible, 0, sizeof(int), st));
+    {
+    ProfScope ps(PT_PREP_ELEM, st);
     hipLaunchKernelGGL(col_flags_kernel, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, st, H, W, R, C, dead, zc);
     GQ_LAUNCH_CHECK();
     hipLaunchKernelGGL(zero_dead_cols_kernel, dim3(2048), dim3(256), 0, st, W, R, C, dead);
@@ -206,6 +208,7 @@ int h_prepare(float* H, float* W, int64_t R, int64_t C, float rel_damp, float* U
     hipLaunchKernelGGL(reverse_copy_kernel, dim3(4096), dim3(256), 0, st, A, H, n);
     GQ_LAUNCH_CHECK();
     GQ_HIP(hipMemsetAsync(X, 0, (size_t)n * n * sizeof(float), st));
+    }
 
     static bool attr_set = false;
     const size_t diag_lds = 2 * NB * NBP * sizeof(float);
@@ -217,10 +220,14 @@ int h_prepare(float* H, float* W, int64_t R, int64_t C, float rel_damp, float* U
     for (int64_t k = 0; k < nblk; ++k) {
         float* Akk = A + (k * NB) * n + k * NB;
         float* Dk = Dinv + k * NB * NB;
-        hipLaunchKernelGGL(diag_potrf_inv_kernel, dim3(1), dim3(256), diag_lds, st, Akk, n, Dk, not_invertible);
-        GQ_LAUNCH_CHECK();
+        {
+            ProfScope ps(PT_DIAG_POTRF, st);
+            hipLaunchKernelGGL(diag_potrf_inv_kernel, dim3(1), dim3(256), diag_lds, st, Akk, n, Dk, not_invertible);
+            GQ_LAUNCH_CHECK();
+        }
         const int64_t mrem = n - (k + 1) * NB;
         if (mrem > 0) {
+            ProfScope ps(PT_CHOL_GEMM, st);
             float* A21 = A + ((k + 1) * NB) * n + k * NB;
             // A21 <- A21 * L11^-T   (in place: a workgroup owns whole rows, N == one tile)
             if ((rc = launch_gemm32<true, 1, false>(A21, n, A21, n, Dk, NB, mrem, NB, NB, st))) return rc;
@@ -229,7 +236,11 @@ int h_prepare(float* H, float* W, int64_t R, int64_t C, float rel_damp, float* U
             if ((rc = launch_gemm32<true, 0, true>(A22, n, A21, n, A21, n, mrem, mrem, NB, st))) return rc;
         }
     }
-    if ((rc = trtri_rec(A, X, U, Dinv, n, 0, nblk, st))) return rc;
+    {
+        ProfScope ps(PT_TRTRI_GEMM, st);
+        if ((rc = trtri_rec(A, X, U, Dinv, n, 0, nblk, st))) return rc;
+    }
+    ProfScope ps(PT_PREP_ELEM, st);
     hipLaunchKernelGGL(finish_u_kernel, dim3(4096), dim3(256), 0, st, U, X, n, not_invertible);
     GQ_LAUNCH_CHECK();
     return GQ_OK;

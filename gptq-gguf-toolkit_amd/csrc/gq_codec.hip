@@ -60,6 +60,7 @@ int launch_dequantize(int q_type, const uint8_t* q, const uint16_t* d, const uin
     if (R <= 0 || C <= 0 || C % 256) GQ_FAIL(GQ_E_BAD_SHAPE, "gq_dequantize: R=%ld C=%ld", (long)R, (long)C);
     const int64_t n16 = R * C / 16;
     dim3 grid((unsigned)((n16 + 255) / 256 < 8192 ? (n16 + 255) / 256 : 8192)), block(256);
+    ProfScope ps(PT_DEQUANT, st);
     switch (out_dtype) {
     case GQ_F32:
         hipLaunchKernelGGL(dequantize_kernel<float>, grid, block, 0, st, q, d, s, dmin, m, R, C, ti.group,
@@ -118,6 +119,7 @@ int launch_rtn_elementwise(const void* W, int w_dtype, const uint16_t* d, const 
     const int64_t n16 = R * C / 16;
     dim3 grid((unsigned)((n16 + 255) / 256 < 8192 ? (n16 + 255) / 256 : 8192)), block(256);
     const float qmin = (float)ti.qmin, qmax = (float)ti.qmax;
+    ProfScope ps(PT_RTN, st);
     switch (w_dtype) {
     case GQ_F32:
         hipLaunchKernelGGL(rtn_quantize_kernel<GQ_F32>, grid, block, 0, st, W, d, s, dmin, m, R, C, ti.group,
@@ -276,6 +278,7 @@ int launch_pack(int q_type, const uint8_t* q, const uint16_t* d, const uint8_t* 
     const int64_t nblocks = R * (C / 256);
     int64_t g = (nblocks + PB - 1) / PB;
     dim3 grid((unsigned)(g < 4096 ? g : 4096)), block(256);
+    ProfScope ps(PT_PACK, st);
     switch (q_type) {
     case GQ_Q2_K: hipLaunchKernelGGL((pack_kernel<GQ_Q2_K, 84, 16>), grid, block, 0, st, q, d, s, dmin, m, nblocks, out); break;
     case GQ_Q3_K: hipLaunchKernelGGL((pack_kernel<GQ_Q3_K, 110, 16>), grid, block, 0, st, q, d, s, dmin, m, nblocks, out); break;

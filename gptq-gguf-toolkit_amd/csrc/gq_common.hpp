@@ -81,4 +81,24 @@ __device__ __forceinline__ float quantize1(float x, float ds, float dm, float qm
 }
 __device__ __forceinline__ float dequantize1(float q, float ds, float dm) { return ds * q - dm; }
 
+// ---- optional per-kernel timing with HIP events on the launch stream (bench.py) ----
+enum ProfTag {
+    PT_TRANSPOSE = 0, PT_SYRK, PT_PREP_ELEM, PT_DIAG_POTRF, PT_CHOL_GEMM, PT_TRTRI_GEMM, PT_SCALE_SEARCH,
+    PT_GPTQ_SEGMENT, PT_TRAILING, PT_BLOCK_FAR, PT_DEQUANT, PT_RTN, PT_PACK, PT_COUNT
+};
+extern unsigned g_prof_mask;
+void prof_begin(int tag, hipStream_t st);
+void prof_end(int tag, hipStream_t st);
+struct ProfScope {
+    int tag;
+    hipStream_t st;
+    bool on;
+    ProfScope(int t, hipStream_t s) : tag(t), st(s), on((g_prof_mask >> t) & 1u) {
+        if (on) prof_begin(tag, st);
+    }
+    ~ProfScope() {
+        if (on) prof_end(tag, st);
+    }
+};
+
 }  // namespace gq

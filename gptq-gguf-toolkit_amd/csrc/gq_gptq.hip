@@ -140,6 +140,7 @@ __global__ __launch_bounds__(256) void copy2d_kernel(float* __restrict__ dst, in
 // gq_gemm32.hpp (MODE 0: k-ordered fma chain from 0, then one subtraction).
 int launch_trailing_update(float* Cmat, int64_t ldc, const float* A, int64_t lda, const float* B, int64_t ldb,
                            int64_t M, int64_t N, int64_t K, hipStream_t st) {
+    ProfScope ps(PT_TRAILING, st);
     return launch_gemm32<false, 0, false>(Cmat, ldc, A, lda, B, ldb, M, N, K, st);
 }
 
@@ -182,6 +183,7 @@ int gptq_quantize(float* W, const float* U, int64_t R, int64_t C, int q_type, in
         const bool single = (c2 - c1) <= SEG && (c1 / 256 == (c2 - 1) / 256);
         const int64_t ncols = c2 - c1;
         if (!single) {  // w_blk lives in scratch
+            ProfScope ps(PT_BLOCK_FAR, st);
             hipLaunchKernelGGL(copy2d_kernel, dim3(2048), dim3(256), 0, st, Wblk, B, W + c1, C, R, ncols);
             GQ_LAUNCH_CHECK();
         }
@@ -203,11 +205,15 @@ int gptq_quantize(float* W, const float* U, int64_t R, int64_t C, int q_type, in
             }
             const float* srcp = single ? (W + a) : (Wblk + (a - c1));
             const int64_t ld_src = single ? C : B;
-            hipLaunchKernelGGL(gptq_segment_kernel, seg_grid, seg_block, 0, st, W, C, srcp, ld_src, U, a, len, R, d, s,
-                               dmin, m, ti.group, ti.is_signed, (float)ti.qmin, (float)ti.qmax, qweight, Err, B,
-                               a - c1);
-            GQ_LAUNCH_CHECK();
+            {
+                ProfScope ps(PT_GPTQ_SEGMENT, st);
+                hipLaunchKernelGGL(gptq_segment_kernel, seg_grid, seg_block, 0, st, W, C, srcp, ld_src, U, a, len, R, d,
+                                   s, dmin, m, ti.group, ti.is_signed, (float)ti.qmin, (float)ti.qmax, qweight, Err, B,
+                                   a - c1);
+                GQ_LAUNCH_CHECK();
+            }
             if (e < c2) {  // push this segment's rank-1 updates into the rest of the block
+                ProfScope ps(PT_BLOCK_FAR, st);
                 hipLaunchKernelGGL(block_far_update_kernel, dim3(2048), dim3(256), 0, st, Wblk + (e - c1), B,
                                    c2 - e, R, Err, B, a - c1, len, U, C, a, e);
                 GQ_LAUNCH_CHECK();

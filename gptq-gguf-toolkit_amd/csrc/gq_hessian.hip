@@ -216,6 +216,7 @@ int h_accumulate(float* H, const void* X, int x_dtype, int64_t T, int64_t C, flo
     const int64_t nt = (C + HT - 1) / HT;
     const dim3 grid((unsigned)(nt * (nt + 1) / 2)), block(256);
     if (x_dtype == GQ_F32) {
+        ProfScope ps(PT_SYRK, st);
         hipLaunchKernelGGL(syrk32_kernel, grid, block, 0, st, H, C, (const float*)X, T, beta, alpha);
         GQ_LAUNCH_CHECK();
         return GQ_OK;
@@ -226,8 +227,12 @@ int h_accumulate(float* H, const void* X, int x_dtype, int64_t T, int64_t C, flo
     const int64_t Tp = (T + HK - 1) / HK * HK;
     uint16_t* Xt = reinterpret_cast<uint16_t*>(((uintptr_t)ws + 255) & ~(uintptr_t)255);
     dim3 tg((unsigned)((Tp + 63) / 64), (unsigned)((C + 63) / 64));
-    hipLaunchKernelGGL(transpose16_kernel, tg, block, 0, st, (const uint16_t*)X, T, C, Xt, Tp);
-    GQ_LAUNCH_CHECK();
+    {
+        ProfScope ps(PT_TRANSPOSE, st);
+        hipLaunchKernelGGL(transpose16_kernel, tg, block, 0, st, (const uint16_t*)X, T, C, Xt, Tp);
+        GQ_LAUNCH_CHECK();
+    }
+    ProfScope ps(PT_SYRK, st);
     if (x_dtype == GQ_BF16)
         hipLaunchKernelGGL(syrk16_kernel<true>, grid, block, 0, st, H, C, Xt, Tp, beta, alpha);
     else

@@ -268,6 +268,7 @@ int launch_scale_search(const float* x, int64_t rows, int64_t ld, int q_type, co
     for (int i = 0; i < 24; ++i) sp.num[i] = (float)(rmin + rdelta * (double)i + maxq);
     const int rpw = ti.group == 32 ? 4 : 2;
     dim3 grid((unsigned)((rows + rpw - 1) / rpw)), block(256);
+    ProfScope ps(PT_SCALE_SEARCH, st);
 #define GQ_SS(G, B, K, S, Q)                                                                                \
     hipLaunchKernelGGL((scale_search_kernel<G, B, K, S, Q>), grid, block, 0, st, x, rows, ld, sp, d, d_stride, \
                        s, s_ld, dmin, dmin_stride, m, m_ld)

@@ -137,6 +137,14 @@ int gq_pack(int q_type, const uint8_t* qweight, const uint16_t* d, const uint8_t
 int gq_trailing_update(float* Cmat, int64_t ldc, const float* A, int64_t lda, const float* B, int64_t ldb,
                        int64_t M, int64_t N, int64_t K, void* stream);
 
+/* Optional HIP-event timing of the library's own kernels, on the stream they are
+   launched on (bench.py's roofline leg).  tag_mask bit t enables tag t; collect()
+   synchronises the recorded events and ADDS elapsed ms / launch counts per tag. */
+void gq_prof_enable(unsigned tag_mask);
+int gq_prof_ntags(void);
+const char* gq_prof_name(int tag);
+int gq_prof_collect(double* ms_host, long* n_host);
+
 #ifdef __cplusplus
 }
 #endif
