@@ -51,7 +51,7 @@ class GPTQ:
     def update(self, input: Tensor) -> None:
         """H <- n/(n+b) H + 2/(n+b) X^T X  (reference gptq.py:79-114)."""
         batch_size = input.shape[0]
-        if self.shared_H_with is not None:  # this handle's H is the other handle's H (same input)
+        if self.shared_H_with is not None:  # this handle's H is the leader's H (same input tensor)
             self.num_samples += batch_size
             return
         if self.H is None:
@@ -80,26 +80,41 @@ class GPTQ:
     def quantization_pre_step(self) -> None:
         """All-reduce of H + fp32 working copy (reference gptq.py:122-143).  The dead-channel
         fix of :134-135,141 happens inside gq_h_prepare together with _prepare's masking."""
-        if self.shared_H_with is not None:
-            self.H = self.shared_H_with.H
-        assert self.H is not None, "One has to process at least one sample of calibration data to run pruning"
-        if self.shared_H_with is None or not getattr(self.shared_H_with, "_reduced", False):
-            dist_utils.allreduce_hessian(self.H)
-            self._reduced = True
-        W = self.W.detach().clone().float()
-        if isinstance(self.layer, _ConvNd):
-            W = W.flatten(1, -1)
-        self.W = W.contiguous()
+        self.sync_hessian()
+        self.make_working_copy()
         self.pre_step_completed = True
 
     @torch.no_grad()
-    def _prepare(self) -> Tensor:
-        """-> U = chol_upper(H^-1); mutates H (damping) and W (dead columns) like the reference (:304-324)."""
-        H = self.H
+    def sync_hessian(self) -> None:
+        """One collective per DISTINCT Hessian (reference gptq.py:131-132 does one per handle)."""
         if self.shared_H_with is not None:
-            H = self.H.clone()  # each reference handle damps its own copy of the (identical) H
+            leader = self.shared_H_with
+            if not getattr(leader, "_reduced", False):
+                leader.sync_hessian()
+            self.H = leader.H
+            self._reduced = True
+            return
+        assert self.H is not None, "One has to process at least one sample of calibration data to run pruning"
+        if not getattr(self, "_reduced", False):
+            dist_utils.allreduce_hessian(self.H)
+            self._reduced = True
+
+    @torch.no_grad()
+    def make_working_copy(self) -> None:
+        W = self.layer.weight.detach().clone().float()  # gptq.py:138
+        if isinstance(self.layer, _ConvNd):
+            W = W.flatten(1, -1)
+        self.W = W.contiguous()
+
+    @torch.no_grad()
+    def _prepare(self) -> Tensor:
+        """-> U = chol_upper(H^-1); mutates H (damping) and W (dead columns) like the reference (:304-324).
+        Handles that share one accumulated H each damp their own copy, as the reference's
+        independent (identical) Hessians would."""
+        shared = self.shared_H_with is not None or getattr(self, "_has_followers", False)
+        H = self.H.clone() if shared else self.H
         U, self._flag = _ops.h_prepare(H, self.W, self.rel_damp)
-        if self.shared_H_with is None:
+        if not shared:
             self.H = H
         return U
 
@@ -108,32 +123,42 @@ class GPTQ:
         return bool(self._flag is not None and int(self._flag.item()) != 0)
 
     @torch.no_grad()
-    def step(self, q_type: GGMLQuantizationType) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor]:
+    def compute(self, q_type: GGMLQuantizationType):
+        """Rank-local numerical body of step() (reference gptq.py:158-276); no communication."""
+        if q_type == GGMLQuantizationType.Q3_K:  # reference gptq.py:204-206 mutates the handle
+            self.act_order = False
+            self.static_groups = False
+        if self.act_order:
+            raise NotImplementedError("act_order (gptq.py:211-216, off in run_quant.sh) is not implemented")
+        U = self._prepare()
+        return _ops.gptq_quantize(self.W, U, int(q_type), self.block_size, self.static_groups, self.rmin,
+                                  self.rdelta, self.nstep)
+
+    def _empty_result(self, q_type):
         bits, clamp, scale_maxq, group_size, supergroup_size, sz_dtype, q_dtype = GGML_QUANT_SIZES[q_type]
-        d_row, d_col = self.d_row, self.d_col
-        dev = self.W_device
-        ng, nsg = d_col // group_size, d_col // supergroup_size
-        if dist_utils.get_rank() == self.owner_rank:
-            if q_type == GGMLQuantizationType.Q3_K:  # reference gptq.py:204-206 mutates the handle
-                self.act_order = False
-                self.static_groups = False
-            if self.act_order:
-                raise NotImplementedError("act_order (gptq.py:211-216, off in run_quant.sh) is not implemented")
-            U = self._prepare()
-            qweight, d, s, dmin, m = _ops.gptq_quantize(
-                self.W, U, int(q_type), self.block_size, self.static_groups, self.rmin, self.rdelta, self.nstep)
-            del U
-        else:
-            qweight = torch.empty(d_row, d_col, device=dev, dtype=q_dtype)
-            d = torch.empty(d_row, nsg, device=dev, dtype=torch.float16)
-            dmin = torch.empty(d_row, nsg, device=dev, dtype=torch.float16)
-            s = torch.empty(d_row, ng, device=dev, dtype=sz_dtype)
-            m = torch.empty(d_row, ng, device=dev, dtype=sz_dtype)
+        dev, R, C = self.W_device, self.d_row, self.d_col
+        return (torch.empty(R, C, device=dev, dtype=q_dtype),
+                torch.empty(R, C // supergroup_size, device=dev, dtype=torch.float16),
+                torch.empty(R, C // group_size, device=dev, dtype=sz_dtype),
+                torch.empty(R, C // supergroup_size, device=dev, dtype=torch.float16),
+                torch.empty(R, C // group_size, device=dev, dtype=sz_dtype))
+
+    @torch.no_grad()
+    def exchange(self, result, q_type: GGMLQuantizationType):
+        """Broadcast of the 5 result tensors from the owner (reference gptq.py:287-293, src=0 there)."""
+        if result is None:
+            result = self._empty_result(q_type)
         if dist_utils.is_dist_available_and_initialized() and dist_utils.get_world_size() > 1:
-            for t in (qweight, d, dmin, s, m):  # reference gptq.py:287-293 (src = owner instead of 0)
+            for t in result:
                 dist.broadcast(t, src=self.owner_rank)
-        # reference return order (gptq.py:295)
-        return qweight, d, s, dmin, m
+        return result
+
+    @torch.no_grad()
+    def step(self, q_type: GGMLQuantizationType) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor]:
+        """-> (qweight, super_group_scale, group_scale_quant, super_group_zero, group_zero_quant)
+        on every rank (reference return order, gptq.py:295)."""
+        res = self.compute(q_type) if dist_utils.get_rank() == self.owner_rank else None
+        return self.exchange(res, q_type)
 
     def quantize(self, q_type: GGMLQuantizationType):
         self.quantization_pre_step()
