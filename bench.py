@@ -75,19 +75,22 @@ def make_weights(shapes, dev, seed=0):
     return W
 
 
-def quantize_block(shapes, W16, X, owners, rank, world, q_type=Q4_K, block_size=128, rel_damp=0.01, keep=None):
+def quantize_block(shapes, W16, X, owners, rank, world, q_type=Q4_K, block_size=128, rel_damp=0.01, keep=None,
+                   hbatch=None, hws=None):
     dev = next(iter(W16.values())).device
-    # ---- Hessians: one per distinct input, one update per (local) sequence
-    H = {}
-    for inp, x in X.items():
-        C = x.shape[-1]
-        h = torch.zeros(C, C, device=dev, dtype=torch.float32)
-        ws = torch.empty(ops.workspace_bytes(_cabi.WS_H_ACCUMULATE, 0, C, x.shape[1]), dtype=torch.uint8, device=dev)
-        n = 0
-        for s in range(x.shape[0]):
-            ops.h_accumulate(h, x[s], n / (n + 1), 2.0 / (n + 1), ws)  # b = 1 per 3-D sample (gptq.py:88)
-            n += 1
-        H[inp] = h
+    # ---- Hessians: one per distinct input.  The activations of `hbatch` sequences are folded in
+    # per launch (beta = n/(n+b), alpha = 2/(n+b): the telescoped form of b single-sample updates of
+    # gptq.py:106-112), all distinct inputs of the block in ONE grouped SYRK grid.
+    H = {inp: torch.zeros(x.shape[-1], x.shape[-1], device=dev, dtype=torch.float32) for inp, x in X.items()}
+    names = list(X)
+    nseq = X[names[0]].shape[0]
+    hb = hbatch or nseq
+    n = 0
+    while n < nseq:
+        b = min(hb, nseq - n)
+        ops.h_accumulate_grouped([H[i] for i in names], [X[i][n:n + b].reshape(-1, X[i].shape[-1]) for i in names],
+                                 [n / (n + b)] * len(names), [2.0 / (n + b)] * len(names), ws=hws)
+        n += b
     if world > 1:
         for inp in sorted(H):
             dist.all_reduce(H[inp], op=dist.ReduceOp.AVG)  # RCCL over xGMI
@@ -141,6 +144,8 @@ def main():
     ap.add_argument("--workload", default="llama3-8b-block-q4k", choices=["llama3-8b-block-q4k", "tinyllama-block-q4k"])
     ap.add_argument("--calib-seqs", type=int, default=None)
     ap.add_argument("--seq-len", type=int, default=None)
+    ap.add_argument("--hessian-batch", type=int, default=None,
+                    help="sequences folded into H per SYRK launch (default: all local sequences; 1 = reference cadence)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="one extra profiled step: per-kernel ms to stderr")
     args = ap.parse_args()
@@ -167,6 +172,9 @@ def main():
 
     W16 = make_weights(shapes, dev)
     X = make_inputs(shapes, nseq_local, L, dev, seed=1 + rank)
+    hb = args.hessian_batch or nseq_local
+    hws = torch.empty(sum(ops.workspace_bytes(_cabi.WS_H_ACCUMULATE, 0, x.shape[-1], hb * L) for x in X.values()),
+                      dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
 
     def sync():
@@ -175,7 +183,7 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        quantize_block(shapes, W16, X, owners, rank, world)
+        quantize_block(shapes, W16, X, owners, rank, world, hbatch=hb, hws=hws)
     sync()
     # dominant kernel (the fp16 MFMA SYRK of the Hessian accumulation) timed live with HIP
     # events on its launch stream, inside the timed region
@@ -183,7 +191,8 @@ def main():
     keep = {}
     t0 = time.perf_counter()
     for i in range(args.steps):
-        quantize_block(shapes, W16, X, owners, rank, world, keep=keep if i == args.steps - 1 else None)
+        quantize_block(shapes, W16, X, owners, rank, world, keep=keep if i == args.steps - 1 else None, hbatch=hb,
+                       hws=hws)
     sync()
     dt = time.perf_counter() - t0
     prof = _cabi.prof_collect()
@@ -195,7 +204,7 @@ def main():
 
     if args.breakdown and rank == 0:
         _cabi.prof_enable(None)
-        quantize_block(shapes, W16, X, owners, rank, world)
+        quantize_block(shapes, W16, X, owners, rank, world, hbatch=hb, hws=hws)
         torch.cuda.synchronize()
         bd = _cabi.prof_collect()
         _cabi.prof_enable([])
@@ -211,9 +220,9 @@ def main():
         for inp, x in X.items():
             C = x.shape[-1]
             nt = C // 128
-            flops += x.shape[0] * args.steps * 2.0 * L * 128 * 128 * (nt * (nt + 1) // 2)
+            flops += x.shape[0] * args.steps * 2.0 * L * 128 * 128 * (nt * (nt + 1) // 2)  # all launches together
         ach = flops / (syrk_ms * 1e-3) / 1e12 if syrk_ms > 0 else None
-        roof = {"bound": "mfma", "kernel": "syrk16_kernel<f16> (gq_h_accumulate)",
+        roof = {"bound": "mfma", "kernel": "syrk16_kernel<f16> (gq_h_accumulate_grouped)",
                 "achieved": round(ach, 2) if ach else None, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_F16_MFMA_TFLOPS, 4) if ach else None, "traffic": None,
                 "launches": syrk_n, "avg_launch_ms": round(syrk_ms / max(syrk_n, 1), 4),
@@ -224,7 +233,8 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: 7 Linears of one block ({params / 1e6:.1f} M params), "
-                                   f"{nseq}x{L}-token calibration, block_size 128, rel_damp 0.01, nstep 20",
+                                   f"{nseq}x{L}-token calibration ({hb} sequences per Hessian launch), block_size 128, "
+                                   f"rel_damp 0.01, nstep 20",
                        "calib_seqs_per_rank": nseq_local, "parallelism": f"calib-dp{world}+matrix-fanout",
                        "owners": owners if world > 1 else "rank0"},
             "wall_s_llama3_8b_32_blocks_extrapolated": round(dt / args.steps * 32, 2)

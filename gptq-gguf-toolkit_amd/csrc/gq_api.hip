@@ -21,6 +21,8 @@ int gptq_quantize(float*, const float*, int64_t, int64_t, int, int, int, const g
                   uint8_t*, uint16_t*, uint8_t*, void*, size_t, hipStream_t);
 size_t h_accumulate_workspace_bytes(int64_t, int64_t);
 int h_accumulate(float*, const void*, int, int64_t, int64_t, float, float, void*, size_t, hipStream_t);
+int h_accumulate_grouped(int, float* const*, const void* const*, const int64_t*, const int64_t*, const float*, const float*,
+                         int, void*, size_t, hipStream_t);
 size_t h_prepare_workspace_bytes(int64_t, int64_t);
 int h_prepare(float*, float*, int64_t, int64_t, float, float*, int*, void*, size_t, hipStream_t);
 }  // namespace gq
@@ -83,6 +85,13 @@ size_t gq_workspace_bytes(int op, int64_t R, int64_t C, int64_t T, int block_siz
 int gq_h_accumulate(float* H, const void* X, int x_dtype, int64_t T, int64_t C, float beta, float alpha, void* ws,
                     size_t ws_bytes, void* stream) {
     return h_accumulate(H, X, x_dtype, T, C, beta, alpha, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int gq_h_accumulate_grouped(int n, float* const* H_host, const void* const* X_host, const int64_t* T_host,
+                            const int64_t* C_host, const float* beta_host, const float* alpha_host, int x_dtype, void* ws,
+                            size_t ws_bytes, void* stream) {
+    return h_accumulate_grouped(n, H_host, X_host, T_host, C_host, beta_host, alpha_host, x_dtype, ws, ws_bytes,
+                                (hipStream_t)stream);
 }
 
 int gq_h_prepare(float* H, float* W, int64_t R, int64_t C, float rel_damp, float* U, int* not_invertible, void* ws,

@@ -39,9 +39,33 @@ __global__ __launch_bounds__(256) void transpose16_kernel(const uint16_t* __rest
 }
 
 // ------------------------------------------------------------ 16-bit SYRK
-constexpr int HT = 128;       // output tile
-constexpr int HK = 32;        // k per stage (16-bit elements)
-constexpr int HLD = HK + 8;   // LDS row stride in elements (80 B: keeps 16-B alignment)
+// Grouped launch: up to 8 problems (the distinct Linear inputs of one transformer
+// block) share one grid, so the tile count is >> 256 CUs even when C = 4096 gives only
+// 528 upper-triangular tiles per Hessian.
+//
+// Workgroup = 256 threads = 4 waves (2x2), tile 128x128, wave tile 64x64 = 2x2
+// v_mfma_f32_32x32x16_{f16,bf16}.  K streams in stages of 64 elements (128 B per row)
+// through a double-buffered 64 KiB LDS image filled with global_load_lds_dwordx4
+// (16 B per lane, no VGPR round trip).  The LDS image is row-major [128][128 B] with the
+// eight 16-B chunks of a row XOR-swizzled by (row & 7): global_load_lds writes lane-linear,
+// so the swizzle is applied to the per-lane SOURCE address (8 consecutive lanes still
+// fetch one full 128-B line) and again on the ds_read_b128 fragment address.
+constexpr int HT = 128;  // output tile
+constexpr int HK = 64;   // k per stage (16-bit elements) = 128 B per row
+constexpr int H_STAGE_BYTES = 2 * HT * HK * 2;  // A + B = 32 KiB
+constexpr int H_MAX_GROUP = 8;
+
+struct SyrkProblem {
+    float* H;
+    const uint16_t* Xt;
+    int64_t C, Tp;
+    float beta, alpha;
+    int tile_begin, nt;
+};
+struct SyrkGroup {
+    int n, total_tiles;
+    SyrkProblem p[H_MAX_GROUP];
+};
 
 template <bool BF16>
 __device__ __forceinline__ f32x16 mfma16(const uint4& a, const uint4& b, f32x16 c) {
@@ -64,17 +88,30 @@ __device__ __forceinline__ void tri_tile(int64_t bid, int64_t nt, int64_t& ti, i
     tj = i + rem;
 }
 
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
 template <bool BF16>
-__global__ __launch_bounds__(256) void syrk16_kernel(float* __restrict__ H, int64_t C, const uint16_t* __restrict__ Xt,
-                                                     int64_t Tp, float beta, float alpha) {
-    __shared__ __attribute__((aligned(16))) uint16_t As[HT * HLD];
-    __shared__ __attribute__((aligned(16))) uint16_t Bs[HT * HLD];
+__global__ __launch_bounds__(256, 2) void syrk16_kernel(const SyrkGroup grp) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 stages x (A 16 KiB | B 16 KiB)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
-    const int64_t nt = (C + HT - 1) / HT;
+    // XCD-aware bijective remap: block b runs on XCD b % 8; give each XCD a contiguous run of
+    // logical tiles (same tile row => the A panel stays in that XCD's L2)
+    int logical;
+    {
+        const int n = grp.total_tiles, q = n >> 3, r = n & 7, xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    int pi = 0;
+    for (int i = 1; i < grp.n; ++i)
+        if (logical >= grp.p[i].tile_begin) pi = i;
+    const SyrkProblem& P = grp.p[pi];
     int64_t ti, tj;
-    tri_tile(blockIdx.x, nt, ti, tj);
-    const int64_t i0 = ti * HT, j0 = tj * HT;
+    tri_tile(logical - P.tile_begin, P.nt, ti, tj);
+    const int64_t i0 = ti * HT, j0 = tj * HT, Tp = P.Tp, C = P.C;
+    const uint16_t* __restrict__ Xt = P.Xt;
+
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -83,36 +120,67 @@ __global__ __launch_bounds__(256) void syrk16_kernel(float* __restrict__ H, int6
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-    const int li = lane & 31, lk = lane >> 5;
-    for (int64_t k0 = 0; k0 < Tp; k0 += HK) {
-        // stage: 128 rows x 32 elements = 128 x 4 uint4 per operand; 2 per thread each
+    // staging map: chunk p = t*256 + tid (16 B each), row = p>>3, stored chunk kc' = p&7 holds k-chunk kc'^(row&7)
+    const uint16_t* srcA[4];
+    const uint16_t* srcB[4];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            int idx = tid + t * 256;
-            int rr = idx >> 2, c8 = (idx & 3) * 8;
-            uint4 va = make_uint4(0, 0, 0, 0), vb = make_uint4(0, 0, 0, 0);
-            if (i0 + rr < C) va = *reinterpret_cast<const uint4*>(Xt + (i0 + rr) * Tp + k0 + c8);
-            if (j0 + rr < C) vb = *reinterpret_cast<const uint4*>(Xt + (j0 + rr) * Tp + k0 + c8);
-            *reinterpret_cast<uint4*>(As + rr * HLD + c8) = va;
-            *reinterpret_cast<uint4*>(Bs + rr * HLD + c8) = vb;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int kk = 0; kk < HK; kk += 16) {
-            uint4 a[2], b[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-                a[i] = *reinterpret_cast<const uint4*>(As + (wm * 64 + i * 32 + li) * HLD + kk + lk * 8);
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                b[j] = *reinterpret_cast<const uint4*>(Bs + (wn * 64 + j * 32 + li) * HLD + kk + lk * 8);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = mfma16<BF16>(a[i], b[j], acc[i][j]);
-        }
-        __syncthreads();
+    for (int t = 0; t < 4; ++t) {
+        const int p = t * 256 + tid, row = p >> 3, kc = (p & 7) ^ (row & 7);
+        srcA[t] = Xt + (i0 + row) * Tp + kc * 8;
+        srcB[t] = Xt + (j0 + row) * Tp + kc * 8;
     }
+    auto stage = [&](int buf, int64_t k0) {
+        unsigned char* base = smem + buf * H_STAGE_BYTES;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            // LDS destination = wave-uniform base + lane*16 (hardware adds the lane offset)
+            unsigned char* la = base + (t * 256 + wid * 64) * 16;
+            __builtin_amdgcn_global_load_lds((glb_void*)(srcA[t] + k0), (lds_void*)la, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void*)(srcB[t] + k0), (lds_void*)(la + HT * HK * 2), 16, 0, 0);
+        }
+    };
+    const int li = lane & 31, lk = lane >> 5;
+    int offA[2], offB[2], swz[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ra = wm * 64 + i * 32 + li, rb = wn * 64 + i * 32 + li;
+        offA[i] = ra * 128;
+        offB[i] = HT * HK * 2 + rb * 128;
+        swz[0][i] = ra & 7;
+        swz[1][i] = rb & 7;
+    }
+    const int64_t nk = Tp / HK;
+    stage(0, 0);
+    __syncthreads();
+    for (int64_t t = 0; t < nk; ++t) {
+        // 1) pull ALL fragments of stage t into registers while no LDS-DMA is in flight (hipcc
+        //    conservatively drains vmcnt before any ds_read that follows a global_load_lds)
+        const unsigned char* base = smem + (t & 1) * H_STAGE_BYTES;
+        uint4 a[4][2], b[4][2];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const int kc = s4 * 2 + lk;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[s4][i] = *reinterpret_cast<const uint4*>(base + offA[i] + ((kc ^ swz[0][i]) << 4));
+                b[s4][i] = *reinterpret_cast<const uint4*>(base + offB[i] + ((kc ^ swz[1][i]) << 4));
+            }
+        }
+        // 2) start the DMA of stage t+1 into the other buffer (last read one barrier ago)
+        if (t + 1 < nk) stage((int)((t + 1) & 1), (t + 1) * HK);
+        __builtin_amdgcn_sched_barrier(0);  // keep the DMA issue ahead of the MFMA block ...
+        // 3) 16 MFMAs per wave cover the DMA flight
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma16<BF16>(a[s4][i], b[s4][j], acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);  // ... and the MFMA block ahead of the vmcnt(0) drain
+        __syncthreads();  // vmcnt(0) + barrier: stage t+1 landed, stage t's buffer is free
+    }
+    float* __restrict__ H = P.H;
+    const float beta = P.beta, alpha = P.alpha;
     const int lc = lane & 31, lh = lane >> 5;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -122,11 +190,9 @@ __global__ __launch_bounds__(256) void syrk16_kernel(float* __restrict__ H, int6
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int64_t row = i0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                if (row < C && col < C) {
-                    float h = beta * H[row * C + col] + alpha * acc[i][j][e];
-                    H[row * C + col] = h;
-                    if (ti != tj) H[col * C + row] = h;  // mirror (H stays exactly symmetric)
-                }
+                float h = beta * H[row * C + col] + alpha * acc[i][j][e];
+                H[row * C + col] = h;
+                if (ti != tj) H[col * C + row] = h;  // mirror (H stays exactly symmetric)
             }
         }
 }
@@ -209,36 +275,68 @@ size_t h_accumulate_workspace_bytes(int64_t T, int64_t C) {
     return (size_t)C * (size_t)Tp * 2 + 256;
 }
 
-int h_accumulate(float* H, const void* X, int x_dtype, int64_t T, int64_t C, float beta, float alpha, void* ws,
-                 size_t ws_bytes, hipStream_t st) {
-    if (!H || !X) GQ_FAIL(GQ_E_NULL, "gq_h_accumulate: null pointer");
-    if (T <= 0 || C <= 0 || (C % 8)) GQ_FAIL(GQ_E_BAD_SHAPE, "gq_h_accumulate: T=%ld C=%ld (C %% 8 != 0)", (long)T, (long)C);
-    const int64_t nt = (C + HT - 1) / HT;
-    const dim3 grid((unsigned)(nt * (nt + 1) / 2)), block(256);
+int h_accumulate_grouped(int n, float* const* H, const void* const* X, const int64_t* T, const int64_t* C,
+                         const float* beta, const float* alpha, int x_dtype, void* ws, size_t ws_bytes,
+                         hipStream_t st) {
+    if (n <= 0 || n > H_MAX_GROUP) GQ_FAIL(GQ_E_BAD_SHAPE, "gq_h_accumulate_grouped: n=%d not in 1..%d", n, H_MAX_GROUP);
+    if (!H || !X || !T || !C || !beta || !alpha) GQ_FAIL(GQ_E_NULL, "gq_h_accumulate_grouped: null pointer");
+    const dim3 block(256);
     if (x_dtype == GQ_F32) {
-        ProfScope ps(PT_SYRK, st);
-        hipLaunchKernelGGL(syrk32_kernel, grid, block, 0, st, H, C, (const float*)X, T, beta, alpha);
-        GQ_LAUNCH_CHECK();
+        for (int i = 0; i < n; ++i) {
+            if (T[i] <= 0 || C[i] <= 0 || (C[i] % HT)) GQ_FAIL(GQ_E_BAD_SHAPE, "gq_h_accumulate: T=%ld C=%ld (C %% 128 != 0)", (long)T[i], (long)C[i]);
+            const int64_t nt = C[i] / HT;
+            ProfScope ps(PT_SYRK, st);
+            hipLaunchKernelGGL(syrk32_kernel, dim3((unsigned)(nt * (nt + 1) / 2)), block, 0, st, H[i],
+                               C[i], (const float*)X[i], T[i], beta[i], alpha[i]);
+            GQ_LAUNCH_CHECK();
+        }
         return GQ_OK;
     }
     if (x_dtype != GQ_F16 && x_dtype != GQ_BF16) GQ_FAIL(GQ_E_BAD_TYPE, "gq_h_accumulate: unknown x_dtype %d", x_dtype);
-    const size_t need = h_accumulate_workspace_bytes(T, C);
+    size_t need = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!H[i] || !X[i]) GQ_FAIL(GQ_E_NULL, "gq_h_accumulate: null pointer");
+        if (T[i] <= 0 || C[i] <= 0 || (C[i] % HT)) GQ_FAIL(GQ_E_BAD_SHAPE, "gq_h_accumulate: T=%ld C=%ld (C %% 128 != 0)", (long)T[i], (long)C[i]);
+        need += h_accumulate_workspace_bytes(T[i], C[i]);
+    }
     if (!ws || ws_bytes < need) GQ_FAIL(GQ_E_WORKSPACE, "gq_h_accumulate: workspace %zu < %zu bytes", ws_bytes, need);
-    const int64_t Tp = (T + HK - 1) / HK * HK;
-    uint16_t* Xt = reinterpret_cast<uint16_t*>(((uintptr_t)ws + 255) & ~(uintptr_t)255);
-    dim3 tg((unsigned)((Tp + 63) / 64), (unsigned)((C + 63) / 64));
-    {
-        ProfScope ps(PT_TRANSPOSE, st);
-        hipLaunchKernelGGL(transpose16_kernel, tg, block, 0, st, (const uint16_t*)X, T, C, Xt, Tp);
-        GQ_LAUNCH_CHECK();
+    SyrkGroup grp;
+    grp.n = n;
+    int tiles = 0;
+    unsigned char* wp = reinterpret_cast<unsigned char*>(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+    for (int i = 0; i < n; ++i) {
+        const int64_t Tp = (T[i] + HK - 1) / HK * HK;
+        uint16_t* Xt = reinterpret_cast<uint16_t*>(wp);
+        wp += ((size_t)C[i] * Tp * 2 + 255) & ~(size_t)255;
+        {
+            ProfScope ps(PT_TRANSPOSE, st);
+            dim3 tg((unsigned)((Tp + 63) / 64), (unsigned)((C[i] + 63) / 64));
+            hipLaunchKernelGGL(transpose16_kernel, tg, block, 0, st, (const uint16_t*)X[i], T[i], C[i], Xt, Tp);
+            GQ_LAUNCH_CHECK();
+        }
+        const int nt = (int)(C[i] / HT);
+        grp.p[i] = SyrkProblem{H[i], Xt, C[i], Tp, beta[i], alpha[i], tiles, nt};
+        tiles += nt * (nt + 1) / 2;
+    }
+    grp.total_tiles = tiles;
+    static bool attr_set = false;
+    if (!attr_set) {
+        GQ_HIP(hipFuncSetAttribute((const void*)syrk16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * H_STAGE_BYTES));
+        GQ_HIP(hipFuncSetAttribute((const void*)syrk16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * H_STAGE_BYTES));
+        attr_set = true;
     }
     ProfScope ps(PT_SYRK, st);
     if (x_dtype == GQ_BF16)
-        hipLaunchKernelGGL(syrk16_kernel<true>, grid, block, 0, st, H, C, Xt, Tp, beta, alpha);
+        hipLaunchKernelGGL(syrk16_kernel<true>, dim3((unsigned)tiles), block, 2 * H_STAGE_BYTES, st, grp);
     else
-        hipLaunchKernelGGL(syrk16_kernel<false>, grid, block, 0, st, H, C, Xt, Tp, beta, alpha);
+        hipLaunchKernelGGL(syrk16_kernel<false>, dim3((unsigned)tiles), block, 2 * H_STAGE_BYTES, st, grp);
     GQ_LAUNCH_CHECK();
     return GQ_OK;
+}
+
+int h_accumulate(float* H, const void* X, int x_dtype, int64_t T, int64_t C, float beta, float alpha, void* ws,
+                 size_t ws_bytes, hipStream_t st) {
+    return h_accumulate_grouped(1, &H, &X, &T, &C, &beta, &alpha, x_dtype, ws, ws_bytes, st);
 }
 
 }  // namespace gq

@@ -45,6 +45,12 @@ class GPTQ:
         self.shared_H_with = None      # another handle fed by the SAME input tensor (q/k/v, gate/up)
         self._flag = None
         self._ws = None
+        # activations are buffered (288 GB of HBM per GPU) and folded into H in long-K SYRK launches:
+        # b samples at once give beta = n/(n+b), alpha = 2/(n+b), the telescoped form of b single updates
+        self.flush_tokens = 1 << 17
+        self._buf = None
+        self._fill = 0
+        self._buf_b = 0
 
     # ------------------------------------------------------------------ Hessian
     @torch.no_grad()
@@ -64,16 +70,36 @@ class GPTQ:
             x = unfold(input).transpose(1, 2).flatten(0, 1)
         if x.dtype not in (torch.float16, torch.bfloat16, torch.float32):
             x = x.float()
-        beta = self.num_samples / (self.num_samples + batch_size)
-        alpha = 2.0 / (self.num_samples + batch_size)
-        _ops.h_accumulate(self.H, x.contiguous(), beta, alpha)
-        self.num_samples += batch_size
+        t = x.shape[0]
+        if self._buf is not None and (self._buf.dtype != x.dtype or self._fill + t > self._buf.shape[0]):
+            self.flush()
+        if self._buf is None:
+            self._buf = torch.empty((max(self.flush_tokens, t), self.d_col), device=x.device, dtype=x.dtype)
+        self._buf[self._fill:self._fill + t].copy_(x)
+        self._fill += t
+        self._buf_b += batch_size
+        if self._fill >= self.flush_tokens:
+            self.flush()
+
+    @torch.no_grad()
+    def flush(self) -> None:
+        """Fold the buffered activations into H (one gq_h_accumulate over all buffered tokens)."""
+        if self._fill == 0:
+            return
+        n, b = self.num_samples, self._buf_b
+        _ops.h_accumulate(self.H, self._buf[:self._fill], n / (n + b), 2.0 / (n + b))
+        self.num_samples += b
+        self._fill = 0
+        self._buf_b = 0
 
     def reset(self) -> None:
         self.W = self.layer.weight
         self.H = None
         self.num_samples = 0
         self._ws = None
+        self._buf = None
+        self._fill = 0
+        self._buf_b = 0
 
     # ------------------------------------------------------------------- quantize
     @torch.no_grad()
@@ -95,6 +121,8 @@ class GPTQ:
             self._reduced = True
             return
         assert self.H is not None, "One has to process at least one sample of calibration data to run pruning"
+        self.flush()
+        self._buf = None
         if not getattr(self, "_reduced", False):
             dist_utils.allreduce_hessian(self.H)
             self._reduced = True

@@ -68,6 +68,30 @@ def h_accumulate(H: torch.Tensor, X: torch.Tensor, beta: float, alpha: float, ws
     return H
 
 
+def h_accumulate_grouped(Hs, Xs, betas, alphas, ws: Optional[torch.Tensor] = None):
+    """Up to 8 Hessians in one grid: Hs[i] = betas[i]*Hs[i] + alphas[i] * Xs[i]^T Xs[i]."""
+    n = len(Hs)
+    assert n == len(Xs) == len(betas) == len(alphas) and 1 <= n <= 8
+    _need_cuda(*Hs, *Xs)
+    dt = Xs[0].dtype
+    for H, X in zip(Hs, Xs):
+        assert H.dtype == torch.float32 and H.is_contiguous() and X.is_contiguous() and X.dim() == 2
+        assert X.dtype == dt and H.shape == (X.shape[1], X.shape[1])
+    need = sum(workspace_bytes(_cabi.WS_H_ACCUMULATE, 0, X.shape[1], X.shape[0]) for X in Xs)
+    if ws is None or ws.numel() < need:
+        ws = _ws(need, Xs[0].device)
+    vp = ctypes.c_void_p
+    Hp = (vp * n)(*[H.data_ptr() for H in Hs])
+    Xp = (vp * n)(*[X.data_ptr() for X in Xs])
+    Ts = (ctypes.c_int64 * n)(*[X.shape[0] for X in Xs])
+    Cs = (ctypes.c_int64 * n)(*[X.shape[1] for X in Xs])
+    bs = (ctypes.c_float * n)(*[float(b) for b in betas])
+    as_ = (ctypes.c_float * n)(*[float(a) for a in alphas])
+    check(lib().gq_h_accumulate_grouped(n, Hp, Xp, Ts, Cs, bs, as_, _DT[dt], _ptr(ws), ws.numel(), _stream(Xs[0])),
+          "gq_h_accumulate_grouped")
+    return Hs
+
+
 def h_prepare(H: torch.Tensor, W: torch.Tensor, rel_damp: float) -> Tuple[torch.Tensor, torch.Tensor]:
     """In-place dead-channel fix / masking / damping of (H, W); returns (U, not_invertible[int32 tensor])."""
     _need_cuda(H, W)

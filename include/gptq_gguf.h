@@ -86,6 +86,14 @@ size_t gq_workspace_bytes(int op, int64_t R, int64_t C, int64_t T, int block_siz
 int gq_h_accumulate(float* H, const void* X, int x_dtype, int64_t T, int64_t C,
                     float beta, float alpha, void* ws, size_t ws_bytes, void* stream);
 
+/* The same for up to 8 Hessians in ONE grid (the distinct Linear inputs of a transformer
+   block: attn-in, o-in, mlp-in, down-in): H_host[i] <- beta[i]*H[i] + alpha[i]*X[i]^T X[i].
+   The *_host arrays live in host memory and hold device pointers / sizes.  Workspace =
+   sum of gq_workspace_bytes(GQ_WS_H_ACCUMULATE, 0, C[i], T[i], 0). */
+int gq_h_accumulate_grouped(int n, float* const* H_host, const void* const* X_host, const int64_t* T_host,
+                            const int64_t* C_host, const float* beta_host, const float* alpha_host,
+                            int x_dtype, void* ws, size_t ws_bytes, void* stream);
+
 /* replaces gptq.py:134-135,141 (dead channels) + gptq.py:304-324 (_prepare) +
    linalg_utils.py:8-12: zero-column masking, damping, U = chol_upper(inv(H)).
    H and W are mutated exactly as in the reference (damping persists in H).
