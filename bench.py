@@ -94,20 +94,30 @@ def quantize_block(shapes, W16, X, owners, rank, world, q_type=Q4_K, block_size=
     if world > 1:
         for inp in sorted(H):
             dist.all_reduce(H[inp], op=dist.ReduceOp.AVG)  # RCCL over xGMI
-    # ---- per Linear on its owner
+    # ---- per Linear on its owner.  Linears fed by the same input share H, hence U when their
+    # dead/zero-column sets agree (gq_w_prepare checks; the leader's U is then bit-identical).
     out = {}
+    ucache = {}
     for name, (R, C, inp) in shapes.items():
         deq = None
         if owners[name] == rank:
             Wf = W16[name].float()
-            Hc = H[inp].clone()  # each reference handle damps its own H
-            U, flag = ops.h_prepare(Hc, Wf, rel_damp)
+            U = None
+            if inp in ucache:
+                U0, flag0, cf0 = ucache[inp]
+                if int(ops.w_prepare(cf0, Wf).item()) == 0:
+                    U, flag = U0, flag0
+            if U is None:
+                Hc = H[inp].clone()  # each reference handle damps its own H
+                U, flag, cf = ops.h_prepare(Hc, Wf, rel_damp, want_flags=True)
+                ucache[inp] = (U, flag, cf)
+                del Hc
             q, d, s, dmin, m = ops.gptq_quantize(Wf, U, q_type, block_size)
             deq = ops.dequantize(q_type, q, d, s, dmin, m, torch.float16)
             packed = ops.pack(q_type, q, d, s, dmin, m)
             if keep is not None:
                 keep[name] = (q, d, s, dmin, m, packed, flag, U if name == "k_proj" else None)
-            del U, Hc, Wf
+            del U, Wf
         if world > 1:
             if deq is None:
                 deq = torch.empty(R, C, device=dev, dtype=torch.float16)

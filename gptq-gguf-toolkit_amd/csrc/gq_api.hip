@@ -24,7 +24,8 @@ int h_accumulate(float*, const void*, int, int64_t, int64_t, float, float, void*
 int h_accumulate_grouped(int, float* const*, const void* const*, const int64_t*, const int64_t*, const float*, const float*,
                          int, void*, size_t, hipStream_t);
 size_t h_prepare_workspace_bytes(int64_t, int64_t);
-int h_prepare(float*, float*, int64_t, int64_t, float, float*, int*, void*, size_t, hipStream_t);
+int h_prepare(float*, float*, int64_t, int64_t, float, float*, int*, uint8_t*, void*, size_t, hipStream_t);
+int w_prepare(const uint8_t*, float*, int64_t, int64_t, int*, hipStream_t);
 }  // namespace gq
 
 #include <mutex>
@@ -94,9 +95,13 @@ int gq_h_accumulate_grouped(int n, float* const* H_host, const void* const* X_ho
                                 (hipStream_t)stream);
 }
 
-int gq_h_prepare(float* H, float* W, int64_t R, int64_t C, float rel_damp, float* U, int* not_invertible, void* ws,
-                 size_t ws_bytes, void* stream) {
-    return h_prepare(H, W, R, C, rel_damp, U, not_invertible, ws, ws_bytes, (hipStream_t)stream);
+int gq_h_prepare(float* H, float* W, int64_t R, int64_t C, float rel_damp, float* U, int* not_invertible,
+                 uint8_t* col_flags_out, void* ws, size_t ws_bytes, void* stream) {
+    return h_prepare(H, W, R, C, rel_damp, U, not_invertible, col_flags_out, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int gq_w_prepare(const uint8_t* col_flags, float* W, int64_t R, int64_t C, int* mismatch, void* stream) {
+    return w_prepare(col_flags, W, R, C, mismatch, (hipStream_t)stream);
 }
 
 int gq_scale_search(const float* x, int64_t rows, int64_t ld, int q_type, const gq_search_t* p, uint16_t* d,

@@ -50,6 +50,31 @@ __global__ __launch_bounds__(256) void zero_dead_cols_kernel(float* __restrict__
         if (dead[t % C]) W[t] = 0.0f;  // gptq.py:141
 }
 
+// Follower of a shared Hessian: apply the leader's dead-channel set to this W and compare this
+// W's zero-column set with the leader's (equal sets => identical masked/damped H => identical U).
+__global__ __launch_bounds__(256) void w_prepare_kernel(float* __restrict__ W, int64_t R, int64_t C,
+                                                        const uint8_t* __restrict__ dead,
+                                                        const uint8_t* __restrict__ zc, int* __restrict__ mismatch) {
+    const int64_t j = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+    const int ty = threadIdx.x >> 6;
+    __shared__ int nz[4][64];
+    int any = 0;
+    if (j < C) {
+        const bool dd = dead[j];
+        for (int64_t r = ty; r < R; r += 4) {
+            if (dd) W[r * C + j] = 0.0f;  // gptq.py:141
+            else any |= (W[r * C + j] != 0.0f);
+        }
+    }
+    nz[ty][threadIdx.x & 63] = any;
+    __syncthreads();
+    if (ty == 0 && j < C) {
+        int a = nz[0][threadIdx.x] | nz[1][threadIdx.x] | nz[2][threadIdx.x] | nz[3][threadIdx.x];
+        uint8_t mine = dead[j] || !a;
+        if (mine != zc[j]) atomicOr(mismatch, 1);
+    }
+}
+
 // H[zc,:] = 0; H[:,zc] = 0; H[zc,zc] = 1  (gptq.py:311-313; also covers H[dead,dead]=1, :135)
 __global__ __launch_bounds__(256) void mask_h_kernel(float* __restrict__ H, int64_t C, const uint8_t* __restrict__ zc) {
     const int64_t total = C * C;
@@ -97,55 +122,110 @@ __global__ __launch_bounds__(256) void finish_u_kernel(float* __restrict__ U, co
 }
 
 // --------------------------------------------------- diagonal block: potrf + inverse
-// One workgroup (256 threads).  A_kk (lower) -> L_kk in place; Dinv = L_kk^-1 (dense
-// 128x128 with zeros above the diagonal).  A non-positive pivot raises *flag.
+// One workgroup (256 threads), ONE barrier per column.  A_kk (lower) -> L_kk in place;
+// Dinv = L_kk^-1 (dense 128x128, zeros above the diagonal).  Left-looking: in step j
+// thread i (waves 0-1, one row each) forms a_ij - <L_i,0:j , L_j,0:j> with 16-byte LDS
+// reads (its own row: conflict-free at a 132-float stride; the pivot row: broadcast) and
+// recomputes the pivot's own dot product instead of waiting for it.  Waves 2-3 run the
+// forward substitution for L^-1 one row behind the factorisation (thread c owns column c,
+// stored transposed so that its dot products are 16-byte reads too).
+// A non-positive (or NaN) pivot raises *flag (gptq.py:321-323 identity fallback).
+constexpr int LDP = NB + 4;
+
 __global__ __launch_bounds__(256) void diag_potrf_inv_kernel(float* __restrict__ A, int64_t lda,
                                                              float* __restrict__ Dinv, int* __restrict__ flag) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* S = smem;             // [NB][NBP]
-    float* Xs = smem + NB * NBP; // [NB][NBP]
+    float* S = smem;              // [NB][LDP]  L (lower), zeros above
+    float* XT = smem + NB * LDP;  // [NB][LDP]  XT[c][i] = (L^-1)[i][c]
+    float* dg = XT + NB * LDP;    // [NB] original diagonal
     const int tid = threadIdx.x;
     for (int idx = tid; idx < NB * NB; idx += 256) {
         int i = idx / NB, j = idx % NB;
-        S[i * NBP + j] = (j <= i) ? A[i * lda + j] : 0.0f;
-        Xs[i * NBP + j] = 0.0f;
+        float v = (j <= i) ? A[i * lda + j] : 0.0f;
+        S[i * LDP + j] = v;
+        XT[i * LDP + j] = 0.0f;
+        if (i == j) dg[i] = v;
     }
-    const int ti = tid >> 4, tc = tid & 15;
-    for (int j = 0; j < NB; ++j) {
-        __syncthreads();
-        if (tid == 0) {
-            float piv = S[j * NBP + j];
-            if (!(piv > 0.0f)) {  // also catches NaN
-                *flag = 1;
-                piv = 1.0f;
+    __syncthreads();
+    const bool fac = tid < NB;
+    const int i = tid & (NB - 1);
+    for (int j = 0; j <= NB; ++j) {
+        if (fac) {
+            if (j < NB && i >= j) {
+                const float4* ri = reinterpret_cast<const float4*>(S + i * LDP);
+                const float4* rj = reinterpret_cast<const float4*>(S + j * LDP);
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
+                const int n4 = j >> 2;
+                int p4 = 0;
+                for (; p4 + 4 <= n4; p4 += 4) {  // 8 LDS reads in flight, 4 independent chains each
+                    float4 a[4], b[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { a[u] = ri[p4 + u]; b[u] = rj[p4 + u]; }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        a0 = fmaf(a[u].x, b[u].x, a0); a1 = fmaf(a[u].y, b[u].y, a1);
+                        a2 = fmaf(a[u].z, b[u].z, a2); a3 = fmaf(a[u].w, b[u].w, a3);
+                        q0 = fmaf(b[u].x, b[u].x, q0); q1 = fmaf(b[u].y, b[u].y, q1);
+                        q2 = fmaf(b[u].z, b[u].z, q2); q3 = fmaf(b[u].w, b[u].w, q3);
+                    }
+                }
+                for (; p4 < n4; ++p4) {
+                    const float4 a = ri[p4], b = rj[p4];
+                    a0 = fmaf(a.x, b.x, a0); a1 = fmaf(a.y, b.y, a1); a2 = fmaf(a.z, b.z, a2); a3 = fmaf(a.w, b.w, a3);
+                    q0 = fmaf(b.x, b.x, q0); q1 = fmaf(b.y, b.y, q1); q2 = fmaf(b.z, b.z, q2); q3 = fmaf(b.w, b.w, q3);
+                }
+                float acc = (a0 + a1) + (a2 + a3), accp = (q0 + q1) + (q2 + q3);
+                for (int p = p4 * 4; p < j; ++p) {
+                    const float a = S[i * LDP + p], b = S[j * LDP + p];
+                    acc = fmaf(a, b, acc);
+                    accp = fmaf(b, b, accp);
+                }
+                float piv = dg[j] - accp;
+                const bool bad = !(piv > 0.0f);  // also NaN
+                if (bad) piv = 1.0f;
+                const float ljj = sqrtf(piv);
+                if (i == j) {
+                    S[j * LDP + j] = ljj;
+                    if (bad) *flag = 1;
+                } else {
+                    S[i * LDP + j] = (S[i * LDP + j] - acc) / ljj;
+                }
             }
-            S[j * NBP + j] = sqrtf(piv);
+        } else if (j >= 1) {
+            const int r = j - 1, c = i;  // row r of L is final since the previous barrier
+            if (c == r) {
+                XT[c * LDP + r] = 1.0f / S[r * LDP + r];
+            } else if (c < r) {
+                const float4* lr = reinterpret_cast<const float4*>(S + r * LDP);
+                const float4* xc = reinterpret_cast<const float4*>(XT + c * LDP);
+                // XT[c][p] is 0 for p < c and for p >= r, S[r][p] is 0 for p > r: whole 16-byte chunks
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                int p4 = c >> 2;
+                const int e4 = r >> 2;
+                for (; p4 + 3 <= e4; p4 += 4) {
+                    float4 a[4], b[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { a[u] = lr[p4 + u]; b[u] = xc[p4 + u]; }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        a0 = fmaf(a[u].x, b[u].x, a0); a1 = fmaf(a[u].y, b[u].y, a1);
+                        a2 = fmaf(a[u].z, b[u].z, a2); a3 = fmaf(a[u].w, b[u].w, a3);
+                    }
+                }
+                for (; p4 <= e4; ++p4) {
+                    const float4 a = lr[p4], b = xc[p4];
+                    a0 = fmaf(a.x, b.x, a0); a1 = fmaf(a.y, b.y, a1); a2 = fmaf(a.z, b.z, a2); a3 = fmaf(a.w, b.w, a3);
+                }
+                const float acc = (a0 + a1) + (a2 + a3);
+                XT[c * LDP + r] = -acc / S[r * LDP + r];
+            }
         }
         __syncthreads();
-        const float ljj = S[j * NBP + j];
-        for (int i = j + 1 + tid; i < NB; i += 256) S[i * NBP + j] = S[i * NBP + j] / ljj;
-        __syncthreads();
-        for (int i = j + 1 + ti; i < NB; i += 16) {
-            const float lij = S[i * NBP + j];
-            for (int c = j + 1 + tc; c <= i; c += 16) S[i * NBP + c] = fmaf(-lij, S[c * NBP + j], S[i * NBP + c]);
-        }
     }
-    __syncthreads();
-    // inverse by forward substitution, one thread per column
-    if (tid < NB) {
-        const int c = tid;
-        Xs[c * NBP + c] = 1.0f / S[c * NBP + c];
-        for (int i = c + 1; i < NB; ++i) {
-            float acc = 0.0f;
-            for (int p = c; p < i; ++p) acc = fmaf(S[i * NBP + p], Xs[p * NBP + c], acc);
-            Xs[i * NBP + c] = -acc / S[i * NBP + i];
-        }
-    }
-    __syncthreads();
     for (int idx = tid; idx < NB * NB; idx += 256) {
-        int i = idx / NB, j = idx % NB;
-        if (j <= i) A[i * lda + j] = S[i * NBP + j];
-        Dinv[idx] = Xs[i * NBP + j];
+        int r = idx / NB, c = idx % NB;
+        if (c <= r) A[r * lda + c] = S[r * LDP + c];
+        Dinv[idx] = XT[c * LDP + r];
     }
 }
 
@@ -180,8 +260,19 @@ static int trtri_rec(const float* M, float* X, float* Tmp, const float* Dinv, in
     return launch_gemm32<false, 2, false>(X + o21, n, X + o22, n, Tmp + o21, n, m2, m1, m2, st);
 }
 
-int h_prepare(float* H, float* W, int64_t R, int64_t C, float rel_damp, float* U, int* not_invertible, void* ws,
-              size_t ws_bytes, hipStream_t st) {
+int w_prepare(const uint8_t* flags, float* W, int64_t R, int64_t C, int* mismatch, hipStream_t st) {
+    if (!flags || !W || !mismatch) GQ_FAIL(GQ_E_NULL, "gq_w_prepare: null pointer");
+    if (R <= 0 || C <= 0) GQ_FAIL(GQ_E_BAD_SHAPE, "gq_w_prepare: R=%ld C=%ld", (long)R, (long)C);
+    GQ_HIP(hipMemsetAsync(mismatch, 0, sizeof(int), st));
+    ProfScope ps(PT_PREP_ELEM, st);
+    hipLaunchKernelGGL(w_prepare_kernel, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, st, W, R, C, flags, flags + C,
+                       mismatch);
+    GQ_LAUNCH_CHECK();
+    return GQ_OK;
+}
+
+int h_prepare(float* H, float* W, int64_t R, int64_t C, float rel_damp, float* U, int* not_invertible,
+              uint8_t* col_flags_out, void* ws, size_t ws_bytes, hipStream_t st) {
     if (!H || !W || !U || !not_invertible) GQ_FAIL(GQ_E_NULL, "gq_h_prepare: null pointer");
     if (R <= 0 || C <= 0 || C % NB) GQ_FAIL(GQ_E_BAD_SHAPE, "gq_h_prepare: R=%ld C=%ld (C %% 128 != 0)", (long)R, (long)C);
     const size_t need = h_prepare_workspace_bytes(R, C);
@@ -201,6 +292,7 @@ int h_prepare(float* H, float* W, int64_t R, int64_t C, float rel_damp, float* U
     GQ_LAUNCH_CHECK();
     hipLaunchKernelGGL(zero_dead_cols_kernel, dim3(2048), dim3(256), 0, st, W, R, C, dead);
     GQ_LAUNCH_CHECK();
+    if (col_flags_out) GQ_HIP(hipMemcpyAsync(col_flags_out, dead, 2 * (size_t)C, hipMemcpyDeviceToDevice, st));
     hipLaunchKernelGGL(mask_h_kernel, dim3(4096), dim3(256), 0, st, H, C, zc);
     GQ_LAUNCH_CHECK();
     hipLaunchKernelGGL(damp_kernel, dim3(1), dim3(1024), 0, st, H, C, rel_damp);
@@ -211,7 +303,7 @@ int h_prepare(float* H, float* W, int64_t R, int64_t C, float rel_damp, float* U
     }
 
     static bool attr_set = false;
-    const size_t diag_lds = 2 * NB * NBP * sizeof(float);
+    const size_t diag_lds = (2 * NB * LDP + NB) * sizeof(float);
     if (!attr_set) {
         GQ_HIP(hipFuncSetAttribute((const void*)diag_potrf_inv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)diag_lds));

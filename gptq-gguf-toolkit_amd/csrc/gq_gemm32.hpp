@@ -9,7 +9,9 @@
 //   LOWER:   only tiles with tile_row >= tile_col are computed (square, symmetric updates)
 //
 // Workgroup = 256 threads = 4 waves (2x2); tile 128x128; each wave owns 64x64 = 2x2
-// MFMA tiles (64 accumulator VGPRs); K streams through LDS in chunks of 32.
+// MFMA tiles (64 accumulator VGPRs).  K streams in chunks of 32 through a double-buffered
+// LDS image: the global loads of chunk t+1 are issued into registers before the 64 MFMAs
+// of chunk t and written to the other LDS buffer after them (one barrier per chunk).
 #pragma once
 #include "gq_common.hpp"
 
@@ -20,12 +22,69 @@ constexpr int TM = 128, TN = 128, TK = 32;
 constexpr int LDA_S = TK + 1;   // A tile [TM][TK]: lanes walk rows -> odd stride
 constexpr int LDB_S = TN + 4;   // B tile [TK][TN] (NN): lanes walk columns
 constexpr int LDBT_S = TK + 1;  // B tile [TN][TK] (NT)
+constexpr int G32_A_FLOATS = TM * LDA_S;
+constexpr int G32_B_FLOATS = (TK * LDB_S > TN * LDBT_S) ? TK * LDB_S : TN * LDBT_S;
+constexpr int G32_STAGE_FLOATS = G32_A_FLOATS + G32_B_FLOATS;
+constexpr int G32_LDS_BYTES = 2 * G32_STAGE_FLOATS * 4;
+
+// rows x 32-float panel chunk -> 4 float4 per thread (128 rows x 8 float4)
+__device__ __forceinline__ void g32_load_rows(float4 (&v)[4], const float* P, int64_t ld, int64_t r0, int64_t rmax,
+                                              int64_t k0, int64_t K, int tid) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int idx = tid + t * 256, rr = idx >> 3, c4 = (idx & 7) * 4;
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r0 + rr < rmax) {
+            const float* p = P + (r0 + rr) * ld + k0 + c4;
+            if (k0 + c4 + 3 < K) x = *reinterpret_cast<const float4*>(p);
+            else {
+                if (k0 + c4 + 0 < K) x.x = p[0];
+                if (k0 + c4 + 1 < K) x.y = p[1];
+                if (k0 + c4 + 2 < K) x.z = p[2];
+            }
+        }
+        v[t] = x;
+    }
+}
+__device__ __forceinline__ void g32_store_rows(const float4 (&v)[4], float* S, int lds, int tid) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int idx = tid + t * 256, rr = idx >> 3, c4 = (idx & 7) * 4;
+        float* o = S + rr * lds + c4;
+        o[0] = v[t].x; o[1] = v[t].y; o[2] = v[t].z; o[3] = v[t].w;
+    }
+}
+// 32 k-rows x 128 columns chunk of a [K,N] matrix -> 4 float4 per thread (32 rows x 32 float4)
+__device__ __forceinline__ void g32_load_kn(float4 (&v)[4], const float* B, int64_t ldb, int64_t n0, int64_t N,
+                                            int64_t k0, int64_t K, int tid) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int idx = tid + t * 256, kk = idx >> 5, c4 = (idx & 31) * 4;
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k0 + kk < K) {
+            const float* p = B + (k0 + kk) * ldb + n0 + c4;
+            if (n0 + c4 + 3 < N) x = *reinterpret_cast<const float4*>(p);
+            else {
+                if (n0 + c4 + 0 < N) x.x = p[0];
+                if (n0 + c4 + 1 < N) x.y = p[1];
+                if (n0 + c4 + 2 < N) x.z = p[2];
+            }
+        }
+        v[t] = x;
+    }
+}
+__device__ __forceinline__ void g32_store_kn(const float4 (&v)[4], float* S, int tid) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int idx = tid + t * 256, kk = idx >> 5, c4 = (idx & 31) * 4;
+        *reinterpret_cast<float4*>(S + kk * LDB_S + c4) = v[t];
+    }
+}
 
 template <bool TRANS_B, int MODE, bool LOWER>
-__global__ __launch_bounds__(256) void gemm32_kernel(float* Cmat, int64_t ldc, const float* A, int64_t lda,
-                                                     const float* B, int64_t ldb, int64_t M, int64_t N, int64_t K) {
-    __shared__ float As[TM * LDA_S];
-    __shared__ float Bs[TRANS_B ? TN * LDBT_S : TK * LDB_S];
+__global__ __launch_bounds__(256, 2) void gemm32_kernel(float* Cmat, int64_t ldc, const float* A, int64_t lda,
+                                                        const float* B, int64_t ldb, int64_t M, int64_t N, int64_t K) {
+    extern __shared__ __attribute__((aligned(16))) float g32_smem[];
     if (LOWER && blockIdx.x > blockIdx.y) return;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
@@ -38,63 +97,28 @@ __global__ __launch_bounds__(256) void gemm32_kernel(float* Cmat, int64_t ldc, c
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-    for (int64_t k0 = 0; k0 < K; k0 += TK) {
-        // A[m0:m0+128, k0:k0+32]: 128 rows x 8 float4
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            int idx = tid + t * 256;
-            int rr = idx >> 3, c4 = (idx & 7) * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m0 + rr < M) {
-                const float* p = A + (m0 + rr) * lda + k0 + c4;
-                if (k0 + c4 + 3 < K) v = *reinterpret_cast<const float4*>(p);
-                else {
-                    if (k0 + c4 + 0 < K) v.x = p[0];
-                    if (k0 + c4 + 1 < K) v.y = p[1];
-                    if (k0 + c4 + 2 < K) v.z = p[2];
-                }
-            }
-            float* o = As + rr * LDA_S + c4;
-            o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
-        }
-        if constexpr (TRANS_B) {  // B[n0:n0+128, k0:k0+32]
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                int idx = tid + t * 256;
-                int rr = idx >> 3, c4 = (idx & 7) * 4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (n0 + rr < N) {
-                    const float* p = B + (n0 + rr) * ldb + k0 + c4;
-                    if (k0 + c4 + 3 < K) v = *reinterpret_cast<const float4*>(p);
-                    else {
-                        if (k0 + c4 + 0 < K) v.x = p[0];
-                        if (k0 + c4 + 1 < K) v.y = p[1];
-                        if (k0 + c4 + 2 < K) v.z = p[2];
-                    }
-                }
-                float* o = Bs + rr * LDBT_S + c4;
-                o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
-            }
-        } else {  // B[k0:k0+32, n0:n0+128]: 32 rows x 32 float4
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                int idx = tid + t * 256;
-                int kk = idx >> 5, c4 = (idx & 31) * 4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (k0 + kk < K) {
-                    const float* p = B + (k0 + kk) * ldb + n0 + c4;
-                    if (n0 + c4 + 3 < N) v = *reinterpret_cast<const float4*>(p);
-                    else {
-                        if (n0 + c4 + 0 < N) v.x = p[0];
-                        if (n0 + c4 + 1 < N) v.y = p[1];
-                        if (n0 + c4 + 2 < N) v.z = p[2];
-                    }
-                }
-                *reinterpret_cast<float4*>(Bs + kk * LDB_S + c4) = v;
-            }
-        }
-        __syncthreads();
-        const int li = lane & 31, lk = lane >> 5;
+    float4 va[4], vb[4];
+    auto fetch = [&](int64_t k0) {
+        g32_load_rows(va, A, lda, m0, M, k0, K, tid);
+        if constexpr (TRANS_B) g32_load_rows(vb, B, ldb, n0, N, k0, K, tid);
+        else g32_load_kn(vb, B, ldb, n0, N, k0, K, tid);
+    };
+    auto commit = [&](int buf) {
+        float* As = g32_smem + buf * G32_STAGE_FLOATS;
+        float* Bs = As + G32_A_FLOATS;
+        g32_store_rows(va, As, LDA_S, tid);
+        if constexpr (TRANS_B) g32_store_rows(vb, Bs, LDBT_S, tid);
+        else g32_store_kn(vb, Bs, tid);
+    };
+    const int li = lane & 31, lk = lane >> 5;
+    const int64_t nk = (K + TK - 1) / TK;
+    fetch(0);
+    commit(0);
+    __syncthreads();
+    for (int64_t t = 0; t < nk; ++t) {
+        if (t + 1 < nk) fetch((t + 1) * TK);  // in flight during the MFMA block
+        const float* As = g32_smem + (t & 1) * G32_STAGE_FLOATS;
+        const float* Bs = As + G32_A_FLOATS;
 #pragma unroll 4
         for (int kk = 0; kk < TK; kk += 2) {
             float av[2], bv[2];
@@ -111,6 +135,7 @@ __global__ __launch_bounds__(256) void gemm32_kernel(float* Cmat, int64_t ldc, c
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
+        if (t + 1 < nk) commit((int)((t + 1) & 1));  // the other buffer: its readers passed the last barrier
         __syncthreads();
     }
     // D layout: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
@@ -139,8 +164,15 @@ inline int launch_gemm32(float* Cmat, int64_t ldc, const float* A, int64_t lda, 
     if (M <= 0 || N <= 0 || K <= 0) return GQ_OK;
     if ((lda % 4) || (ldb % 4) || ((uintptr_t)A % 16) || ((uintptr_t)B % 16))
         GQ_FAIL(GQ_E_BAD_SHAPE, "gemm32: A/B must be 16-byte aligned with ld %% 4 == 0");
+    static bool attr_set = false;
+    if (!attr_set) {
+        GQ_HIP(hipFuncSetAttribute((const void*)gemm32_kernel<TRANS_B, MODE, LOWER>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, G32_LDS_BYTES));
+        attr_set = true;
+    }
     dim3 grid((unsigned)((N + TN - 1) / TN), (unsigned)((M + TM - 1) / TM)), block(256);
-    hipLaunchKernelGGL((gemm32_kernel<TRANS_B, MODE, LOWER>), grid, block, 0, st, Cmat, ldc, A, lda, B, ldb, M, N, K);
+    hipLaunchKernelGGL((gemm32_kernel<TRANS_B, MODE, LOWER>), grid, block, G32_LDS_BYTES, st, Cmat, ldc, A, lda, B, ldb,
+                       M, N, K);
     GQ_LAUNCH_CHECK();
     return GQ_OK;
 }

@@ -27,6 +27,7 @@ int launch_scale_search(const float* x, int64_t rows, int64_t ld, int q_type, co
 //   qparams d/dmin [R, C/256], s/m [R, C/G] already hold the super-group of `a`
 constexpr int SEG = 128;
 constexpr int SB = 16;  // register sub-block
+constexpr int SEG_LDS_BYTES = (SEG * 64 + SEG * SEG) * 4;
 
 __global__ __launch_bounds__(64) void gptq_segment_kernel(
     float* W, int64_t C, const float* src, int64_t ld_src,  // may alias (single-segment blocks)
@@ -34,8 +35,17 @@ __global__ __launch_bounds__(64) void gptq_segment_kernel(
     const uint16_t* __restrict__ d, const uint8_t* __restrict__ s, const uint16_t* __restrict__ dmin,
     const uint8_t* __restrict__ m, int G, int is_signed, float qmin, float qmax,
     uint8_t* __restrict__ qweight, float* __restrict__ Err, int64_t ld_err, int64_t err_col0) {
-    __shared__ float wl[SEG * 64];  // wl[j*64 + lane]: working copy, column-major per wave
+    extern __shared__ __attribute__((aligned(16))) float seg_smem[];
+    float* wl = seg_smem;             // wl[j*64 + lane]: working copy, column-major per wave (32 KiB)
+    float* Us = seg_smem + SEG * 64;  // Us[i*SEG + j] = U[a+i, a+j]: the segment's diagonal block (64 KiB),
+                                      // read back with wave-uniform (broadcast) 16-byte LDS loads
     const int lane = threadIdx.x;
+    for (int idx = lane; idx < len * (SEG / 4); idx += 64) {
+        const int i = idx / (SEG / 4), j4 = (idx % (SEG / 4)) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (j4 < len) v = *reinterpret_cast<const float4*>(U + (a + i) * C + a + j4);
+        *reinterpret_cast<float4*>(Us + i * SEG + j4) = v;
+    }
     const int64_t row = (int64_t)blockIdx.x * 64 + lane;
     const bool live = row < R;
     const int64_t r = live ? row : 0;
@@ -52,6 +62,7 @@ __global__ __launch_bounds__(64) void gptq_segment_kernel(
         }
     }
     const int64_t nsg = C / 256, ng = C / G;
+    __syncthreads();
 
     for (int i0 = 0; i0 < len; i0 += SB) {
         const int64_t col0 = a + i0;
@@ -64,7 +75,7 @@ __global__ __launch_bounds__(64) void gptq_segment_kernel(
         for (int k = 0; k < SB; ++k) wr[k] = wl[(i0 + k) * 64 + lane];
 #pragma unroll
         for (int k = 0; k < SB; ++k) {
-            const float* urow = U + (col0 + k) * C + col0;  // wave-uniform -> scalar loads
+            const float* urow = Us + (i0 + k) * SEG + i0;  // wave-uniform LDS address (broadcast)
             const float dii = urow[k];
             const float q = quantize1(wr[k], ds, dm, qmin, qmax);  // gptq.py:247-254
             wq[k] = dequantize1(q, ds, dm);                        // :255-261
@@ -96,7 +107,7 @@ __global__ __launch_bounds__(64) void gptq_segment_kernel(
             for (int jj = 0; jj < SB; ++jj) wt[jj] = wl[(j0 + jj) * 64 + lane];
 #pragma unroll
             for (int k = 0; k < SB; ++k) {
-                const float* urow = U + (col0 + k) * C + a + j0;
+                const float* urow = Us + (i0 + k) * SEG + j0;
 #pragma unroll
                 for (int jj = 0; jj < SB; ++jj) wt[jj] = wt[jj] + nerr[k] * urow[jj];
             }
@@ -177,6 +188,12 @@ int gptq_quantize(float* W, const float* U, int64_t R, int64_t C, int q_type, in
                 return rc;
     }
     const dim3 seg_grid((unsigned)((R + 63) / 64)), seg_block(64);
+    static bool seg_attr = false;
+    if (!seg_attr) {
+        GQ_HIP(hipFuncSetAttribute((const void*)gptq_segment_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   SEG_LDS_BYTES));
+        seg_attr = true;
+    }
     for (int64_t c1 = 0; c1 < C; c1 += B) {  // gptq.py:222
         const int64_t c2 = c1 + B < C ? c1 + B : C;
         // one segment iff the block fits in LDS and stays inside one 256-column super-group
@@ -207,7 +224,7 @@ int gptq_quantize(float* W, const float* U, int64_t R, int64_t C, int q_type, in
             const int64_t ld_src = single ? C : B;
             {
                 ProfScope ps(PT_GPTQ_SEGMENT, st);
-                hipLaunchKernelGGL(gptq_segment_kernel, seg_grid, seg_block, 0, st, W, C, srcp, ld_src, U, a, len, R, d,
+                hipLaunchKernelGGL(gptq_segment_kernel, seg_grid, seg_block, SEG_LDS_BYTES, st, W, C, srcp, ld_src, U, a, len, R, d,
                                    s, dmin, m, ti.group, ti.is_signed, (float)ti.qmin, (float)ti.qmax, qweight, Err, B,
                                    a - c1);
                 GQ_LAUNCH_CHECK();

@@ -96,19 +96,21 @@ __global__ __launch_bounds__(256, 2) void syrk16_kernel(const SyrkGroup grp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 stages x (A 16 KiB | B 16 KiB)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
-    // XCD-aware bijective remap: block b runs on XCD b % 8; give each XCD a contiguous run of
-    // logical tiles (same tile row => the A panel stays in that XCD's L2)
-    int logical;
-    {
-        const int n = grp.total_tiles, q = n >> 3, r = n & 7, xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
-        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-    }
+    // Tile order.  A 128x128 tile streams two 128-row panels of Xt; at 2 workgroups per CU the
+    // 64 workgroups resident on one XCD (block b runs on XCD b % 8) are mapped to ONE 8x8
+    // super-tile of the upper triangle, so together they stream 16 panels instead of 65 and the
+    // XCD's L2 serves the other 3/4 of the operand traffic (HBM-bound -> MFMA/L2-bound).
+    const int xcd = blockIdx.x & 7, kx = blockIdx.x >> 3;
+    const int g = (kx >> 6) * 8 + xcd, slot = kx & 63;
+    if (g >= grp.total_tiles) return;  // total_tiles counts SUPER-tiles here
     int pi = 0;
     for (int i = 1; i < grp.n; ++i)
-        if (logical >= grp.p[i].tile_begin) pi = i;
+        if (g >= grp.p[i].tile_begin) pi = i;
     const SyrkProblem& P = grp.p[pi];
-    int64_t ti, tj;
-    tri_tile(logical - P.tile_begin, P.nt, ti, tj);
+    int64_t sI, sJ;
+    tri_tile(g - P.tile_begin, (P.nt + 7) >> 3, sI, sJ);
+    const int64_t ti = sI * 8 + (slot >> 3), tj = sJ * 8 + (slot & 7);
+    if (ti >= P.nt || tj >= P.nt || ti > tj) return;
     const int64_t i0 = ti * HT, j0 = tj * HT, Tp = P.Tp, C = P.C;
     const uint16_t* __restrict__ Xt = P.Xt;
 
@@ -316,7 +318,8 @@ int h_accumulate_grouped(int n, float* const* H, const void* const* X, const int
         }
         const int nt = (int)(C[i] / HT);
         grp.p[i] = SyrkProblem{H[i], Xt, C[i], Tp, beta[i], alpha[i], tiles, nt};
-        tiles += nt * (nt + 1) / 2;
+        const int ns = (nt + 7) / 8;  // 8x8 super-tiles per dimension
+        tiles += ns * (ns + 1) / 2;
     }
     grp.total_tiles = tiles;
     static bool attr_set = false;
@@ -327,9 +330,9 @@ int h_accumulate_grouped(int n, float* const* H, const void* const* X, const int
     }
     ProfScope ps(PT_SYRK, st);
     if (x_dtype == GQ_BF16)
-        hipLaunchKernelGGL(syrk16_kernel<true>, dim3((unsigned)tiles), block, 2 * H_STAGE_BYTES, st, grp);
+        hipLaunchKernelGGL(syrk16_kernel<true>, dim3((unsigned)((tiles + 7) / 8 * 8 * 64)), block, 2 * H_STAGE_BYTES, st, grp);
     else
-        hipLaunchKernelGGL(syrk16_kernel<false>, dim3((unsigned)tiles), block, 2 * H_STAGE_BYTES, st, grp);
+        hipLaunchKernelGGL(syrk16_kernel<false>, dim3((unsigned)((tiles + 7) / 8 * 8 * 64)), block, 2 * H_STAGE_BYTES, st, grp);
     GQ_LAUNCH_CHECK();
     return GQ_OK;
 }

@@ -51,6 +51,7 @@ class GPTQ:
         self._buf = None
         self._fill = 0
         self._buf_b = 0
+        self._U_cache = None
 
     # ------------------------------------------------------------------ Hessian
     @torch.no_grad()
@@ -137,11 +138,19 @@ class GPTQ:
     @torch.no_grad()
     def _prepare(self) -> Tensor:
         """-> U = chol_upper(H^-1); mutates H (damping) and W (dead columns) like the reference (:304-324).
-        Handles that share one accumulated H each damp their own copy, as the reference's
-        independent (identical) Hessians would."""
-        shared = self.shared_H_with is not None or getattr(self, "_has_followers", False)
-        H = self.H.clone() if shared else self.H
-        U, self._flag = _ops.h_prepare(H, self.W, self.rel_damp)
+        Handles fed by the same input tensor hold the same H; U depends on (H, dead set, zero-column set
+        of W) only, so a follower whose sets equal its leader's reuses the leader's U bit-for-bit."""
+        leader = self.shared_H_with
+        if leader is not None and getattr(leader, "_U_cache", None) is not None:
+            U, flag, cf = leader._U_cache
+            if int(_ops.w_prepare(cf, self.W).item()) == 0:
+                self._flag = flag
+                return U
+        shared = leader is not None or getattr(self, "_has_followers", False)
+        H = self.H.clone() if shared else self.H  # every reference handle damps its own copy
+        U, self._flag, cf = _ops.h_prepare(H, self.W, self.rel_damp, want_flags=True)
+        if getattr(self, "_has_followers", False):
+            self._U_cache = (U, self._flag, cf)
         if not shared:
             self.H = H
         return U

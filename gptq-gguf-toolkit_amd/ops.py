@@ -92,17 +92,29 @@ def h_accumulate_grouped(Hs, Xs, betas, alphas, ws: Optional[torch.Tensor] = Non
     return Hs
 
 
-def h_prepare(H: torch.Tensor, W: torch.Tensor, rel_damp: float) -> Tuple[torch.Tensor, torch.Tensor]:
-    """In-place dead-channel fix / masking / damping of (H, W); returns (U, not_invertible[int32 tensor])."""
+def h_prepare(H: torch.Tensor, W: torch.Tensor, rel_damp: float, want_flags: bool = False):
+    """In-place dead-channel fix / masking / damping of (H, W); returns (U, not_invertible[int32 tensor])
+    (+ col_flags uint8[2*C] if want_flags: the dead / zero-column sets U depends on)."""
     _need_cuda(H, W)
     assert H.dtype == torch.float32 and W.dtype == torch.float32 and H.is_contiguous() and W.is_contiguous()
     R, C = W.shape
     U = torch.empty_like(H)
     flag = torch.zeros(1, dtype=torch.int32, device=H.device)
+    cf = torch.empty(2 * C, dtype=torch.uint8, device=H.device) if want_flags else None
     ws = _ws(workspace_bytes(_cabi.WS_H_PREPARE, R, C), H.device)
-    check(lib().gq_h_prepare(_ptr(H), _ptr(W), R, C, rel_damp, _ptr(U), _ptr(flag), _ptr(ws), ws.numel(), _stream(H)),
-          "gq_h_prepare")
-    return U, flag
+    check(lib().gq_h_prepare(_ptr(H), _ptr(W), R, C, rel_damp, _ptr(U), _ptr(flag), _ptr(cf), _ptr(ws), ws.numel(),
+                             _stream(H)), "gq_h_prepare")
+    return (U, flag, cf) if want_flags else (U, flag)
+
+
+def w_prepare(col_flags: torch.Tensor, W: torch.Tensor) -> torch.Tensor:
+    """Follower of a shared Hessian: zero this W's dead columns; returns mismatch[int32 tensor]
+    (0 => the leader's U is this Linear's U)."""
+    _need_cuda(col_flags, W)
+    assert W.dtype == torch.float32 and W.is_contiguous() and col_flags.numel() == 2 * W.shape[1]
+    mm = torch.zeros(1, dtype=torch.int32, device=W.device)
+    check(lib().gq_w_prepare(_ptr(col_flags), _ptr(W), W.shape[0], W.shape[1], _ptr(mm), _stream(W)), "gq_w_prepare")
+    return mm
 
 
 def scale_search(x: torch.Tensor, q_type: int, rmin=-1.0, rdelta=0.1, nstep=20):

@@ -98,9 +98,17 @@ int gq_h_accumulate_grouped(int n, float* const* H_host, const void* const* X_ho
    linalg_utils.py:8-12: zero-column masking, damping, U = chol_upper(inv(H)).
    H and W are mutated exactly as in the reference (damping persists in H).
    *not_invertible (device int) is set to 1 and U to the identity when H is not
-   positive definite (gptq.py:321-323), else 0. */
+   positive definite (gptq.py:321-323), else 0.
+   col_flags_out (device, 2*C bytes, may be NULL) receives dead[C] (H_jj == 0 on entry)
+   followed by zc[C] (dead or all-zero weight column): the two sets U depends on. */
 int gq_h_prepare(float* H, float* W, int64_t R, int64_t C, float rel_damp, float* U,
-                 int* not_invertible, void* ws, size_t ws_bytes, void* stream);
+                 int* not_invertible, uint8_t* col_flags_out, void* ws, size_t ws_bytes, void* stream);
+
+/* For a Linear whose Hessian is the SAME as one already prepared (q/k/v, gate/up share
+   their input): applies the dead-channel set to this W (gptq.py:141) and sets *mismatch
+   (device int) to 1 iff this W's zero-column set differs from col_flags' -- if 0, the
+   leader's U is exactly the U the reference would compute for this Linear. */
+int gq_w_prepare(const uint8_t* col_flags, float* W, int64_t R, int64_t C, int* mismatch, void* stream);
 
 /* replaces quant_utils.py:90-145 (Quantizer.get_scale_and_zero) incl.
    make_k_quants :199-274 / make_quants :147-197, on one [rows,256] panel with row
