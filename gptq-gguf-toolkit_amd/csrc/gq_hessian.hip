@@ -47,7 +47,9 @@ __global__ __launch_bounds__(256) void transpose16_kernel(const uint16_t* __rest
 // v_mfma_f32_32x32x16_{f16,bf16}.  K streams in stages of 64 elements (128 B per row)
 // through a double-buffered 64 KiB LDS image filled with global_load_lds_dwordx4
 // (16 B per lane, no VGPR round trip).  The LDS image is row-major [128][128 B] with the
-// eight 16-B chunks of a row XOR-swizzled by (row & 7): global_load_lds writes lane-linear,
+// eight 16-B chunks of a row XOR-swizzled by ((row >> 1) & 7) -- row parity already picks the
+// half of the 256-B bank row, so the 16 rows of a ds_read_b128 lane group land on 16 distinct
+// 16-B slots (conflict-free; (row & 7) measured 2-way).  global_load_lds writes lane-linear,
 // so the swizzle is applied to the per-lane SOURCE address (8 consecutive lanes still
 // fetch one full 128-B line) and again on the ds_read_b128 fragment address.
 constexpr int HT = 128;  // output tile
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void syrk16_kernel(const SyrkGroup grp) {
     const uint16_t* srcB[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        const int p = t * 256 + tid, row = p >> 3, kc = (p & 7) ^ (row & 7);
+        const int p = t * 256 + tid, row = p >> 3, kc = (p & 7) ^ ((row >> 1) & 7);
         srcA[t] = Xt + (i0 + row) * Tp + kc * 8;
         srcB[t] = Xt + (j0 + row) * Tp + kc * 8;
     }
@@ -148,8 +150,8 @@ __global__ __launch_bounds__(256, 2) void syrk16_kernel(const SyrkGroup grp) {
         const int ra = wm * 64 + i * 32 + li, rb = wn * 64 + i * 32 + li;
         offA[i] = ra * 128;
         offB[i] = HT * HK * 2 + rb * 128;
-        swz[0][i] = ra & 7;
-        swz[1][i] = rb & 7;
+        swz[0][i] = (ra >> 1) & 7;
+        swz[1][i] = (rb >> 1) & 7;
     }
     const int64_t nk = Tp / HK;
     stage(0, 0);
