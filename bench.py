@@ -76,7 +76,7 @@ def make_weights(shapes, dev, seed=0):
 
 
 def quantize_block(shapes, W16, X, owners, rank, world, q_type=Q4_K, block_size=128, rel_damp=0.01, keep=None,
-                   hbatch=None, hws=None):
+                   hbatch=None, hws=None, streams=None):
     dev = next(iter(W16.values())).device
     # ---- Hessians: one per distinct input.  The activations of `hbatch` sequences are folded in
     # per launch (beta = n/(n+b), alpha = 2/(n+b): the telescoped form of b single-sample updates of
@@ -96,33 +96,58 @@ def quantize_block(shapes, W16, X, owners, rank, world, q_type=Q4_K, block_size=
             dist.all_reduce(H[inp], op=dist.ReduceOp.AVG)  # RCCL over xGMI
     # ---- per Linear on its owner.  Linears fed by the same input share H, hence U when their
     # dead/zero-column sets agree (gq_w_prepare checks; the leader's U is then bit-identical).
-    out = {}
-    ucache = {}
+    # The input groups are independent chains (prepare -> column loop), so each runs on its own HIP
+    # stream: the single-workgroup diagonal factorisations and the 64-wave column-loop kernels of one
+    # chain overlap with the GEMMs of the others.
+    out, pending = {}, []
+    main = torch.cuda.current_stream(dev)
+    ev_h = torch.cuda.Event()
+    ev_h.record(main)
+    groups = {}
     for name, (R, C, inp) in shapes.items():
-        deq = None
         if owners[name] == rank:
+            groups.setdefault(inp, []).append(name)
+    order = sorted(groups, key=lambda g: -sum(shapes[n][0] * shapes[n][1] * shapes[n][1] for n in groups[g]))
+    for gi, inp in enumerate(order):
+        st = streams[gi % len(streams)] if streams else main
+        st.wait_event(ev_h)
+        with torch.cuda.stream(st):
+            U = flag = cf = None
+            for name in groups[inp]:
+                R, C, _ = shapes[name]
+                Wf = W16[name].float()
+                mm = None
+                if U is None:
+                    Hc = H[inp].clone()  # each reference handle damps its own H
+                    U, flag, cf = ops.h_prepare(Hc, Wf, rel_damp, want_flags=True)
+                    del Hc
+                else:
+                    mm = ops.w_prepare(cf, Wf)  # speculative reuse of the leader's U, verified below
+                q, d, s, dmin, m = ops.gptq_quantize(Wf, U, q_type, block_size)
+                deq = ops.dequantize(q_type, q, d, s, dmin, m, torch.float16)
+                packed = ops.pack(q_type, q, d, s, dmin, m)
+                out[name] = deq
+                pending.append((name, inp, mm))
+                if keep is not None:
+                    keep[name] = (q, d, s, dmin, m, packed, flag, U if name == "k_proj" else None)
+                del Wf
+            del U
+        ev = torch.cuda.Event()
+        ev.record(st)
+        main.wait_event(ev)
+    for name, inp, mm in pending:  # a follower whose zero-column set differs gets its own factorisation
+        if mm is not None and int(mm.item()) != 0:
+            R, C, _ = shapes[name]
             Wf = W16[name].float()
-            U = None
-            if inp in ucache:
-                U0, flag0, cf0 = ucache[inp]
-                if int(ops.w_prepare(cf0, Wf).item()) == 0:
-                    U, flag = U0, flag0
-            if U is None:
-                Hc = H[inp].clone()  # each reference handle damps its own H
-                U, flag, cf = ops.h_prepare(Hc, Wf, rel_damp, want_flags=True)
-                ucache[inp] = (U, flag, cf)
-                del Hc
+            U, flag = ops.h_prepare(H[inp].clone(), Wf, rel_damp)
             q, d, s, dmin, m = ops.gptq_quantize(Wf, U, q_type, block_size)
-            deq = ops.dequantize(q_type, q, d, s, dmin, m, torch.float16)
-            packed = ops.pack(q_type, q, d, s, dmin, m)
-            if keep is not None:
-                keep[name] = (q, d, s, dmin, m, packed, flag, U if name == "k_proj" else None)
-            del U, Wf
-        if world > 1:
-            if deq is None:
-                deq = torch.empty(R, C, device=dev, dtype=torch.float16)
-            dist.broadcast(deq, src=owners[name])
-        out[name] = deq
+            out[name] = ops.dequantize(q_type, q, d, s, dmin, m, torch.float16)
+            ops.pack(q_type, q, d, s, dmin, m)
+    if world > 1:
+        for name, (R, C, inp) in shapes.items():
+            if name not in out:
+                out[name] = torch.empty(R, C, device=dev, dtype=torch.float16)
+            dist.broadcast(out[name], src=owners[name])
     return out
 
 
@@ -156,6 +181,7 @@ def main():
     ap.add_argument("--seq-len", type=int, default=None)
     ap.add_argument("--hessian-batch", type=int, default=None,
                     help="sequences folded into H per SYRK launch (default: all local sequences; 1 = reference cadence)")
+    ap.add_argument("--streams", type=int, default=4, help="HIP streams for the independent per-input chains (0: one)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="one extra profiled step: per-kernel ms to stderr")
     args = ap.parse_args()
@@ -185,6 +211,7 @@ def main():
     hb = args.hessian_batch or nseq_local
     hws = torch.empty(sum(ops.workspace_bytes(_cabi.WS_H_ACCUMULATE, 0, x.shape[-1], hb * L) for x in X.values()),
                       dtype=torch.uint8, device=dev)
+    streams = [torch.cuda.Stream(dev) for _ in range(args.streams)] if args.streams > 0 else None
     torch.cuda.synchronize()
 
     def sync():
@@ -193,7 +220,7 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        quantize_block(shapes, W16, X, owners, rank, world, hbatch=hb, hws=hws)
+        quantize_block(shapes, W16, X, owners, rank, world, hbatch=hb, hws=hws, streams=streams)
     sync()
     # dominant kernel (the fp16 MFMA SYRK of the Hessian accumulation) timed live with HIP
     # events on its launch stream, inside the timed region
@@ -202,7 +229,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         quantize_block(shapes, W16, X, owners, rank, world, keep=keep if i == args.steps - 1 else None, hbatch=hb,
-                       hws=hws)
+                       hws=hws, streams=streams)
     sync()
     dt = time.perf_counter() - t0
     prof = _cabi.prof_collect()
@@ -214,7 +241,7 @@ def main():
 
     if args.breakdown and rank == 0:
         _cabi.prof_enable(None)
-        quantize_block(shapes, W16, X, owners, rank, world, hbatch=hb, hws=hws)
+        quantize_block(shapes, W16, X, owners, rank, world, hbatch=hb, hws=hws, streams=streams)
         torch.cuda.synchronize()
         bd = _cabi.prof_collect()
         _cabi.prof_enable([])

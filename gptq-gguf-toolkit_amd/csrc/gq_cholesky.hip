@@ -133,7 +133,8 @@ __global__ __launch_bounds__(256) void finish_u_kernel(float* __restrict__ U, co
 constexpr int LDP = NB + 4;
 
 __global__ __launch_bounds__(256) void diag_potrf_inv_kernel(float* __restrict__ A, int64_t lda,
-                                                             float* __restrict__ Dinv, int* __restrict__ flag) {
+                                                             float* __restrict__ Xout, int64_t ldx,
+                                                             int* __restrict__ flag) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* S = smem;              // [NB][LDP]  L (lower), zeros above
     float* XT = smem + NB * LDP;  // [NB][LDP]  XT[c][i] = (L^-1)[i][c]
@@ -225,39 +226,47 @@ __global__ __launch_bounds__(256) void diag_potrf_inv_kernel(float* __restrict__
     for (int idx = tid; idx < NB * NB; idx += 256) {
         int r = idx / NB, c = idx % NB;
         if (c <= r) A[r * lda + c] = S[r * LDP + c];
-        Dinv[idx] = XT[c * LDP + r];
+        Xout[r * ldx + c] = XT[c * LDP + r];
     }
-}
-
-__global__ __launch_bounds__(256) void copy_block_kernel(float* __restrict__ dst, int64_t ldd,
-                                                         const float* __restrict__ src) {
-    for (int idx = threadIdx.x; idx < NB * NB; idx += 256) dst[(idx / NB) * ldd + (idx % NB)] = src[idx];
 }
 
 size_t h_prepare_workspace_bytes(int64_t R, int64_t C) {
     (void)R;
     const size_t n2 = (size_t)C * (size_t)C * sizeof(float);
-    return 2 * n2 + (size_t)C * NB * sizeof(float) + 2 * (size_t)C + 1024;
+    return 2 * n2 + 2 * (size_t)C + 1024;
 }
 
-// X[lo:hi, lo:hi] = inverse of the lower-triangular M[lo:hi, lo:hi] (block indices)
-static int trtri_rec(const float* M, float* X, float* Tmp, const float* Dinv, int64_t n, int64_t lo, int64_t hi,
-                     hipStream_t st) {
+// Recursive blocked Cholesky WITH inverse, all level-3 work on the fp32 matrix cores:
+//   [A11 .  ]      L11 = chol(A11), X11 = L11^-1                     (recursion)
+//   [A21 A22]      L21 = A21 X11^T                                   (GEMM, X11 triangular: k-range skip)
+//                  A22 -= L21 L21^T                                  (SYRK, lower tiles only)
+//                  L22 = chol(A22), X22 = L22^-1                     (recursion)
+//                  X21 = -X22 (L21 X11)                              (two GEMMs, triangular k-range skips)
+// L21 lives in Tmp (the factor itself is not an output: only X = L^-1 is), the product L21 X11
+// reuses the dead A21 block.  Leaves are 128x128 (diag_potrf_inv_kernel, writes X_kk directly).
+static int chol_inv_rec(float* A, float* X, float* Tmp, int* flag, int64_t n, int64_t lo, int64_t hi, size_t diag_lds,
+                        hipStream_t st) {
     if (hi - lo == 1) {
-        hipLaunchKernelGGL(copy_block_kernel, dim3(1), dim3(256), 0, st, X + (lo * NB) * n + lo * NB, n,
-                           Dinv + lo * NB * NB);
+        ProfScope ps(PT_DIAG_POTRF, st);
+        const int64_t o = (lo * NB) * n + lo * NB;
+        hipLaunchKernelGGL(diag_potrf_inv_kernel, dim3(1), dim3(256), diag_lds, st, A + o, n, X + o, n, flag);
         GQ_LAUNCH_CHECK();
         return GQ_OK;
     }
     const int64_t mid = (lo + hi) / 2;
     int rc;
-    if ((rc = trtri_rec(M, X, Tmp, Dinv, n, lo, mid, st))) return rc;
-    if ((rc = trtri_rec(M, X, Tmp, Dinv, n, mid, hi, st))) return rc;
-    const int64_t m2 = (hi - mid) * NB, m1 = (mid - lo) * NB;
+    if ((rc = chol_inv_rec(A, X, Tmp, flag, n, lo, mid, diag_lds, st))) return rc;
+    const int64_t n1 = (mid - lo) * NB, n2 = (hi - mid) * NB;
     const int64_t o21 = (mid * NB) * n + lo * NB, o11 = (lo * NB) * n + lo * NB, o22 = (mid * NB) * n + mid * NB;
-    // T = M21 * X11 ;  X21 = -(X22 * T)
-    if ((rc = launch_gemm32<false, 1, false>(Tmp + o21, n, M + o21, n, X + o11, n, m2, m1, m1, st))) return rc;
-    return launch_gemm32<false, 2, false>(X + o21, n, X + o22, n, Tmp + o21, n, m2, m1, m2, st);
+    {
+        ProfScope ps(PT_CHOL_GEMM, st);
+        if ((rc = launch_gemm32<true, 1, false, 1>(Tmp + o21, n, A + o21, n, X + o11, n, n2, n1, n1, st))) return rc;
+        if ((rc = launch_gemm32<true, 0, true, 0>(A + o22, n, Tmp + o21, n, Tmp + o21, n, n2, n2, n1, st))) return rc;
+    }
+    if ((rc = chol_inv_rec(A, X, Tmp, flag, n, mid, hi, diag_lds, st))) return rc;
+    ProfScope ps(PT_TRTRI_GEMM, st);
+    if ((rc = launch_gemm32<false, 1, false, 2>(A + o21, n, Tmp + o21, n, X + o11, n, n2, n1, n1, st))) return rc;
+    return launch_gemm32<false, 2, false, 3>(X + o21, n, X + o22, n, A + o21, n, n2, n1, n2, st);
 }
 
 int w_prepare(const uint8_t* flags, float* W, int64_t R, int64_t C, int* mismatch, hipStream_t st) {
@@ -280,8 +289,7 @@ int h_prepare(float* H, float* W, int64_t R, int64_t C, float rel_damp, float* U
     const int64_t n = C, nblk = C / NB;
     float* A = reinterpret_cast<float*>(((uintptr_t)ws + 255) & ~(uintptr_t)255);
     float* X = A + (size_t)n * n;
-    float* Dinv = X + (size_t)n * n;
-    uint8_t* dead = reinterpret_cast<uint8_t*>(Dinv + (size_t)n * NB);
+    uint8_t* dead = reinterpret_cast<uint8_t*>(X + (size_t)n * n);
     uint8_t* zc = dead + n;
     int rc;
 
@@ -301,7 +309,6 @@ int h_prepare(float* H, float* W, int64_t R, int64_t C, float rel_damp, float* U
     GQ_LAUNCH_CHECK();
     GQ_HIP(hipMemsetAsync(X, 0, (size_t)n * n * sizeof(float), st));
     }
-
     static bool attr_set = false;
     const size_t diag_lds = (2 * NB * LDP + NB) * sizeof(float);
     if (!attr_set) {
@@ -309,29 +316,7 @@ int h_prepare(float* H, float* W, int64_t R, int64_t C, float rel_damp, float* U
                                    (int)diag_lds));
         attr_set = true;
     }
-    for (int64_t k = 0; k < nblk; ++k) {
-        float* Akk = A + (k * NB) * n + k * NB;
-        float* Dk = Dinv + k * NB * NB;
-        {
-            ProfScope ps(PT_DIAG_POTRF, st);
-            hipLaunchKernelGGL(diag_potrf_inv_kernel, dim3(1), dim3(256), diag_lds, st, Akk, n, Dk, not_invertible);
-            GQ_LAUNCH_CHECK();
-        }
-        const int64_t mrem = n - (k + 1) * NB;
-        if (mrem > 0) {
-            ProfScope ps(PT_CHOL_GEMM, st);
-            float* A21 = A + ((k + 1) * NB) * n + k * NB;
-            // A21 <- A21 * L11^-T   (in place: a workgroup owns whole rows, N == one tile)
-            if ((rc = launch_gemm32<true, 1, false>(A21, n, A21, n, Dk, NB, mrem, NB, NB, st))) return rc;
-            // A22 -= A21 A21^T, lower tiles only
-            float* A22 = A + ((k + 1) * NB) * n + (k + 1) * NB;
-            if ((rc = launch_gemm32<true, 0, true>(A22, n, A21, n, A21, n, mrem, mrem, NB, st))) return rc;
-        }
-    }
-    {
-        ProfScope ps(PT_TRTRI_GEMM, st);
-        if ((rc = trtri_rec(A, X, U, Dinv, n, 0, nblk, st))) return rc;
-    }
+    if ((rc = chol_inv_rec(A, X, U, not_invertible, n, 0, nblk, diag_lds, st))) return rc;
     ProfScope ps(PT_PREP_ELEM, st);
     hipLaunchKernelGGL(finish_u_kernel, dim3(4096), dim3(256), 0, st, U, X, n, not_invertible);
     GQ_LAUNCH_CHECK();

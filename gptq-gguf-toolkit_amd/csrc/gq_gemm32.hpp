@@ -7,6 +7,9 @@
 //   MODE 2:  C = -(A op(B))
 //   TRANS_B: op(B) = B^T with B stored [N,K] row-major (else B is [K,N] row-major)
 //   LOWER:   only tiles with tile_row >= tile_col are computed (square, symmetric updates)
+//   KR:      k-range restriction for triangular operands (zeros are skipped, not multiplied):
+//            0 full; 1: k < n0+128 (B^T lower-triangular); 2: k >= n0 (B lower-triangular);
+//            3: k < m0+128 (A lower-triangular)
 //
 // Workgroup = 256 threads = 4 waves (2x2); tile 128x128; each wave owns 64x64 = 2x2
 // MFMA tiles (64 accumulator VGPRs).  K streams in chunks of 32 through a double-buffered
@@ -81,7 +84,7 @@ __device__ __forceinline__ void g32_store_kn(const float4 (&v)[4], float* S, int
     }
 }
 
-template <bool TRANS_B, int MODE, bool LOWER>
+template <bool TRANS_B, int MODE, bool LOWER, int KR = 0>
 __global__ __launch_bounds__(256, 2) void gemm32_kernel(float* Cmat, int64_t ldc, const float* A, int64_t lda,
                                                         const float* B, int64_t ldb, int64_t M, int64_t N, int64_t K) {
     extern __shared__ __attribute__((aligned(16))) float g32_smem[];
@@ -111,12 +114,18 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(float* Cmat, int64_t ldc
         else g32_store_kn(vb, Bs, tid);
     };
     const int li = lane & 31, lk = lane >> 5;
-    const int64_t nk = (K + TK - 1) / TK;
-    fetch(0);
-    commit(0);
+    int64_t kb = 0, ke = K;
+    if constexpr (KR == 1) ke = (n0 + TN < K) ? n0 + TN : K;
+    if constexpr (KR == 2) kb = (n0 < K) ? n0 : K;
+    if constexpr (KR == 3) ke = (m0 + TM < K) ? m0 + TM : K;
+    const int64_t nk = (ke - kb + TK - 1) / TK;
+    if (nk > 0) {
+        fetch(kb);
+        commit(0);
+    }
     __syncthreads();
     for (int64_t t = 0; t < nk; ++t) {
-        if (t + 1 < nk) fetch((t + 1) * TK);  // in flight during the MFMA block
+        if (t + 1 < nk) fetch(kb + (t + 1) * TK);  // in flight during the MFMA block
         const float* As = g32_smem + (t & 1) * G32_STAGE_FLOATS;
         const float* Bs = As + G32_A_FLOATS;
 #pragma unroll 4
@@ -158,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(float* Cmat, int64_t ldc
         }
 }
 
-template <bool TRANS_B, int MODE, bool LOWER>
+template <bool TRANS_B, int MODE, bool LOWER, int KR = 0>
 inline int launch_gemm32(float* Cmat, int64_t ldc, const float* A, int64_t lda, const float* B, int64_t ldb, int64_t M,
                          int64_t N, int64_t K, hipStream_t st) {
     if (M <= 0 || N <= 0 || K <= 0) return GQ_OK;
@@ -166,12 +175,12 @@ inline int launch_gemm32(float* Cmat, int64_t ldc, const float* A, int64_t lda, 
         GQ_FAIL(GQ_E_BAD_SHAPE, "gemm32: A/B must be 16-byte aligned with ld %% 4 == 0");
     static bool attr_set = false;
     if (!attr_set) {
-        GQ_HIP(hipFuncSetAttribute((const void*)gemm32_kernel<TRANS_B, MODE, LOWER>,
+        GQ_HIP(hipFuncSetAttribute((const void*)gemm32_kernel<TRANS_B, MODE, LOWER, KR>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, G32_LDS_BYTES));
         attr_set = true;
     }
     dim3 grid((unsigned)((N + TN - 1) / TN), (unsigned)((M + TM - 1) / TM)), block(256);
-    hipLaunchKernelGGL((gemm32_kernel<TRANS_B, MODE, LOWER>), grid, block, G32_LDS_BYTES, st, Cmat, ldc, A, lda, B, ldb,
+    hipLaunchKernelGGL((gemm32_kernel<TRANS_B, MODE, LOWER, KR>), grid, block, G32_LDS_BYTES, st, Cmat, ldc, A, lda, B, ldb,
                        M, N, K);
     GQ_LAUNCH_CHECK();
     return GQ_OK;
