@@ -10,8 +10,9 @@
 // Only the upper-triangular 128x128 tiles are computed; each is mirrored in the
 // epilogue, so flops = T*C^2 (+ diagonal tiles) instead of 2*T*C^2.
 //
-// 16-bit path: X[T,C] is first transposed to Xt[C,Tp] (Tp = T rounded up to 32,
-// zero padded) so that both MFMA operands are 16-byte K-contiguous fragments.
+// 16-bit path: X[T,C] is first re-laid out (transpose16_kernel) into per-(panel, stage) blocks
+// that ARE the LDS image of an operand stage, so both MFMA operands are 16-byte K-contiguous
+// fragments and the operand stream is perfectly sequential in HBM.
 #include "gq_common.hpp"
 
 namespace gq {
@@ -21,20 +22,34 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // ---------------------------------------------------------------- transpose
-// Xt[c, t] = X[t, c] for 16-bit elements, 64x64 tiles through LDS.
+// X[T,C] (16-bit) -> Xb[C/128 panels][Tp/64 stages][128 rows][64 k]: each (panel, stage) block is
+// the 16 KiB LDS image of one SYRK operand stage, contiguous in HBM and ALREADY XOR-swizzled
+// (16-byte chunk kc of row r is stored at chunk kc ^ ((r >> 1) & 7)), so the SYRK kernel streams it
+// with lane-linear global_load_lds: every wave instruction copies 1 KiB of consecutive bytes.
+// Tokens t >= T are zero padding.  One workgroup = one block; 16-byte global accesses on both sides.
 __global__ __launch_bounds__(256) void transpose16_kernel(const uint16_t* __restrict__ X, int64_t T, int64_t C,
-                                                          uint16_t* __restrict__ Xt, int64_t Tp) {
-    __shared__ uint16_t tile[64][64 + 2];
-    const int64_t t0 = (int64_t)blockIdx.x * 64, c0 = (int64_t)blockIdx.y * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
-    for (int r = ty; r < 64; r += 4) {
-        int64_t t = t0 + r, c = c0 + tx;
-        tile[r][tx] = (t < T && c < C) ? X[t * C + c] : (uint16_t)0;
+                                                          uint16_t* __restrict__ Xb, int64_t nstage) {
+    __shared__ __attribute__((aligned(16))) uint16_t tile[64][128 + 8];  // [t][c], row = 272 B
+    const int64_t st = blockIdx.x, pn = blockIdx.y;
+    const int64_t t0 = st * 64, c0 = pn * 128;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int idx = tid + u * 256, tr = idx >> 4, c8 = (idx & 15) * 8;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (t0 + tr < T) v = *reinterpret_cast<const uint4*>(X + (t0 + tr) * C + c0 + c8);
+        *reinterpret_cast<uint4*>(&tile[tr][c8]) = v;
     }
     __syncthreads();
-    for (int r = ty; r < 64; r += 4) {
-        int64_t c = c0 + r, t = t0 + tx;
-        if (c < C && t < Tp) Xt[c * Tp + t] = tile[tx][r];
+    uint16_t* out = Xb + (pn * nstage + st) * (128 * 64);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int p = tid + u * 256, r = p >> 3, kc = (p & 7) ^ ((r >> 1) & 7);  // stored chunk p holds k-chunk kc
+        uint32_t w[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            w[e] = (uint32_t)tile[kc * 8 + 2 * e][r] | ((uint32_t)tile[kc * 8 + 2 * e + 1][r] << 16);
+        *reinterpret_cast<uint4*>(out + p * 8) = make_uint4(w[0], w[1], w[2], w[3]);
     }
 }
 
@@ -124,23 +139,20 @@ __global__ __launch_bounds__(256, 2) void syrk16_kernel(const SyrkGroup grp) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-    // staging map: chunk p = t*256 + tid (16 B each), row = p>>3, stored chunk kc' = p&7 holds k-chunk kc'^(row&7)
-    const uint16_t* srcA[4];
-    const uint16_t* srcB[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int p = t * 256 + tid, row = p >> 3, kc = (p & 7) ^ ((row >> 1) & 7);
-        srcA[t] = Xt + (i0 + row) * Tp + kc * 8;
-        srcB[t] = Xt + (j0 + row) * Tp + kc * 8;
-    }
-    auto stage = [&](int buf, int64_t k0) {
+    // operand stage (panel, s) is the contiguous, pre-swizzled 16 KiB block Xb[(panel*nstage + s)*8192 ...]
+    const int64_t nk = Tp / HK;
+    const uint16_t* srcA = Xt + (ti * nk) * (HT * HK) + tid * 8;
+    const uint16_t* srcB = Xt + (tj * nk) * (HT * HK) + tid * 8;
+    auto stage = [&](int buf, int64_t s) {
         unsigned char* base = smem + buf * H_STAGE_BYTES;
+        const uint16_t* pa = srcA + s * (HT * HK);
+        const uint16_t* pb = srcB + s * (HT * HK);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             // LDS destination = wave-uniform base + lane*16 (hardware adds the lane offset)
             unsigned char* la = base + (t * 256 + wid * 64) * 16;
-            __builtin_amdgcn_global_load_lds((glb_void*)(srcA[t] + k0), (lds_void*)la, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_void*)(srcB[t] + k0), (lds_void*)(la + HT * HK * 2), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void*)(pa + t * 2048), (lds_void*)la, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void*)(pb + t * 2048), (lds_void*)(la + HT * HK * 2), 16, 0, 0);
         }
     };
     const int li = lane & 31, lk = lane >> 5;
@@ -153,7 +165,6 @@ __global__ __launch_bounds__(256, 2) void syrk16_kernel(const SyrkGroup grp) {
         swz[0][i] = (ra >> 1) & 7;
         swz[1][i] = (rb >> 1) & 7;
     }
-    const int64_t nk = Tp / HK;
     stage(0, 0);
     __syncthreads();
     for (int64_t t = 0; t < nk; ++t) {
@@ -171,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void syrk16_kernel(const SyrkGroup grp) {
             }
         }
         // 2) start the DMA of stage t+1 into the other buffer (last read one barrier ago)
-        if (t + 1 < nk) stage((int)((t + 1) & 1), (t + 1) * HK);
+        if (t + 1 < nk) stage((int)((t + 1) & 1), t + 1);
         __builtin_amdgcn_sched_barrier(0);  // keep the DMA issue ahead of the MFMA block ...
         // 3) 16 MFMAs per wave cover the DMA flight
 #pragma unroll
@@ -314,8 +325,8 @@ int h_accumulate_grouped(int n, float* const* H, const void* const* X, const int
         wp += ((size_t)C[i] * Tp * 2 + 255) & ~(size_t)255;
         {
             ProfScope ps(PT_TRANSPOSE, st);
-            dim3 tg((unsigned)((Tp + 63) / 64), (unsigned)((C[i] + 63) / 64));
-            hipLaunchKernelGGL(transpose16_kernel, tg, block, 0, st, (const uint16_t*)X[i], T[i], C[i], Xt, Tp);
+            dim3 tg((unsigned)(Tp / HK), (unsigned)(C[i] / HT));
+            hipLaunchKernelGGL(transpose16_kernel, tg, block, 0, st, (const uint16_t*)X[i], T[i], C[i], Xt, Tp / HK);
             GQ_LAUNCH_CHECK();
         }
         const int nt = (int)(C[i] / HT);
