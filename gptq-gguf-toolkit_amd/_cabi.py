@@ -9,7 +9,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-SO_PATH = os.path.join(CSRC, "libgptqgguf_hip.so")
+SO_PATH = os.environ.get("GQ_SO_PATH") or os.path.join(CSRC, "libgptqgguf_hip.so")  # override: kernel A/B probes
 
 F32, F16, BF16 = 0, 1, 2
 WS_H_ACCUMULATE, WS_H_PREPARE, WS_GPTQ_QUANTIZE = 1, 2, 3

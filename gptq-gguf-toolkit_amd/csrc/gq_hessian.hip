@@ -13,6 +13,8 @@
 // 16-bit path: X[T,C] is first re-laid out (transpose16_kernel) into per-(panel, stage) blocks
 // that ARE the LDS image of an operand stage, so both MFMA operands are 16-byte K-contiguous
 // fragments and the operand stream is perfectly sequential in HBM.
+#include <stdlib.h>
+
 #include "gq_common.hpp"
 
 namespace gq {
@@ -139,61 +141,90 @@ __global__ __launch_bounds__(256, 2) void syrk16_kernel(const SyrkGroup grp) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-    // operand stage (panel, s) is the contiguous, pre-swizzled 16 KiB block Xb[(panel*nstage + s)*8192 ...]
+    // operand stage (panel, s) is the contiguous, pre-swizzled 16 KiB block Xb[(panel*nstage + s)*8192 ...];
+    // thread tid owns chunks p = u*256 + tid (u = 0..3) of both operands: global -> VGPR -> LDS, linear.
+    // Register prefetch runs TWO stages ahead (hipcc counts vmcnt per register, so only the stage being
+    // written to LDS is waited for; with global_load_lds it drains everything before any ds_read).
     const int64_t nk = Tp / HK;
-    const uint16_t* srcA = Xt + (ti * nk) * (HT * HK) + tid * 8;
-    const uint16_t* srcB = Xt + (tj * nk) * (HT * HK) + tid * 8;
-    auto stage = [&](int buf, int64_t s) {
-        unsigned char* base = smem + buf * H_STAGE_BYTES;
-        const uint16_t* pa = srcA + s * (HT * HK);
-        const uint16_t* pb = srcB + s * (HT * HK);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            // LDS destination = wave-uniform base + lane*16 (hardware adds the lane offset)
-            unsigned char* la = base + (t * 256 + wid * 64) * 16;
-            __builtin_amdgcn_global_load_lds((glb_void*)(pa + t * 2048), (lds_void*)la, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_void*)(pb + t * 2048), (lds_void*)(la + HT * HK * 2), 16, 0, 0);
-        }
-    };
+    const uint4* srcA = reinterpret_cast<const uint4*>(Xt + (ti * nk) * (HT * HK)) + tid;
+    const uint4* srcB = reinterpret_cast<const uint4*>(Xt + (tj * nk) * (HT * HK)) + tid;
+    // two register sets with static names (arrays indexed through references end up in scratch)
+    uint4 ea0, ea1, ea2, ea3, eb0, eb1, eb2, eb3;  // "even" set
+    uint4 oa0, oa1, oa2, oa3, ob0, ob1, ob2, ob3;  // "odd" set
+#define GQ_FETCH(P, s)                                                                             \
+    do {                                                                                           \
+        const uint4* pa_ = srcA + (s) * 1024;                                                      \
+        const uint4* pb_ = srcB + (s) * 1024;                                                      \
+        P##a0 = pa_[0]; P##a1 = pa_[256]; P##a2 = pa_[512]; P##a3 = pa_[768];                      \
+        P##b0 = pb_[0]; P##b1 = pb_[256]; P##b2 = pb_[512]; P##b3 = pb_[768];                      \
+    } while (0)
+#define GQ_COMMIT(P, buf)                                                                          \
+    do {                                                                                           \
+        uint4* la_ = reinterpret_cast<uint4*>(smem + (buf) * H_STAGE_BYTES) + tid;                 \
+        la_[0] = P##a0; la_[256] = P##a1; la_[512] = P##a2; la_[768] = P##a3;                      \
+        la_[1024] = P##b0; la_[1280] = P##b1; la_[1536] = P##b2; la_[1792] = P##b3;                \
+    } while (0)
     const int li = lane & 31, lk = lane >> 5;
     int offA[2], offB[2], swz[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int ra = wm * 64 + i * 32 + li, rb = wn * 64 + i * 32 + li;
-        offA[i] = ra * 128;
-        offB[i] = HT * HK * 2 + rb * 128;
-        swz[0][i] = (ra >> 1) & 7;
-        swz[1][i] = (rb >> 1) & 7;
+        const int ra_ = wm * 64 + i * 32 + li, rb_ = wn * 64 + i * 32 + li;
+        offA[i] = ra_ * 128;
+        offB[i] = HT * HK * 2 + rb_ * 128;
+        swz[0][i] = (ra_ >> 1) & 7;
+        swz[1][i] = (rb_ >> 1) & 7;
     }
-    stage(0, 0);
-    __syncthreads();
-    for (int64_t t = 0; t < nk; ++t) {
-        // 1) pull ALL fragments of stage t into registers while no LDS-DMA is in flight (hipcc
-        //    conservatively drains vmcnt before any ds_read that follows a global_load_lds)
-        const unsigned char* base = smem + (t & 1) * H_STAGE_BYTES;
-        uint4 a[4][2], b[4][2];
+    auto compute = [&](int buf) {
+        const unsigned char* base = smem + buf * H_STAGE_BYTES;
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
             const int kc = s4 * 2 + lk;
+            uint4 a[2], b[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                a[s4][i] = *reinterpret_cast<const uint4*>(base + offA[i] + ((kc ^ swz[0][i]) << 4));
-                b[s4][i] = *reinterpret_cast<const uint4*>(base + offB[i] + ((kc ^ swz[1][i]) << 4));
+#ifdef GQ_SYRK_NOLDS
+                a[i] = make_uint4(kc + i, lane, 3, 4); b[i] = make_uint4(5, kc, lane + i, 8);
+                asm volatile("" : "+v"(a[i].x), "+v"(b[i].x));
+#else
+                a[i] = *reinterpret_cast<const uint4*>(base + offA[i] + ((kc ^ swz[0][i]) << 4));
+                b[i] = *reinterpret_cast<const uint4*>(base + offB[i] + ((kc ^ swz[1][i]) << 4));
+#endif
             }
-        }
-        // 2) start the DMA of stage t+1 into the other buffer (last read one barrier ago)
-        if (t + 1 < nk) stage((int)((t + 1) & 1), t + 1);
-        __builtin_amdgcn_sched_barrier(0);  // keep the DMA issue ahead of the MFMA block ...
-        // 3) 16 MFMAs per wave cover the DMA flight
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = mfma16<BF16>(a[s4][i], b[s4][j], acc[i][j]);
-        __builtin_amdgcn_sched_barrier(0);  // ... and the MFMA block ahead of the vmcnt(0) drain
-        __syncthreads();  // vmcnt(0) + barrier: stage t+1 landed, stage t's buffer is free
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma16<BF16>(a[i], b[j], acc[i][j]);
+        }
+    };
+    // prologue: stage 0 -> LDS buf 0, stage 1 -> odd register set
+    GQ_FETCH(e, 0);
+    GQ_COMMIT(e, 0);
+    if (nk > 1) GQ_FETCH(o, 1);
+    __syncthreads();
+    for (int64_t t = 0; t < nk; t += 2) {
+        // even step: compute stage t (buf 0); stage t+1 sits in the odd set, stage t+2 goes to the even set
+#ifndef GQ_SYRK_NOLOAD
+        if (t + 2 < nk) GQ_FETCH(e, t + 2);
+#endif
+        compute(0);
+#ifndef GQ_SYRK_NOLOAD
+        if (t + 1 < nk) GQ_COMMIT(o, 1);
+#endif
+        __syncthreads();
+        if (t + 1 < nk) {
+            // odd step: compute stage t+1 (buf 1); stage t+2 sits in the even set, stage t+3 goes to the odd set
+#ifndef GQ_SYRK_NOLOAD
+            if (t + 3 < nk) GQ_FETCH(o, t + 3);
+#endif
+            compute(1);
+#ifndef GQ_SYRK_NOLOAD
+            if (t + 2 < nk) GQ_COMMIT(e, 0);
+#endif
+            __syncthreads();
+        }
     }
+#undef GQ_FETCH
+#undef GQ_COMMIT
     float* __restrict__ H = P.H;
     const float beta = P.beta, alpha = P.alpha;
     const int lc = lane & 31, lh = lane >> 5;
@@ -208,6 +239,130 @@ __global__ __launch_bounds__(256, 2) void syrk16_kernel(const SyrkGroup grp) {
                 float h = beta * H[row * C + col] + alpha * acc[i][j][e];
                 H[row * C + col] = h;
                 if (ti != tj) H[col * C + row] = h;  // mirror (H stays exactly symmetric)
+            }
+        }
+}
+
+// ------------------------------------------------------ 16-bit SYRK, 256x256 tiles
+// Measured on MI355X (profiles/): the 128x128-tile kernel above is bound by the L2 -> CU operand
+// stream (64 flop per operand byte; removing its global loads takes it from 690 to 1230 TFLOP/s).
+// This variant doubles the arithmetic intensity: workgroup = 512 threads = 8 waves (2 x 4), tile
+// 256x256, wave tile 128x64 = 4x2 MFMA tiles (128 accumulator VGPRs), one workgroup per CU with a
+// double-buffered 128 KiB LDS image (two 16 KiB pre-swizzled blocks per operand and stage, fetched
+// through registers one stage ahead).  The 32 workgroups of an XCD form one 4x8 super-tile.
+constexpr int BT = 256;
+constexpr int B_STAGE_BYTES = 2 * BT * HK * 2;  // A 32 KiB | B 32 KiB
+
+template <bool BF16>
+__global__ __launch_bounds__(512, 2) void syrk16_256_kernel(const SyrkGroup grp) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 2, wn = wid & 3;
+    const int xcd = blockIdx.x & 7, kx = blockIdx.x >> 3;
+    const int g = (kx >> 5) * 8 + xcd, slot = kx & 31;
+    if (g >= grp.total_tiles) return;  // total_tiles counts 4x8 SUPER-tiles
+    int pi = 0;
+    for (int i = 1; i < grp.n; ++i)
+        if (g >= grp.p[i].tile_begin) pi = i;
+    const SyrkProblem& P = grp.p[pi];
+    // super-tiles: rows of 4 tiles, columns of 8 tiles, enumerated over the band sJ*8+7 >= sI*4
+    const int nt = P.nt;  // 256-tiles per dimension
+    const int nsc = (nt + 7) >> 3;
+    int rem = g - P.tile_begin, sI = 0;
+    for (;; ++sI) {
+        const int first = (sI * 4) >> 3;  // first super-column touching the upper triangle
+        const int cnt = nsc - first;
+        if (rem < cnt) { rem += first; break; }
+        rem -= cnt;
+    }
+    const int64_t ti = sI * 4 + (slot >> 3), tj = (int64_t)rem * 8 + (slot & 7);
+    if (ti >= nt || tj >= nt || ti > tj) return;
+    const int64_t Tp = P.Tp, C = P.C, nk = Tp / HK;
+    const uint16_t* __restrict__ Xt = P.Xt;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    // chunk q = u*512 + tid (u = 0..3) of the 2048 16-byte chunks of an operand stage (two 128-row blocks)
+    const uint4* srcA[4];
+    const uint4* srcB[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int q = u * 512 + tid;
+        srcA[u] = reinterpret_cast<const uint4*>(Xt + ((2 * ti + (q >> 10)) * nk) * (HT * HK)) + (q & 1023);
+        srcB[u] = reinterpret_cast<const uint4*>(Xt + ((2 * tj + (q >> 10)) * nk) * (HT * HK)) + (q & 1023);
+    }
+    uint4 fa0, fa1, fa2, fa3, fb0, fb1, fb2, fb3;
+#define GQ_FETCH256(s)                                                                           \
+    do {                                                                                         \
+        fa0 = srcA[0][(s) * 1024]; fa1 = srcA[1][(s) * 1024]; fa2 = srcA[2][(s) * 1024];         \
+        fa3 = srcA[3][(s) * 1024]; fb0 = srcB[0][(s) * 1024]; fb1 = srcB[1][(s) * 1024];         \
+        fb2 = srcB[2][(s) * 1024]; fb3 = srcB[3][(s) * 1024];                                    \
+    } while (0)
+#define GQ_COMMIT256(buf)                                                                        \
+    do {                                                                                         \
+        uint4* la_ = reinterpret_cast<uint4*>(smem + (buf) * B_STAGE_BYTES) + tid;               \
+        la_[0] = fa0; la_[512] = fa1; la_[1024] = fa2; la_[1536] = fa3;                          \
+        la_[2048] = fb0; la_[2560] = fb1; la_[3072] = fb2; la_[3584] = fb3;                      \
+    } while (0)
+    const int li = lane & 31, lk = lane >> 5;
+    int offA[4], offB[2], swA[4], swB[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = wm * 128 + i * 32 + li;  // row in the 256-row A image = 2 blocks of [128][128 B]
+        offA[i] = r * 128;
+        swA[i] = (r >> 1) & 7;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = wn * 64 + j * 32 + li;
+        offB[j] = BT * HK * 2 + r * 128;
+        swB[j] = (r >> 1) & 7;
+    }
+    GQ_FETCH256(0);
+    GQ_COMMIT256(0);
+    __syncthreads();
+    for (int64_t t = 0; t < nk; ++t) {
+        if (t + 1 < nk) GQ_FETCH256(t + 1);
+        const unsigned char* base = smem + (t & 1) * B_STAGE_BYTES;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const int kc = s4 * 2 + lk;
+            uint4 a[4], b[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const uint4*>(base + offA[i] + ((kc ^ swA[i]) << 4));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const uint4*>(base + offB[j] + ((kc ^ swB[j]) << 4));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma16<BF16>(a[i], b[j], acc[i][j]);
+        }
+        if (t + 1 < nk) GQ_COMMIT256((int)((t + 1) & 1));
+        __syncthreads();
+    }
+#undef GQ_FETCH256
+#undef GQ_COMMIT256
+    float* __restrict__ H = P.H;
+    const float beta = P.beta, alpha = P.alpha;
+    const int lc = lane & 31, lh = lane >> 5;
+    const int64_t i0 = ti * BT, j0 = tj * BT;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int64_t col = j0 + wn * 64 + j * 32 + lc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int64_t row = i0 + wm * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                float h = beta * H[row * C + col] + alpha * acc[i][j][e];
+                H[row * C + col] = h;
+                if (ti != tj) H[col * C + row] = h;
             }
         }
 }
@@ -317,6 +472,8 @@ int h_accumulate_grouped(int n, float* const* H, const void* const* X, const int
     if (!ws || ws_bytes < need) GQ_FAIL(GQ_E_WORKSPACE, "gq_h_accumulate: workspace %zu < %zu bytes", ws_bytes, need);
     SyrkGroup grp;
     grp.n = n;
+    bool big = getenv("GQ_SYRK_128") == nullptr;
+    for (int i = 0; i < n; ++i) big = big && (C[i] % BT == 0);
     int tiles = 0;
     unsigned char* wp = reinterpret_cast<unsigned char*>(((uintptr_t)ws + 255) & ~(uintptr_t)255);
     for (int i = 0; i < n; ++i) {
@@ -329,23 +486,36 @@ int h_accumulate_grouped(int n, float* const* H, const void* const* X, const int
             hipLaunchKernelGGL(transpose16_kernel, tg, block, 0, st, (const uint16_t*)X[i], T[i], C[i], Xt, Tp / HK);
             GQ_LAUNCH_CHECK();
         }
-        const int nt = (int)(C[i] / HT);
-        grp.p[i] = SyrkProblem{H[i], Xt, C[i], Tp, beta[i], alpha[i], tiles, nt};
-        const int ns = (nt + 7) / 8;  // 8x8 super-tiles per dimension
-        tiles += ns * (ns + 1) / 2;
+        if (big) {
+            const int nt = (int)(C[i] / BT), nsc = (nt + 7) / 8, nsr = (nt + 3) / 4;
+            grp.p[i] = SyrkProblem{H[i], Xt, C[i], Tp, beta[i], alpha[i], tiles, nt};
+            for (int sI = 0; sI < nsr; ++sI) tiles += nsc - ((sI * 4) >> 3);  // 4x8 super-tiles on/above the diagonal
+        } else {
+            const int nt = (int)(C[i] / HT);
+            grp.p[i] = SyrkProblem{H[i], Xt, C[i], Tp, beta[i], alpha[i], tiles, nt};
+            const int ns = (nt + 7) / 8;  // 8x8 super-tiles per dimension
+            tiles += ns * (ns + 1) / 2;
+        }
     }
     grp.total_tiles = tiles;
     static bool attr_set = false;
     if (!attr_set) {
         GQ_HIP(hipFuncSetAttribute((const void*)syrk16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * H_STAGE_BYTES));
         GQ_HIP(hipFuncSetAttribute((const void*)syrk16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * H_STAGE_BYTES));
+        GQ_HIP(hipFuncSetAttribute((const void*)syrk16_256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * B_STAGE_BYTES));
+        GQ_HIP(hipFuncSetAttribute((const void*)syrk16_256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * B_STAGE_BYTES));
         attr_set = true;
     }
     ProfScope ps(PT_SYRK, st);
-    if (x_dtype == GQ_BF16)
-        hipLaunchKernelGGL(syrk16_kernel<true>, dim3((unsigned)((tiles + 7) / 8 * 8 * 64)), block, 2 * H_STAGE_BYTES, st, grp);
-    else
-        hipLaunchKernelGGL(syrk16_kernel<false>, dim3((unsigned)((tiles + 7) / 8 * 8 * 64)), block, 2 * H_STAGE_BYTES, st, grp);
+    if (big) {
+        const dim3 grid((unsigned)((tiles + 7) / 8 * 8 * 32)), blk(512);
+        if (x_dtype == GQ_BF16) hipLaunchKernelGGL(syrk16_256_kernel<true>, grid, blk, 2 * B_STAGE_BYTES, st, grp);
+        else hipLaunchKernelGGL(syrk16_256_kernel<false>, grid, blk, 2 * B_STAGE_BYTES, st, grp);
+    } else {
+        const dim3 grid((unsigned)((tiles + 7) / 8 * 8 * 64));
+        if (x_dtype == GQ_BF16) hipLaunchKernelGGL(syrk16_kernel<true>, grid, block, 2 * H_STAGE_BYTES, st, grp);
+        else hipLaunchKernelGGL(syrk16_kernel<false>, grid, block, 2 * H_STAGE_BYTES, st, grp);
+    }
     GQ_LAUNCH_CHECK();
     return GQ_OK;
 }
