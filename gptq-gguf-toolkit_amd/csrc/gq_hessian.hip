@@ -330,19 +330,39 @@ __global__ __launch_bounds__(512, 2) void syrk16_256_kernel(const SyrkGroup grp)
     for (int64_t t = 0; t < nk; ++t) {
         if (t + 1 < nk) GQ_FETCH256(t + 1);
         const unsigned char* base = smem + (t & 1) * B_STAGE_BYTES;
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-            const int kc = s4 * 2 + lk;
-            uint4 a[4], b[2];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const uint4*>(base + offA[i] + ((kc ^ swA[i]) << 4));
-#pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const uint4*>(base + offB[j] + ((kc ^ swB[j]) << 4));
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = mfma16<BF16>(a[i], b[j], acc[i][j]);
-        }
+        // fragments of k16-step s4+1 are read while the 8 MFMAs of step s4 run (register double buffer;
+        // sched_group_barrier pins "6 LDS reads, then 8 MFMAs" so the reads are not sunk to their use)
+        uint4 a[2][4], b[2][2];
+#define GQ_FRAGS(S, D)                                                                                      \
+    do {                                                                                                    \
+        const int kc_ = (S) * 2 + lk;                                                                       \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                       \
+            a[D][i] = *reinterpret_cast<const uint4*>(base + offA[i] + ((kc_ ^ swA[i]) << 4));              \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                       \
+            b[D][j] = *reinterpret_cast<const uint4*>(base + offB[j] + ((kc_ ^ swB[j]) << 4));              \
+    } while (0)
+#define GQ_MFMAS(D)                                                                                         \
+    do {                                                                                                    \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                       \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] = mfma16<BF16>(a[D][i], b[D][j], acc[i][j]); \
+    } while (0)
+        GQ_FRAGS(0, 0);
+        GQ_FRAGS(1, 1);
+        __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+        GQ_MFMAS(0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+        GQ_FRAGS(2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+        GQ_MFMAS(1);
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+        GQ_FRAGS(3, 1);
+        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+        GQ_MFMAS(0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+        GQ_MFMAS(1);
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+#undef GQ_FRAGS
+#undef GQ_MFMAS
         if (t + 1 < nk) GQ_COMMIT256((int)((t + 1) & 1));
         __syncthreads();
     }
