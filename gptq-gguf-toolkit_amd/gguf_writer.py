@@ -1,0 +1,160 @@
+"""Minimal GGUF v3 writer (container only), written from the GGUF specification.
+
+The reference delegates the container to gguf-py 0.17.1 (`GGUFWriter`, not vendored in its
+tree and not installable here): header, key/value metadata, tensor infos, 32-byte aligned
+tensor data.  PARITY UNPINNED for whole-file byte identity (no reference file exists to
+compare against); the tensor PAYLOADS are the pinned part (packing_utils / gq_pack).
+Layout (little endian):
+  magic "GGUF" | u32 version=3 | u64 n_tensors | u64 n_kv
+  n_kv x { string key | u32 value_type | value }
+  n_tensors x { string name | u32 n_dims | u64 dims[n_dims] (ggml order: innermost first)
+                | u32 ggml_type | u64 offset (from the start of the data section) }
+  padding to `general.alignment` (32) | tensor data, each tensor padded to the alignment
+"""
+import struct
+from typing import Any, List, Sequence, Tuple
+
+import numpy as np
+
+GGUF_MAGIC = b"GGUF"
+GGUF_VERSION = 3
+ALIGNMENT = 32
+
+
+class GGUFValueType:
+    UINT8, INT8, UINT16, INT16, UINT32, INT32, FLOAT32, BOOL, STRING, ARRAY, UINT64, INT64, FLOAT64 = range(13)
+
+
+class GGMLType:
+    F32, F16 = 0, 1
+    Q2_K, Q3_K, Q4_K, Q5_K, Q6_K = 10, 11, 12, 13, 14
+    BF16 = 30
+
+
+# (block size in values, bytes per block)
+GGML_QUANT_SIZES = {GGMLType.F32: (1, 4), GGMLType.F16: (1, 2), GGMLType.BF16: (1, 2), GGMLType.Q2_K: (256, 84),
+                    GGMLType.Q3_K: (256, 110), GGMLType.Q4_K: (256, 144), GGMLType.Q5_K: (256, 176),
+                    GGMLType.Q6_K: (256, 210)}
+
+
+def _s(b: str) -> bytes:
+    e = b.encode("utf-8")
+    return struct.pack("<Q", len(e)) + e
+
+
+_SCALAR_FMT = {GGUFValueType.UINT8: "<B", GGUFValueType.INT8: "<b", GGUFValueType.UINT16: "<H",
+               GGUFValueType.INT16: "<h", GGUFValueType.UINT32: "<I", GGUFValueType.INT32: "<i",
+               GGUFValueType.FLOAT32: "<f", GGUFValueType.BOOL: "<?", GGUFValueType.UINT64: "<Q",
+               GGUFValueType.INT64: "<q", GGUFValueType.FLOAT64: "<d"}
+
+
+def _pack_value(vtype: int, v: Any, sub: int = None) -> bytes:
+    if vtype == GGUFValueType.STRING:
+        return _s(v)
+    if vtype == GGUFValueType.ARRAY:
+        out = struct.pack("<IQ", sub, len(v))
+        return out + b"".join(_pack_value(sub, x) for x in v)
+    return struct.pack(_SCALAR_FMT[vtype], v)
+
+
+def quant_shape_from_byte_shape(shape: Sequence[int], ggml_type: int) -> Tuple[int, ...]:
+    bs, ts = GGML_QUANT_SIZES[ggml_type]
+    assert shape[-1] % ts == 0
+    return (*shape[:-1], shape[-1] // ts * bs)
+
+
+class GGUFWriter:
+    def __init__(self, path: str, arch: str):
+        self.path = path
+        self.kv: List[Tuple[str, int, Any, int]] = []
+        self.tensors: List[Tuple[str, Tuple[int, ...], int, np.ndarray]] = []
+        self.add_string("general.architecture", arch)
+
+    # ---- metadata
+    def add(self, key, vtype, value, sub=None):
+        self.kv.append((key, vtype, value, sub))
+
+    def add_string(self, k, v): self.add(k, GGUFValueType.STRING, v)
+    def add_uint32(self, k, v): self.add(k, GGUFValueType.UINT32, int(v))
+    def add_float32(self, k, v): self.add(k, GGUFValueType.FLOAT32, float(v))
+    def add_bool(self, k, v): self.add(k, GGUFValueType.BOOL, bool(v))
+    def add_array(self, k, v, sub): self.add(k, GGUFValueType.ARRAY, list(v), sub)
+
+    # ---- tensors
+    def add_tensor(self, name: str, data: np.ndarray, raw_dtype: int = None):
+        """raw_dtype given: `data` is uint8 [.., nbytes] block bytes (reference pack_gptq_into_gguf.py:344-348)."""
+        data = np.ascontiguousarray(data)
+        if raw_dtype is None:
+            raw_dtype = {np.dtype(np.float32): GGMLType.F32, np.dtype(np.float16): GGMLType.F16}[data.dtype]
+            shape = data.shape
+        else:
+            shape = quant_shape_from_byte_shape(data.shape, raw_dtype) if data.dtype == np.uint8 else data.shape
+        self.tensors.append((name, tuple(int(x) for x in shape), int(raw_dtype), data))
+
+    def write(self):
+        with open(self.path, "wb") as f:
+            f.write(GGUF_MAGIC + struct.pack("<IQQ", GGUF_VERSION, len(self.tensors), len(self.kv)))
+            for k, t, v, sub in self.kv:
+                f.write(_s(k) + struct.pack("<I", t) + _pack_value(t, v, sub))
+            off = 0
+            for name, shape, gt, data in self.tensors:
+                f.write(_s(name) + struct.pack("<I", len(shape)))
+                f.write(b"".join(struct.pack("<Q", d) for d in reversed(shape)))  # ggml ne[0] = innermost
+                f.write(struct.pack("<IQ", gt, off))
+                off += (data.nbytes + ALIGNMENT - 1) // ALIGNMENT * ALIGNMENT
+            pad = (-f.tell()) % ALIGNMENT
+            f.write(b"\x00" * pad)
+            for _, _, _, data in self.tensors:
+                f.write(data.tobytes())
+                f.write(b"\x00" * ((-data.nbytes) % ALIGNMENT))
+
+
+def read_gguf(path: str):
+    """Tiny reader (tests / verification): -> (kv dict, {name: (shape, ggml_type, raw bytes as np.uint8)})."""
+    buf = open(path, "rb").read()
+    pos = 0
+
+    def rd(fmt):
+        nonlocal pos
+        v = struct.unpack_from(fmt, buf, pos)
+        pos += struct.calcsize(fmt)
+        return v if len(v) > 1 else v[0]
+
+    def rs():
+        nonlocal pos
+        n = rd("<Q")
+        s = buf[pos:pos + n].decode("utf-8")
+        pos += n
+        return s
+
+    def rv(t):
+        if t == GGUFValueType.STRING:
+            return rs()
+        if t == GGUFValueType.ARRAY:
+            sub, n = rd("<I"), rd("<Q")
+            return [rv(sub) for _ in range(n)]
+        return rd(_SCALAR_FMT[t])
+
+    assert buf[:4] == GGUF_MAGIC
+    pos = 4
+    ver, nt, nkv = rd("<I"), rd("<Q"), rd("<Q")
+    assert ver == GGUF_VERSION
+    kv = {}
+    for _ in range(nkv):
+        k = rs()
+        t = rd("<I")
+        kv[k] = rv(t)
+    infos = []
+    for _ in range(nt):
+        name = rs()
+        nd = rd("<I")
+        dims = [rd("<Q") for _ in range(nd)]
+        gt, off = rd("<I"), rd("<Q")
+        infos.append((name, tuple(reversed(dims)), gt, off))
+    data0 = (pos + ALIGNMENT - 1) // ALIGNMENT * ALIGNMENT
+    tensors = {}
+    for name, shape, gt, off in infos:
+        bs, ts = GGML_QUANT_SIZES[gt]
+        n = int(np.prod(shape)) // bs * ts
+        tensors[name] = (shape, gt, np.frombuffer(buf, np.uint8, n, data0 + off))
+    return kv, tensors

@@ -1,0 +1,80 @@
+"""CPU stand-in for gptq_gguf_toolkit_amd.ops, backed by the ORACLE, used ONLY by the CPU tests of
+the host logic (driver walk, Hessian sharing, 2-rank gloo exchange).  It mirrors the ops signatures
+on CPU torch tensors.  This is test scaffolding: the product package never imports it."""
+import numpy as np
+import torch
+
+from oracle import oracle as O
+
+calls = {"h_accumulate": 0, "h_prepare": 0, "w_prepare": 0, "gptq_quantize": 0}
+
+
+def _f16(bits):
+    return torch.from_numpy(np.ascontiguousarray(bits).view(np.int16)).view(torch.float16)
+
+
+def _bits(t):
+    return t.contiguous().view(torch.int16).numpy().view(np.uint16)
+
+
+def h_accumulate(H, X, beta, alpha, ws=None):
+    calls["h_accumulate"] += 1
+    H.copy_(torch.from_numpy(O.h_accumulate(H.numpy(), X.float().numpy(), beta, alpha)))
+    return H
+
+
+def h_prepare(H, W, rel_damp, want_flags=False):
+    calls["h_prepare"] += 1
+    H0 = H.numpy().copy()
+    dead = (np.diag(H0) == 0)
+    U, H2, W2, bad = O.h_prepare(H0, W.numpy(), rel_damp)
+    H.copy_(torch.from_numpy(H2))
+    W.copy_(torch.from_numpy(W2))
+    flag = torch.tensor([int(bad)], dtype=torch.int32)
+    zc = dead | (W2 == 0).all(axis=0)
+    cf = torch.from_numpy(np.concatenate([dead, zc]).astype(np.uint8))
+    U = torch.from_numpy(U)
+    return (U, flag, cf) if want_flags else (U, flag)
+
+
+def w_prepare(cf, W):
+    calls["w_prepare"] += 1
+    C = W.shape[1]
+    dead, zc = cf[:C].bool(), cf[C:].bool()
+    W[:, dead] = 0
+    mine = dead | (W == 0).all(dim=0)
+    return torch.tensor([int(not torch.equal(mine, zc))], dtype=torch.int32)
+
+
+def gptq_quantize(W, U, q_type, block_size=128, static_groups=False, rmin=-1.0, rdelta=0.1, nstep=20, ws=None):
+    calls["gptq_quantize"] += 1
+    Wd, q, d, s, dmin, m = O.gptq_step(W.numpy(), U.numpy(), q_type, block_size, static_groups, rmin, rdelta, nstep)
+    W.copy_(torch.from_numpy(Wd))
+    return torch.from_numpy(q), _f16(d), torch.from_numpy(s), _f16(dmin), torch.from_numpy(m)
+
+
+def rtn_quantize(W, q_type, rmin=-1.0, rdelta=0.1, nstep=20):
+    q, d, s, dmin, m = O.rtn_quantize(W.float().numpy(), q_type, rmin, rdelta, nstep)
+    return torch.from_numpy(q), _f16(d), torch.from_numpy(s), _f16(dmin), torch.from_numpy(m)
+
+
+def dequantize(q_type, q, d, s, dmin, m, out_dtype=torch.float32):
+    w = O.dequantize(q_type, q.numpy(), _bits(d), s.numpy(), _bits(dmin), m.numpy())
+    return torch.from_numpy(w).to(out_dtype)
+
+
+def install(monkeypatch=None):
+    """Point the host modules at this backend (they normally call the HIP library)."""
+    import sys
+    import gptq_gguf_toolkit_amd.gptq as g
+    import gptq_gguf_toolkit_amd.quant_utils as qu
+    import gptq_gguf_toolkit_amd.quantizer as qz
+    me = sys.modules[__name__]
+    for mod in (g, qu, qz):
+        if monkeypatch is not None:
+            monkeypatch.setattr(mod, "_ops", me)
+        else:
+            mod._ops = me
+    for k in calls:
+        calls[k] = 0
+    return me

@@ -375,9 +375,67 @@ def g8_g9_rtn_dequant():
     save("g8_g9_rtn_dequant", **out)
 
 
-if __name__ == "__main__":
+def _main_all():
     torch.set_num_threads(8)
     for fn in (g1_make_quants, g2_scale_search, g3_elementwise, g4_g5_hessian, g6_g7_step_and_pack,
                g8_g9_rtn_dequant):
         print(fn.__name__)
         fn()
+    g10_driver()
+
+
+# ----------------------------------------------------------------------------- G10 driver tree
+def tiny_llama(seed=0, dtype=torch.float32):
+    """Seeded random LlamaForCausalLM used by the driver fixtures AND by tests/test_driver_gpu.py."""
+    from transformers import LlamaConfig, LlamaForCausalLM
+    cfg = LlamaConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                      num_key_value_heads=2, vocab_size=512, max_position_embeddings=128, rms_norm_eps=1e-5,
+                      tie_word_embeddings=False, attn_implementation="eager")
+    torch.manual_seed(seed)
+    model = LlamaForCausalLM(cfg).to(dtype)
+    model.eval()
+    return model
+
+
+def tiny_calib(n=8, L=64, vocab=512, seed=1):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randint(0, vocab, (1, L), generator=g) for _ in range(n)]
+
+
+MIXED = {"q_proj": "Q3_K", "k_proj": "Q2_K", "v_proj": "Q4_K", "o_proj": "Q5_K", "gate_proj": "Q6_K",
+         "down_proj": "Q3_K", "up_proj": "Q4_K", "embed_tokens": "Q6_K", "lm_head": "Q6_K"}  # README.md:94-106
+
+
+def g10_driver():
+    import tempfile
+    set_sqrt("ieee")
+    model = tiny_llama()
+    data = [([], {"input_ids": ids}) for ids in tiny_calib()]
+    qc = {k: T[v] for k, v in MIXED.items()}
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        drv = RefDriver(model, data_loader=data, quantizable_modules=r".*layers.*((q|k|v|o|gate|up|down)_proj)$",
+                        quantizer_kwargs=dict(rel_damp=0.01, block_size=128, act_order=False, quant_scale="absmax",
+                                              static_groups=False, rmin=-1.0, rdelta=0.1, nstep=20, verbose=False),
+                        pre_block_modules=["model.embed_tokens"], block_modules="model.layers",
+                        post_block_modules=["lm_head"], quant_non_block_modules=True, device="cpu", save_dir=td)
+        drv.quantize(qc)
+        names = sorted(os.listdir(td))
+        out["names"] = np.array(names)
+        for n in names:
+            d = torch.load(os.path.join(td, n, "data.pth"), weights_only=True)
+            out[f"{n}|q_type"] = np.array(d["q_type"])
+            out[f"{n}|qweight"] = d["qweight"].numpy()
+            out[f"{n}|d"], out[f"{n}|dmin"] = u16(d["super_group_scale"]), u16(d["super_group_zero"])
+            out[f"{n}|s"], out[f"{n}|m"] = d["group_scale_quant"].numpy(), d["group_zero_quant"].numpy()
+    # logits of the quantized model on the first calibration sample (end-to-end sanity anchor)
+    with torch.no_grad():
+        out["logits_head"] = model(tiny_calib()[0]).logits[0, :4, :16].numpy()
+    save("g10_driver", **out)
+
+
+if __name__ == "__main__":
+    if "g10" in sys.argv[1:]:
+        g10_driver()
+    else:
+        _main_all()

@@ -1,0 +1,189 @@
+"""Host-side logic on CPU: CLI config rules, sharding / owner assignment, GGUF container + Llama
+permute, and the driver (walk order, Hessian sharing, data.pth schema) with the compute backend
+replaced by tests/fake_ops.py (oracle-backed).  World-size-2 gloo runs cover the N>1 path."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import ROOT, load_golden
+
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+
+
+def test_quant_config_rules(tmp_path):
+    from gptq_gguf_toolkit_amd.quant import build_quant_config, parse_args
+    from gptq_gguf_toolkit_amd.quant_utils import GGMLQuantizationType as T
+    qc = build_quant_config("Q4_K", None)
+    assert set(qc) == {"q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "down_proj", "up_proj", "embed_tokens",
+                       "lm_head"} and all(v == T.Q4_K for v in qc.values())
+    p = tmp_path / "config.json"
+    p.write_text(json.dumps({"q_proj": "Q3_K", "down_proj": "Q6_K"}))
+    qc = build_quant_config("Q4_K", str(p))  # the file REPLACES the default map (quant.py:203-217)
+    assert qc == {"q_proj": T.Q3_K, "down_proj": T.Q6_K}
+    with pytest.raises(ValueError):
+        build_quant_config("Q8_0", None)
+    with pytest.raises(ValueError):
+        build_quant_config("Q4_K", str(tmp_path / "missing.json"))
+    p.write_text(json.dumps({"q_proj": "Q4_0"}))
+    with pytest.raises(ValueError):
+        build_quant_config(None, str(p))
+    a = parse_args(["--model_name_or_path", "m", "--quantizable_modules", "x", "--pre_block_modules", "e",
+                    "--block_modules", "b", "--calibration_data", "c.pt", "--save_dir", "s"])
+    assert (a.rel_damp, a.block_size, a.default_bit_width, a.rmin, a.rdelta, a.nstep, a.quant_scale) == \
+        (1e-2, 128, "Q4_K", -1.0, 0.1, 20, "absmax")
+
+
+def test_sharding_and_owner_assignment():
+    from gptq_gguf_toolkit_amd.dist_utils import assign_owners, shard_calibration
+    data = list(range(11))
+    assert shard_calibration(data, 0, 4) == [0, 1] and shard_calibration(data, 3, 4) == [6, 7]  # remainder dropped
+    shapes = {"q": (4096, 4096), "k": (1024, 4096), "v": (1024, 4096), "o": (4096, 4096), "gate": (14336, 4096),
+              "up": (14336, 4096), "down": (4096, 14336)}
+    costs = {n: float(r) * c * (c + 128) for n, (r, c) in shapes.items()}
+    for w in (1, 2, 4, 8):
+        own = assign_owners(costs, w)
+        assert set(own) == set(costs) and all(0 <= r < w for r in own.values())
+        assert own == assign_owners(dict(reversed(list(costs.items()))), w)  # order independent => same on all ranks
+    own = assign_owners(costs, 2)
+    loads = [sum(costs[n] for n in own if own[n] == r) for r in range(2)]
+    assert max(loads) == costs["down"]  # the largest matrix alone on one rank is the LPT optimum here
+
+
+def test_llama_permute_and_names():
+    from gptq_gguf_toolkit_amd.pack_gptq_into_gguf import map_tensor_name, permute
+    # by hand from pack_gptq_into_gguf.py:2177-2183: rows [h, two, r] -> [h, r, two]
+    n_head, hd = 2, 4
+    w = torch.arange(n_head * hd * 3).reshape(n_head * hd, 3)
+    out = permute(w, n_head, n_head)
+    rows = [h * hd + two * (hd // 2) + r for h in range(n_head) for r in range(hd // 2) for two in range(2)]
+    assert torch.equal(out, w[rows])
+    assert torch.equal(permute(w, 4, 2), permute(w, 2, 2))  # GQA: k_proj uses n_kv_head
+    v = torch.arange(8)  # 1-D (e.g. a [R] scale vector) permutes the same way
+    assert torch.equal(permute(v, 2, 2), v[[0, 2, 1, 3, 4, 6, 5, 7]])
+    assert map_tensor_name("model.layers.3.self_attn.k_proj.weight") == "blk.3.attn_k.weight"
+    assert map_tensor_name("model.layers.0.mlp.down_proj.weight") == "blk.0.ffn_down.weight"
+    assert map_tensor_name("lm_head.weight") == "output.weight"
+    with pytest.raises(ValueError):
+        map_tensor_name("model.layers.0.block_sparse_moe.experts.0.w1.weight")
+
+
+def test_gguf_container_roundtrip(tmp_path):
+    from gptq_gguf_toolkit_amd.gguf_writer import GGMLType, GGUFValueType, GGUFWriter, read_gguf
+    w = GGUFWriter(str(tmp_path / "t.gguf"), "llama")
+    w.add_uint32("llama.block_count", 2)
+    w.add_float32("llama.rope.freq_base", 500000.0)
+    w.add_array("tokenizer.ggml.tokens", ["a", "bc", "déf"], GGUFValueType.STRING)
+    w.add_array("tokenizer.ggml.token_type", [1, 1, 3], GGUFValueType.INT32)
+    f32 = np.arange(12, dtype=np.float32).reshape(3, 4)
+    packed = (np.arange(5 * 2 * 144) % 251).astype(np.uint8).reshape(5, 288)  # Q4_K [5, 512]
+    w.add_tensor("output_norm.weight", f32[0])
+    w.add_tensor("a.weight", f32.astype(np.float16))
+    w.add_tensor("blk.0.attn_q.weight", packed, raw_dtype=GGMLType.Q4_K)
+    w.write()
+    raw = open(tmp_path / "t.gguf", "rb").read()
+    assert raw[:4] == b"GGUF" and int.from_bytes(raw[4:8], "little") == 3
+    kv, ts = read_gguf(str(tmp_path / "t.gguf"))
+    assert kv["general.architecture"] == "llama" and kv["llama.block_count"] == 2
+    assert kv["tokenizer.ggml.tokens"] == ["a", "bc", "déf"] and kv["tokenizer.ggml.token_type"] == [1, 1, 3]
+    assert ts["blk.0.attn_q.weight"][0] == (5, 512) and ts["blk.0.attn_q.weight"][1] == GGMLType.Q4_K
+    assert np.array_equal(ts["blk.0.attn_q.weight"][2], packed.ravel())
+    assert np.array_equal(ts["a.weight"][2].view(np.float16), f32.astype(np.float16).ravel())
+    assert np.array_equal(ts["output_norm.weight"][2].view(np.float32), f32[0])
+
+
+# --------------------------------------------------------------------------- driver (fake backend)
+def _run_driver(save_dir, data, world=1):
+    import fake_ops
+    from make_golden_shim import MIXED, tiny_llama
+    from gptq_gguf_toolkit_amd.quant_utils import GGMLQuantizationType as T
+    from gptq_gguf_toolkit_amd.quantizer import Quantizer
+    fake_ops.install()
+    model = tiny_llama()
+    drv = Quantizer(model, data_loader=data, quantizable_modules=r".*layers.*((q|k|v|o|gate|up|down)_proj)$",
+                    quantizer_kwargs=dict(rel_damp=0.01, block_size=128, act_order=False, quant_scale="absmax",
+                                          static_groups=False, rmin=-1.0, rdelta=0.1, nstep=20, verbose=False),
+                    pre_block_modules=["model.embed_tokens"], block_modules="model.layers",
+                    post_block_modules=["lm_head"], quant_non_block_modules=True, device="cpu", save_dir=save_dir)
+    drv.quantize({k: T[v] for k, v in MIXED.items()})
+    return model, fake_ops
+
+
+def test_driver_walk_schema_and_hessian_sharing(tmp_path):
+    """Same tree, keys, dtypes and shapes as the reference driver (G10); q/k/v and gate/up share one
+    Hessian accumulation; results close to the reference's (H here comes from the fp64 oracle, the
+    reference's from MKL fp32, so near-ties may flip: mismatch RATES are asserted)."""
+    from make_golden_shim import tiny_calib
+    g = load_golden("g10_driver")
+    data = [([], {"input_ids": ids}) for ids in tiny_calib()]
+    model, fake = _run_driver(str(tmp_path), data)
+    names = sorted(os.listdir(tmp_path))
+    assert names == list(g["names"])
+    # 2 blocks x 4 distinct inputs, flushed once each (activations are buffered)
+    assert fake.calls["h_accumulate"] == 2 * 4
+    assert fake.calls["h_prepare"] == 2 * 4 and fake.calls["w_prepare"] == 2 * 3  # q/k/v + gate/up share U
+    worst = 0.0
+    for n in names:
+        d = torch.load(os.path.join(tmp_path, n, "data.pth"), weights_only=True)
+        assert set(d) == {"q_type", "qweight", "super_group_scale", "super_group_zero", "group_scale_quant",
+                          "group_zero_quant"}
+        assert d["q_type"] == int(g[f"{n}|q_type"])
+        q = d["qweight"].numpy()
+        assert q.dtype == g[f"{n}|qweight"].dtype and q.shape == g[f"{n}|qweight"].shape
+        assert d["super_group_scale"].dtype == torch.float16 and d["group_scale_quant"].numpy().dtype == g[f"{n}|s"].dtype
+        mism = float((q != g[f"{n}|qweight"]).mean())
+        worst = max(worst, mism)
+        if n in ("model.embed_tokens", "lm_head"):
+            assert mism == 0.0  # RTN has no Hessian: bit-exact
+    assert worst < 0.05, f"worst per-module int mismatch rate {worst:.3%}"
+
+
+def _worker(rank, world, port, tmp, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from make_golden_shim import tiny_calib
+    from gptq_gguf_toolkit_amd import dist_utils
+    data = dist_utils.shard_calibration(tiny_calib(), rank, world)
+    data = [([], {"input_ids": ids}) for ids in data]
+    model, fake = _run_driver(tmp, data, world)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    ret[rank] = (sd, dict(fake.calls))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_matches_single_rank(tmp_path):
+    """calib-sharded H (all-reduce AVG) + per-matrix owners + broadcast: every rank ends with the same
+    quantized model, equal to the 1-rank run on the full calibration set up to H rounding order."""
+    from make_golden_shim import tiny_calib
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    d2 = str(tmp_path / "w2")
+    os.makedirs(d2)
+    mp.spawn(_worker, args=(world, 29000 + os.getpid() % 2000, d2, ret), nprocs=world, join=True)
+    sd0, calls0 = ret[0]
+    sd1, calls1 = ret[1]
+    for k in sd0:
+        assert torch.equal(sd0[k], sd1[k]), f"ranks disagree on {k}"
+    # owners split the work: each rank ran some, not all, of the 14 column loops
+    assert 0 < calls0["gptq_quantize"] < 14 and calls0["gptq_quantize"] + calls1["gptq_quantize"] == 14
+    d1 = str(tmp_path / "w1")
+    os.makedirs(d1)
+    data = [([], {"input_ids": ids}) for ids in tiny_calib()]
+    model1, _ = _run_driver(d1, data)
+    assert sorted(os.listdir(d1)) == sorted(os.listdir(d2))  # rank 0 wrote the same tree
+    tot = diff = 0
+    for n in sorted(os.listdir(d1)):
+        a = torch.load(os.path.join(d1, n, "data.pth"), weights_only=True)["qweight"]
+        b = torch.load(os.path.join(d2, n, "data.pth"), weights_only=True)["qweight"]
+        tot += a.numel()
+        diff += int((a != b).sum())
+    assert diff / tot < 0.02, f"{diff / tot:.3%} ints differ between 1-rank and 2-rank runs"
