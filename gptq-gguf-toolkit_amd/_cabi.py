@@ -16,7 +16,7 @@ WS_H_ACCUMULATE, WS_H_PREPARE, WS_GPTQ_QUANTIZE = 1, 2, 3
 
 EXPORTS = (
     "gq_abi_version", "gq_last_error", "gq_type_info", "gq_workspace_bytes", "gq_h_accumulate", "gq_h_accumulate_grouped", "gq_h_prepare", "gq_w_prepare",
-    "gq_scale_search", "gq_gptq_quantize", "gq_rtn_quantize", "gq_dequantize", "gq_pack", "gq_trailing_update",
+    "gq_scale_search", "gq_group_search", "gq_gptq_quantize", "gq_rtn_quantize", "gq_dequantize", "gq_pack", "gq_trailing_update",
     "gq_prof_enable", "gq_prof_ntags", "gq_prof_name", "gq_prof_collect",
 )
 
@@ -67,6 +67,7 @@ def lib():
     L.gq_h_prepare.argtypes = [vp, vp, i64, i64, cf, vp, vp, vp, vp, sz, vp]
     L.gq_w_prepare.argtypes = [vp, vp, i64, i64, vp, vp]
     L.gq_scale_search.argtypes = [vp, i64, i64, ci, sp, vp, i64, vp, i64, vp, i64, vp, i64, vp]
+    L.gq_group_search.argtypes = [vp, ci, i64, i64, ci, sp, vp, vp, vp, vp, vp, vp, vp]
     L.gq_gptq_quantize.argtypes = [vp, vp, i64, i64, ci, ci, ci, sp, vp, vp, vp, vp, vp, vp, sz, vp]
     L.gq_rtn_quantize.argtypes = [vp, ci, i64, i64, ci, sp, vp, vp, vp, vp, vp, vp]
     L.gq_dequantize.argtypes = [ci, vp, vp, vp, vp, vp, i64, i64, vp, ci, vp]

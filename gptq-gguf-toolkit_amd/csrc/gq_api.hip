@@ -12,6 +12,8 @@ int launch_rtn_elementwise(const void*, int, const uint16_t*, const uint8_t*, co
                            int64_t, const TypeInfo&, uint8_t*, hipStream_t);
 int launch_rtn_scale_search(const void*, int, int64_t, int64_t, int, const gq_search_t*, uint16_t*, uint8_t*, uint16_t*,
                             uint8_t*, hipStream_t);
+int group_search(const void*, int, int64_t, int64_t, int, const gq_search_t*, float*, float*, uint16_t*, uint8_t*, uint16_t*,
+                 uint8_t*, hipStream_t);
 int launch_pack(int, const uint8_t*, const uint16_t*, const uint8_t*, const uint16_t*, const uint8_t*, int64_t, int64_t,
                 uint8_t*, hipStream_t);
 int launch_trailing_update(float*, int64_t, const float*, int64_t, const float*, int64_t, int64_t, int64_t, int64_t,
@@ -110,6 +112,12 @@ int gq_scale_search(const float* x, int64_t rows, int64_t ld, int q_type, const 
     if (!x || !d || !s || !dmin || !m) GQ_FAIL(GQ_E_NULL, "gq_scale_search: null pointer");
     return launch_scale_search(x, rows, ld, q_type, p, d, d_stride, s, s_ld, dmin, dmin_stride, m, m_ld,
                                (hipStream_t)stream);
+}
+
+int gq_group_search(const void* x, int x_dtype, int64_t rows, int64_t ld, int q_type, const gq_search_t* p,
+                    float* group_scale, float* group_zero, uint16_t* d, uint8_t* s, uint16_t* dmin, uint8_t* m,
+                    void* stream) {
+    return group_search(x, x_dtype, rows, ld, q_type, p, group_scale, group_zero, d, s, dmin, m, (hipStream_t)stream);
 }
 
 int gq_gptq_quantize(float* W, const float* U, int64_t R, int64_t C, int q_type, int block_size, int static_groups,

@@ -52,6 +52,11 @@ __device__ __forceinline__ float h2f(uint16_t h) {
     return (float)v;
 }
 __device__ __forceinline__ uint16_t f2h(float f) {  // RNE, denormals kept
+    // The empty asm pins `f` as an fp32 value in a VGPR.  Without it the backend folds
+    // fptrunc(fmul/fma f32) into v_fma_mixlo_f16, which rounds the EXACT product once to fp16; the
+    // reference (ATen) rounds to fp32 first and then to fp16 (measured: 1 group in ~4600 of an fp16
+    // weight picked a different scale-search candidate through such a double-rounding tie).
+    asm volatile("" : "+v"(f));
     _Float16 v = (_Float16)f;
     return __builtin_bit_cast(uint16_t, v);
 }

@@ -2,7 +2,7 @@
 //
 // Reference: quant_utils.py:90-145 (outer), :199-274 make_k_quants (Q2/Q4/Q5),
 // :147-197 make_quants (Q3/Q6).  Bit-exact with the reference's CPU path given the
-// same fp32 panel; every quirk is kept on purpose (cited inline).
+// same panel; every quirk is kept on purpose (cited inline).
 //
 // Mapping (CDNA4, wave64).  ATen's CPU inner-dim sum adds a 16/32-element group
 // as EIGHT lane accumulators (element e -> accumulator e%8, in order of e/8) that
@@ -12,8 +12,13 @@
 // running sum whose result lands on lane 7 and is re-broadcast with one
 // ds_swizzle.  One 256-thread workgroup = 4 row-panels (G=32) or 2 (G=16); the
 // per-row amax/6-bit re-quantisation of the group scales goes through 128..256 B
-// of LDS.  HBM traffic is one coalesced read of the fp32 panel (1 KiB per row)
+// of LDS.  HBM traffic is one coalesced read of the panel (1 KiB per row in fp32)
 // and ~20 B of outputs per row; the search itself is ~300 VALU-flop/param.
+//
+// RM (rounding mode) 0: fp32 panel (GPTQ.step).  RM 1 / 2: fp16 / bf16 panel for the RTN of
+// embed / lm_head, where the reference runs make_*quants in the MODEL dtype
+// (quantizer.py:109,195): ATen CPU computes each elementwise op in fp32 and rounds the result
+// to the tensor dtype, reductions accumulate in fp32 and round once -- R() below.
 #include "gq_common.hpp"
 
 namespace gq {
@@ -26,7 +31,7 @@ __device__ __forceinline__ float dpp_f(float old, float src) {
 }
 
 // sum of the 8 lane partials of an 8-lane group, added in lane order 0 -> 7
-// (== gqo_aten_sum's final loop), result valid on EVERY lane of the group.
+// (the ATen order the CPU restatement follows), result valid on EVERY lane of the group.
 __device__ __forceinline__ float group_sum8(float partial) {
     float acc = partial;
 #pragma unroll
@@ -58,27 +63,43 @@ __device__ __forceinline__ float group_max8(float v) {
     return v;
 }
 
+template <int RM>
+__device__ __forceinline__ float R(float v) {
+    if constexpr (RM == 1) {
+        // The empty asm hides "this float is an fpext of a half" from LLVM: otherwise
+        // fptrunc(fdiv(fpext a, fpext b)) is narrowed to an fp16 divide, which gfx950 lowers through
+        // v_rcp_f32 (approximate) -- measured: 1 group in ~4600 picked another candidate.
+        float r = h2f(f2h(v));
+        asm volatile("" : "+v"(r));
+        return r;
+    } else if constexpr (RM == 2) {
+        return bf2f(f2bf(v));
+    } else {
+        return v;
+    }
+}
+
 struct SearchParams {
     float num[24];  // fp32(rmin + rdelta*i + maxq), evaluated in double on the host
     int nstep;
 };
 
 // quant_utils.py:199-274 for one group spread over 8 lanes; NS = G/8 values per lane.
-template <int NS, int BITS>
+template <int NS, int BITS, int RM>
 __device__ __forceinline__ void k_search(const float (&x)[NS], const SearchParams& sp, float& scale_out,
                                          float& zero_out) {
     constexpr float maxq = (float)((1 << BITS) - 1);
     constexpr float G = (float)(NS * 8);
-    const float eps = 1e-9f;
+    const float eps = R<RM>(1e-9f);  // quant_utils.py:69; rounds to 0 in fp16
     float w[NS];
     // :203-205
-    float p = x[0] * x[0];
+    float p = R<RM>(x[0] * x[0]);
 #pragma unroll
-    for (int k = 1; k < NS; ++k) p = p + x[k] * x[k];
-    float sum_x2 = group_sum8(p);
-    float av_x = sqrtf(sum_x2 / G);  // IEEE sqrt (MKL vsSqrt note)
+    for (int k = 1; k < NS; ++k) p = p + R<RM>(x[k] * x[k]);
+    float sum_x2 = R<RM>(group_sum8(p));
+    float av_x = R<RM>(sqrtf(R<RM>(sum_x2 / G)));  // IEEE sqrt (MKL vsSqrt note)
 #pragma unroll
-    for (int k = 0; k < NS; ++k) w[k] = av_x + fabsf(x[k]);
+    for (int k = 0; k < NS; ++k) w[k] = R<RM>(av_x + fabsf(x[k]));
     // :208-211
     float mn = x[0], mx = x[0];
 #pragma unroll
@@ -93,75 +114,77 @@ __device__ __forceinline__ void k_search(const float (&x)[NS], const SearchParam
     const float x_max = mx;
     const bool is_const = (x_max == x_min);
     // :214-215
-    float pw = w[0], px = w[0] * x[0];
+    float pw = w[0], px = R<RM>(w[0] * x[0]);
 #pragma unroll
     for (int k = 1; k < NS; ++k) {
         pw = pw + w[k];
-        px = px + w[k] * x[k];
+        px = px + R<RM>(w[k] * x[k]);
     }
-    const float sum_w = group_sum8(pw);
-    const float sum_x = group_sum8(px);
+    const float sum_w = R<RM>(group_sum8(pw));
+    const float sum_x = R<RM>(group_sum8(px));
     // :218-232
-    float sc = (x_max - x_min) / maxq;
+    float sc = R<RM>(R<RM>(x_max - x_min) / maxq);
     if (is_const) sc = 0.0f;
-    const float isc = 1.0f / (sc < eps ? eps : sc);
-    float pe;
-    {
-        float e[NS];
+    const float isc = R<RM>(1.0f / (sc < eps ? eps : sc));
+    float pe = 0.0f;
 #pragma unroll
-        for (int k = 0; k < NS; ++k) {
-            float q = clampf(rintf((x[k] - x_min) * isc), 0.0f, maxq);
-            if (is_const) q = 0.0f;
-            float diff = (sc * q + x_min) - x[k];
-            e[k] = w[k] * (diff * diff);
-        }
-        pe = e[0];
-#pragma unroll
-        for (int k = 1; k < NS; ++k) pe = pe + e[k];
+    for (int k = 0; k < NS; ++k) {
+        float q = 0.0f;
+        if (!is_const) q = clampf(rintf(R<RM>(R<RM>(x[k] - x_min) * isc)), 0.0f, maxq);
+        float diff = R<RM>(R<RM>(R<RM>(sc * q) + x_min) - x[k]);
+        float e = R<RM>(w[k] * R<RM>(diff * diff));
+        pe = (k == 0) ? e : pe + e;
     }
-    float best_err = group_sum8(pe);
+    float best_err = R<RM>(group_sum8(pe));
     float best_scale = sc;
 
     if (sp.nstep >= 1) {  // :235-237
         for (int i = 0; i <= sp.nstep; ++i) {  // :240
             // :241 scalar/tensor == reciprocal()*scalar; x_min is the aliased best_min (:228,:270)
-            float den = x_max - x_min;
+            float den = R<RM>(x_max - x_min);
             den = den < eps ? eps : den;
-            const float cand_iscale = (1.0f / den) * sp.num[i];
+            const float cand_iscale = R<RM>(R<RM>(1.0f / den) * sp.num[i]);
             float L[NS];
-            float pl, pl2, pxl;
+            float pl = 0.0f, pl2 = 0.0f, pxl = 0.0f;
 #pragma unroll
             for (int k = 0; k < NS; ++k) {
-                float q = clampf(rintf((x[k] - x_min) * cand_iscale), 0.0f, maxq);  // :242
-                if (is_const) q = 0.0f;                                            // :243
+                float q = 0.0f;  // :243 const groups
+                if (!is_const) q = clampf(rintf(R<RM>(R<RM>(x[k] - x_min) * cand_iscale)), 0.0f, maxq);  // :242
                 int qi = (int)q;
                 float q2 = (float)((qi * qi) & 255);  // :246 new_q**2 stays uint8 (wraps for Q5_K)
                 L[k] = q;
-                float tl = w[k] * q, tl2 = w[k] * q2, txl = (w[k] * x[k]) * q;
+                float tl = R<RM>(w[k] * q), tl2 = R<RM>(w[k] * q2), txl = R<RM>(R<RM>(w[k] * x[k]) * q);
                 if (k == 0) {
                     pl = tl; pl2 = tl2; pxl = txl;
                 } else {
                     pl = pl + tl; pl2 = pl2 + tl2; pxl = pxl + txl;
                 }
             }
-            const float sum_l = group_sum8(pl);
-            const float sum_l2 = group_sum8(pl2);
-            const float sum_xl = group_sum8(pxl);
-            const float D = sum_w * sum_l2 - sum_l * sum_l;               // :249
-            float this_scale = (sum_w * sum_xl - sum_x * sum_l) / D;     // :254
-            float this_min = (sum_l2 * sum_x - sum_l * sum_xl) / D;      // :255
-            if (this_min > 0.0f) {                                       // :257-260
-                this_scale = sum_xl / (sum_l2 < eps ? eps : sum_l2);
+            const float sum_l = R<RM>(group_sum8(pl));
+            const float sum_l2 = R<RM>(group_sum8(pl2));
+            const float sum_xl = R<RM>(group_sum8(pxl));
+            const float D = R<RM>(R<RM>(sum_w * sum_l2) - R<RM>(sum_l * sum_l));                           // :249
+            float this_scale = R<RM>(R<RM>(R<RM>(sum_w * sum_xl) - R<RM>(sum_x * sum_l)) / D);             // :254
+            float this_min = R<RM>(R<RM>(R<RM>(sum_l2 * sum_x) - R<RM>(sum_l * sum_xl)) / D);              // :255
+            if (this_min > 0.0f) {                                                                          // :257-260
+                this_scale = R<RM>(sum_xl / (sum_l2 < eps ? eps : sum_l2));
                 this_min = 0.0f;
             }
-            float pc;
+            float pc = 0.0f;
 #pragma unroll
             for (int k = 0; k < NS; ++k) {  // :262-264
-                float diff = (this_scale * L[k] + this_min) - x[k];
-                float e = w[k] * (diff * diff);
+                float diff = R<RM>(R<RM>(R<RM>(this_scale * L[k]) + this_min) - x[k]);
+                float e = R<RM>(w[k] * R<RM>(diff * diff));
                 pc = (k == 0) ? e : pc + e;
             }
-            const float cand_err = group_sum8(pc);
+            const float cand_err = R<RM>(group_sum8(pc));
+#ifdef GQ_DBG_ITER  // kernel A/B probe: report (cand_err, best_err) of one iteration instead of the result
+            if (i == GQ_DBG_ITER) {
+                scale_out = cand_err;
+                zero_out = best_err;
+                return;
+            }
+#endif
             // :250-252 the panel-wide `if not valid.any(): continue` is NOT taken
             // here: it only differs when EVERY group of the [rows,256] panel has
             // D <= 1e-9 in this iteration (|x| <~ 1e-7 everywhere); see DESIGN.md.
@@ -177,7 +200,7 @@ __device__ __forceinline__ void k_search(const float (&x)[NS], const SearchParam
 }
 
 // quant_utils.py:147-197 (absmax branch)
-template <int NS, int BITS>
+template <int NS, int BITS, int RM>
 __device__ __forceinline__ void absmax_search(const float (&x)[NS], float& scale_out, float& zero_out) {
     constexpr float maxq = (float)((1 << BITS) - 1);
     float mn = x[0], mx = x[0];
@@ -195,16 +218,24 @@ __device__ __forceinline__ void absmax_search(const float (&x)[NS], float& scale
         mn = -1.0f;
         mx = 1.0f;
     }
-    scale_out = (mx - mn) / maxq;  // :161
-    zero_out = 0.0f;               // :195
+    scale_out = R<RM>(R<RM>(mx - mn) / maxq);  // :161
+    zero_out = 0.0f;                           // :195
+}
+
+template <int RM>
+__device__ __forceinline__ float load_x(const void* x, int64_t idx) {
+    if constexpr (RM == 0) return reinterpret_cast<const float*>(x)[idx];
+    else if constexpr (RM == 1) return h2f(reinterpret_cast<const uint16_t*>(x)[idx]);
+    else return bf2f(reinterpret_cast<const uint16_t*>(x)[idx]);
 }
 
 // One workgroup = 256 threads = 256/(NG*8) row-panels.  NG = 256/G groups per row.
-template <int GSZ, int BITS, bool KSEARCH, bool SIGNED, int SMQ>
+template <int GSZ, int BITS, bool KSEARCH, bool SIGNED, int SMQ, int RM>
 __global__ __launch_bounds__(256) void scale_search_kernel(
-    const float* __restrict__ x, int64_t rows, int64_t ld, SearchParams sp,
+    const void* __restrict__ x, int64_t rows, int64_t ld, SearchParams sp,
     uint16_t* __restrict__ d, int64_t d_stride, uint8_t* __restrict__ s, int64_t s_ld,
-    uint16_t* __restrict__ dmin, int64_t dmin_stride, uint8_t* __restrict__ m, int64_t m_ld) {
+    uint16_t* __restrict__ dmin, int64_t dmin_stride, uint8_t* __restrict__ m, int64_t m_ld,
+    float* __restrict__ gs_out, float* __restrict__ gz_out) {
     constexpr int NS = GSZ / 8;
     constexpr int NG = 256 / GSZ;
     constexpr int LPR = NG * 8;         // lanes per row
@@ -218,17 +249,21 @@ __global__ __launch_bounds__(256) void scale_search_kernel(
     const int l8 = tid & 7;
     const int64_t row = (int64_t)blockIdx.x * RPW + row_l;
     const bool live = row < rows;
-    const float* xr = x + (live ? row : 0) * ld + g * GSZ + l8;
+    const int64_t base = (live ? row : 0) * ld + g * GSZ + l8;
     float xv[NS];
 #pragma unroll
-    for (int k = 0; k < NS; ++k) xv[k] = xr[k * 8];
+    for (int k = 0; k < NS; ++k) xv[k] = load_x<RM>(x, base + k * 8);
 
     float gscale, gzero;
-    if constexpr (KSEARCH) k_search<NS, BITS>(xv, sp, gscale, gzero);
-    else absmax_search<NS, BITS>(xv, gscale, gzero);
+    if constexpr (KSEARCH) k_search<NS, BITS, RM>(xv, sp, gscale, gzero);
+    else absmax_search<NS, BITS, RM>(xv, gscale, gzero);
     if (l8 == 0) {
         sh_scale[row_l][g] = gscale;
         sh_zero[row_l][g] = gzero;
+        if (gs_out && live) {  // make_k_quants / make_quants outputs (gq_group_search)
+            gs_out[row * NG + g] = gscale;
+            gz_out[row * NG + g] = gzero;
+        }
     }
     __syncthreads();
     if (l8 == 0 && live) {
@@ -241,22 +276,23 @@ __global__ __launch_bounds__(256) void scale_search_kernel(
             max_zero = b > max_zero ? b : max_zero;
         }
         constexpr float smq = (float)SMQ;
-        float inv_scale = max_scale > 0.0f ? (1.0f / max_scale) * smq : 0.0f;  // :128
-        float inv_zero = max_zero > 0.0f ? (1.0f / max_zero) * smq : 0.0f;     // :129
-        float a = clampf(rintf(inv_scale * gscale), 0.0f, smq);                // :132-143
-        float b = clampf(rintf(inv_zero * gzero), 0.0f, smq);
+        float inv_scale = max_scale > 0.0f ? R<RM>(R<RM>(1.0f / max_scale) * smq) : 0.0f;  // :128
+        float inv_zero = max_zero > 0.0f ? R<RM>(R<RM>(1.0f / max_zero) * smq) : 0.0f;     // :129
+        float a = clampf(rintf(R<RM>(inv_scale * gscale)), 0.0f, smq);                     // :132-143
+        float b = clampf(rintf(R<RM>(inv_zero * gzero)), 0.0f, smq);
         s[row * s_ld + g] = SIGNED ? (uint8_t)(int8_t)a : (uint8_t)a;
         m[row * m_ld + g] = SIGNED ? (uint8_t)(int8_t)b : (uint8_t)b;
         if (g == 0) {
-            d[row * d_stride] = f2h(max_scale / smq);    // :124
-            dmin[row * dmin_stride] = f2h(max_zero / smq);  // :125
+            d[row * d_stride] = f2h(R<RM>(max_scale / smq));       // :124 (+ .to(float16))
+            dmin[row * dmin_stride] = f2h(R<RM>(max_zero / smq));  // :125
         }
     }
 }
 
-int launch_scale_search(const float* x, int64_t rows, int64_t ld, int q_type, const gq_search_t* p,
-                        uint16_t* d, int64_t d_stride, uint8_t* s, int64_t s_ld, uint16_t* dmin,
-                        int64_t dmin_stride, uint8_t* m, int64_t m_ld, hipStream_t st) {
+template <int RM>
+static int launch_ss(const void* x, int64_t rows, int64_t ld, int q_type, const gq_search_t* p, uint16_t* d,
+                     int64_t d_stride, uint8_t* s, int64_t s_ld, uint16_t* dmin, int64_t dmin_stride, uint8_t* m,
+                     int64_t m_ld, hipStream_t st, float* gs_out = nullptr, float* gz_out = nullptr) {
     TypeInfo ti;
     if (!type_info(q_type, ti)) GQ_FAIL(GQ_E_BAD_TYPE, "gq_scale_search: unknown q_type %d", q_type);
     if (rows <= 0 || ld < 256) GQ_FAIL(GQ_E_BAD_SHAPE, "gq_scale_search: rows=%ld ld=%ld", (long)rows, (long)ld);
@@ -269,9 +305,9 @@ int launch_scale_search(const float* x, int64_t rows, int64_t ld, int q_type, co
     const int rpw = ti.group == 32 ? 4 : 2;
     dim3 grid((unsigned)((rows + rpw - 1) / rpw)), block(256);
     ProfScope ps(PT_SCALE_SEARCH, st);
-#define GQ_SS(G, B, K, S, Q)                                                                                \
-    hipLaunchKernelGGL((scale_search_kernel<G, B, K, S, Q>), grid, block, 0, st, x, rows, ld, sp, d, d_stride, \
-                       s, s_ld, dmin, dmin_stride, m, m_ld)
+#define GQ_SS(G, B, K, S, Q)                                                                                     \
+    hipLaunchKernelGGL((scale_search_kernel<G, B, K, S, Q, RM>), grid, block, 0, st, x, rows, ld, sp, d, d_stride, \
+                       s, s_ld, dmin, dmin_stride, m, m_ld, gs_out, gz_out)
     switch (q_type) {
     case GQ_Q2_K: GQ_SS(16, 2, true, false, 15); break;
     case GQ_Q3_K: GQ_SS(16, 3, false, true, 31); break;
@@ -284,14 +320,47 @@ int launch_scale_search(const float* x, int64_t rows, int64_t ld, int q_type, co
     return GQ_OK;
 }
 
-// RTN scale search in the model dtype (quantizer.py:109,195 hand module.weight to
-// get_scale_and_zero un-cast, so every op of make_*quants rounds to fp16/bf16).
-int launch_rtn_scale_search(const void* W, int w_dtype, int64_t R, int64_t C, int q_type, const gq_search_t* p,
+int launch_scale_search(const float* x, int64_t rows, int64_t ld, int q_type, const gq_search_t* p,
+                        uint16_t* d, int64_t d_stride, uint8_t* s, int64_t s_ld, uint16_t* dmin,
+                        int64_t dmin_stride, uint8_t* m, int64_t m_ld, hipStream_t st) {
+    return launch_ss<0>(x, rows, ld, q_type, p, d, d_stride, s, s_ld, dmin, dmin_stride, m, m_ld, st);
+}
+
+// make_k_quants / make_quants outputs (per-group fp32 scale and zero) of one [rows,256] panel in
+// x_dtype, next to the super-group outputs: the reference functions quant_utils.py:147-274 themselves.
+int group_search(const void* x, int x_dtype, int64_t rows, int64_t ld, int q_type, const gq_search_t* p, float* gs,
+                 float* gz, uint16_t* d, uint8_t* s, uint16_t* dmin, uint8_t* m, hipStream_t st) {
+    TypeInfo ti;
+    if (!type_info(q_type, ti)) GQ_FAIL(GQ_E_BAD_TYPE, "gq_group_search: unknown q_type %d", q_type);
+    if (!x || !gs || !gz || !d || !s || !dmin || !m) GQ_FAIL(GQ_E_NULL, "gq_group_search: null pointer");
+    const int ng = 256 / ti.group;
+    switch (x_dtype) {
+    case GQ_F32: return launch_ss<0>(x, rows, ld, q_type, p, d, 1, s, ng, dmin, 1, m, ng, st, gs, gz);
+    case GQ_F16: return launch_ss<1>(x, rows, ld, q_type, p, d, 1, s, ng, dmin, 1, m, ng, st, gs, gz);
+    case GQ_BF16: return launch_ss<2>(x, rows, ld, q_type, p, d, 1, s, ng, dmin, 1, m, ng, st, gs, gz);
+    default: GQ_FAIL(GQ_E_BAD_TYPE, "gq_group_search: unknown x_dtype %d", x_dtype);
+    }
+}
+
+// RTN scale search in the model dtype (quantizer.py:300-310 over every super-group of the
+// unmodified fp16 / bf16 weight).
+int launch_rtn_scale_search(const void* W, int w_dtype, int64_t R_, int64_t C, int q_type, const gq_search_t* p,
                             uint16_t* d, uint8_t* s, uint16_t* dmin, uint8_t* m, hipStream_t st) {
-    (void)W; (void)R; (void)C; (void)q_type; (void)p; (void)d; (void)s; (void)dmin; (void)m; (void)st;
-    GQ_FAIL(GQ_E_UNSUPPORTED,
-            "gq_rtn_quantize: w_dtype %d (reduced-precision make_*quants emulation) is not implemented; "
-            "pass the weight as fp32 (reference behaviour with --dtype float32)", w_dtype);
+    TypeInfo ti;
+    if (!type_info(q_type, ti)) GQ_FAIL(GQ_E_BAD_TYPE, "gq_rtn_quantize: unknown q_type %d", q_type);
+    if (w_dtype != GQ_F16 && w_dtype != GQ_BF16) GQ_FAIL(GQ_E_BAD_TYPE, "gq_rtn_quantize: unknown w_dtype %d", w_dtype);
+    const int64_t ng = C / ti.group, nsg = C / 256;
+    const int gps = 256 / ti.group;
+    const uint16_t* Wh = reinterpret_cast<const uint16_t*>(W);
+    for (int64_t c = 0; c < C; c += 256) {
+        int rc = w_dtype == GQ_F16
+                     ? launch_ss<1>(Wh + c, R_, C, q_type, p, d + c / 256, nsg, s + (c / 256) * gps, ng, dmin + c / 256,
+                                    nsg, m + (c / 256) * gps, ng, st)
+                     : launch_ss<2>(Wh + c, R_, C, q_type, p, d + c / 256, nsg, s + (c / 256) * gps, ng, dmin + c / 256,
+                                    nsg, m + (c / 256) * gps, ng, st);
+        if (rc) return rc;
+    }
+    return GQ_OK;
 }
 
 }  // namespace gq

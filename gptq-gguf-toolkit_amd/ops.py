@@ -203,3 +203,24 @@ def trailing_update(Cm: torch.Tensor, A: torch.Tensor, B: torch.Tensor):
     check(lib().gq_trailing_update(_ptr(Cm), Cm.stride(0), _ptr(A), A.stride(0), _ptr(B), B.stride(0), M, N, K,
                                    _stream(Cm)), "gq_trailing_update")
     return Cm
+
+
+def group_search(x: torch.Tensor, q_type: int, rmin=-1.0, rdelta=0.1, nstep=20):
+    """make_k_quants / make_quants on a [rows,256] panel (fp32, or fp16/bf16 with per-op rounding).
+    Returns (group_scale f32[rows,ng], group_zero f32[rows,ng], d, s, dmin, m)."""
+    _need_cuda(x)
+    assert x.dim() == 2 and x.shape[1] == 256 and x.stride(1) == 1 and x.dtype in _DT
+    rows = x.shape[0]
+    ng = 256 // type_info(q_type)["group"]
+    dev = x.device
+    gs = torch.empty(rows, ng, dtype=torch.float32, device=dev)
+    gz = torch.empty(rows, ng, dtype=torch.float32, device=dev)
+    d = torch.empty(rows, dtype=torch.float16, device=dev)
+    dmin = torch.empty(rows, dtype=torch.float16, device=dev)
+    s = torch.empty(rows, ng, dtype=torch.uint8, device=dev)
+    m = torch.empty(rows, ng, dtype=torch.uint8, device=dev)
+    check(lib().gq_group_search(_ptr(x), _DT[x.dtype], rows, x.stride(0), int(q_type), _search(rmin, rdelta, nstep),
+                                _ptr(gs), _ptr(gz), _ptr(d), _ptr(s), _ptr(dmin), _ptr(m), _stream(x)),
+          "gq_group_search")
+    t = _idt(q_type)
+    return gs, gz, d, s.view(t), dmin, m.view(t)

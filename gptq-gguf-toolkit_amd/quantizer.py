@@ -183,13 +183,9 @@ class Quantizer:
     def _quant_non_block_module(self, w: torch.Tensor, q_type: GGMLQuantizationType):
         """RTN for embed / lm_head (reference quantizer.py:278-330)."""
         kw = self.quantizer_kwargs
-        if w.dtype != torch.float32:
-            if not self.non_block_fp32:
-                raise NotImplementedError(
-                    f"embed/lm_head RTN on {w.dtype} weights: the reference runs make_*quants in the model dtype "
-                    "(quantizer.py:109,195); that emulation is not implemented yet. Pass non_block_fp32=True "
-                    "(--non_block_fp32) to run the scale search in fp32 instead (results differ from the "
-                    "reference for these two tensors), or load the model with --dtype float32.")
+        # fp16 / bf16 weights: the reference runs make_*quants in the model dtype (quantizer.py:109,195);
+        # gq_rtn_quantize reproduces that per-op rounding.  non_block_fp32 opts into an fp32 search instead.
+        if w.dtype != torch.float32 and self.non_block_fp32:
             w = w.float()
         return _ops.rtn_quantize(w.contiguous(), int(q_type), kw.get("rmin", -1.0), kw.get("rdelta", 0.1),
                                  kw.get("nstep", 20))

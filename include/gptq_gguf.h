@@ -117,6 +117,14 @@ int gq_scale_search(const float* x, int64_t rows, int64_t ld, int q_type, const 
                     uint16_t* d, int64_t d_stride, uint8_t* s, int64_t s_ld,
                     uint16_t* dmin, int64_t dmin_stride, uint8_t* m, int64_t m_ld, void* stream);
 
+/* The same panel search, additionally returning what make_k_quants / make_quants return
+   (quant_utils.py:147-197, :199-274): the per-group fp32 scale and zero, [rows, 256/G] each.
+   x may be fp32, or fp16/bf16 (then every op rounds to that dtype like the reference's RTN of
+   embed/lm_head, quantizer.py:109,195).  d/dmin are [rows], s/m [rows, 256/G], all contiguous. */
+int gq_group_search(const void* x, int x_dtype, int64_t rows, int64_t ld, int q_type, const gq_search_t* p_host,
+                    float* group_scale, float* group_zero, uint16_t* d, uint8_t* s, uint16_t* dmin, uint8_t* m,
+                    void* stream);
+
 /* replaces gptq.py:145-276 (the rank-0 body of GPTQ.step): blocked column-wise
    quantize + error feedback + trailing update.  W (fp32 working copy) becomes the
    dequantized matrix; U is chol_upper(H^-1).  block_size <= 0 means C.

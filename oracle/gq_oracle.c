@@ -113,6 +113,16 @@ float gqo_aten_sum(const float* v, int n) {
     return s;
 }
 
+/* Reduced-precision emulation (reference quantizer.py:109,195: embed/lm_head RTN runs make_*quants in
+   the MODEL dtype).  ATen CPU computes every fp16/bf16 elementwise op in fp32 and rounds the result to
+   the tensor dtype; reductions accumulate in fp32 and round once.  rmode: 0 fp32, 1 fp16, 2 bf16. */
+static inline float rnd(float v, int rmode) {
+    if (rmode == 1) return gqo_f16_to_f32(gqo_f32_to_f16(v));
+    if (rmode == 2) return gqo_bf16_to_f32(gqo_f32_to_bf16(v));
+    return v;
+}
+#define R(v) rnd((v), rmode)
+
 static inline float clampf(float v, float lo, float hi) {
     /* torch.clamp(min,max) = min(max(v, lo), hi); NaN propagates */
     if (v != v) return v;
@@ -137,10 +147,10 @@ typedef struct {
     int valid;
 } kq_state_t;
 
-void gqo_make_k_quants(const float* x, int64_t n_groups, int G, int bits,
-                       double rmin, double rdelta, int nstep, float* scale_out, float* zero_out) {
+static void make_k_quants_r(const float* x, int64_t n_groups, int G, int bits, double rmin, double rdelta, int nstep,
+                            int rmode, float* scale_out, float* zero_out) {
     const float maxq = (float)((1 << bits) - 1);
-    const float eps = 1e-9f; /* quant_utils.py:69 eps: float = 1e-9 -> fp32 scalar */
+    const float eps = R(1e-9f); /* quant_utils.py:69; rounds to 0 in fp16 */
     kq_state_t* st = (kq_state_t*)malloc(sizeof(kq_state_t) * (size_t)n_groups);
     float tmp[GQO_MAXG];
 
@@ -149,10 +159,10 @@ void gqo_make_k_quants(const float* x, int64_t n_groups, int G, int bits,
         const float* xg = x + g * G;
         kq_state_t* s = &st[g];
         /* :203-205 */
-        for (int j = 0; j < G; ++j) tmp[j] = xg[j] * xg[j];
-        float sum_x2 = gqo_aten_sum(tmp, G);
-        float av_x = sqrtf(sum_x2 / (float)G);
-        for (int j = 0; j < G; ++j) s->w[j] = av_x + fabsf(xg[j]);
+        for (int j = 0; j < G; ++j) tmp[j] = R(xg[j] * xg[j]);
+        float sum_x2 = R(gqo_aten_sum(tmp, G));
+        float av_x = R(sqrtf(R(sum_x2 / (float)G)));
+        for (int j = 0; j < G; ++j) s->w[j] = R(av_x + fabsf(xg[j]));
         /* :208-211 */
         float mn = xg[0], mx = xg[0];
         for (int j = 1; j < G; ++j) {
@@ -164,28 +174,30 @@ void gqo_make_k_quants(const float* x, int64_t n_groups, int G, int bits,
         s->x_max = mx;
         s->is_const = (mx == mn);
         /* :214-215 */
-        s->sum_w = gqo_aten_sum(s->w, G);
-        for (int j = 0; j < G; ++j) tmp[j] = s->w[j] * xg[j];
-        s->sum_x = gqo_aten_sum(tmp, G);
+        s->sum_w = R(gqo_aten_sum(s->w, G));
+        for (int j = 0; j < G; ++j) tmp[j] = R(s->w[j] * xg[j]);
+        s->sum_x = R(gqo_aten_sum(tmp, G));
         /* :218-220 */
-        float sc = (mx - mn) / maxq;
+        float sc = R(R(mx - mn) / maxq);
         if (s->is_const) sc = 0.0f;
-        float isc = 1.0f / (sc < eps ? eps : sc);
+        float isc = R(1.0f / (sc < eps ? eps : sc));
         /* :223-225, :228-232 */
         for (int j = 0; j < G; ++j) {
-            float q = clampf(rintf((xg[j] - mn) * isc), 0.0f, maxq);
-            q = (float)(uint8_t)q; /* .to(torch.uint8) */
-            if (s->is_const) q = 0.0f;
-            float diff = (sc * q + mn) - xg[j];
-            tmp[j] = s->w[j] * (diff * diff);
+            float q = 0.0f;
+            if (!s->is_const) {
+                q = clampf(rintf(R(R(xg[j] - mn) * isc)), 0.0f, maxq);
+                q = (float)(uint8_t)q; /* .to(torch.uint8) */
+            }
+            float diff = R(R(R(sc * q) + mn) - xg[j]);
+            tmp[j] = R(s->w[j] * R(diff * diff));
         }
         s->best_scale = sc;
-        s->best_err = gqo_aten_sum(tmp, G);
+        s->best_err = R(gqo_aten_sum(tmp, G));
     }
 
     if (nstep >= 1) { /* :235-237 */
         for (int i = 0; i <= nstep; ++i) { /* :240 */
-            /* python double arithmetic, rounded once to fp32 when multiplied */
+            /* python double arithmetic, rounded once to fp32 when multiplied (opmath scalar) */
             const float num = (float)(rmin + rdelta * (double)i + (double)maxq);
             int any_valid = 0;
 #pragma omp parallel for private(tmp) reduction(| : any_valid) schedule(static)
@@ -194,39 +206,41 @@ void gqo_make_k_quants(const float* x, int64_t n_groups, int G, int bits,
                 kq_state_t* s = &st[g];
                 /* :241  scalar / tensor == tensor.reciprocal() * scalar.
                    x_min here is the ALIASED best_min (:228, :270). */
-                float den = s->x_max - s->x_min;
+                float den = R(s->x_max - s->x_min);
                 den = den < eps ? eps : den;
-                float cand_iscale = (1.0f / den) * num;
+                float cand_iscale = R(R(1.0f / den) * num);
                 float t_l[GQO_MAXG], t_l2[GQO_MAXG], t_xl[GQO_MAXG];
                 for (int j = 0; j < G; ++j) {
-                    float q = clampf(rintf((xg[j] - s->x_min) * cand_iscale), 0.0f, maxq);
-                    uint8_t qi = (uint8_t)q; /* :242 */
-                    if (s->is_const) qi = 0;  /* :243 */
+                    uint8_t qi = 0;
+                    if (!s->is_const) { /* :243 */
+                        float q = clampf(rintf(R(R(xg[j] - s->x_min) * cand_iscale)), 0.0f, maxq);
+                        qi = (uint8_t)q; /* :242 */
+                    }
                     uint8_t q2 = (uint8_t)(qi * qi); /* :246 new_q**2 stays uint8 (wraps) */
                     float qf = (float)qi;
                     s->L[j] = qf;
-                    t_l[j] = s->w[j] * qf;                 /* :245 */
-                    t_l2[j] = s->w[j] * (float)q2;         /* :246 */
-                    t_xl[j] = (s->w[j] * xg[j]) * qf;      /* :247 */
+                    t_l[j] = R(s->w[j] * qf);                 /* :245 */
+                    t_l2[j] = R(s->w[j] * (float)q2);         /* :246 */
+                    t_xl[j] = R(R(s->w[j] * xg[j]) * qf);     /* :247 */
                 }
-                float sum_l = gqo_aten_sum(t_l, G);
-                float sum_l2 = gqo_aten_sum(t_l2, G);
-                float sum_xl = gqo_aten_sum(t_xl, G);
-                float D = s->sum_w * sum_l2 - sum_l * sum_l; /* :249 */
-                s->valid = D > eps;                          /* :250 */
+                float sum_l = R(gqo_aten_sum(t_l, G));
+                float sum_l2 = R(gqo_aten_sum(t_l2, G));
+                float sum_xl = R(gqo_aten_sum(t_xl, G));
+                float D = R(R(s->sum_w * sum_l2) - R(sum_l * sum_l)); /* :249 */
+                s->valid = D > eps;                                    /* :250 */
                 any_valid |= s->valid;
-                float this_scale = (s->sum_w * sum_xl - s->sum_x * sum_l) / D; /* :254 */
-                float this_min = (sum_l2 * s->sum_x - sum_l * sum_xl) / D;     /* :255 */
+                float this_scale = R(R(R(s->sum_w * sum_xl) - R(s->sum_x * sum_l)) / D); /* :254 */
+                float this_min = R(R(R(sum_l2 * s->sum_x) - R(sum_l * sum_xl)) / D);     /* :255 */
                 if (this_min > 0.0f) { /* :257-260 */
                     float c = sum_l2 < eps ? eps : sum_l2;
-                    this_scale = sum_xl / c;
+                    this_scale = R(sum_xl / c);
                     this_min = 0.0f;
                 }
                 for (int j = 0; j < G; ++j) { /* :262-264 */
-                    float diff = (this_scale * s->L[j] + this_min) - xg[j];
-                    tmp[j] = s->w[j] * (diff * diff);
+                    float diff = R(R(R(this_scale * s->L[j]) + this_min) - xg[j]);
+                    tmp[j] = R(s->w[j] * R(diff * diff));
                 }
-                s->cand_err = gqo_aten_sum(tmp, G);
+                s->cand_err = R(gqo_aten_sum(tmp, G));
                 s->this_scale = this_scale;
                 s->this_min = this_min;
             }
@@ -249,9 +263,14 @@ void gqo_make_k_quants(const float* x, int64_t n_groups, int G, int bits,
     free(st);
 }
 
+void gqo_make_k_quants(const float* x, int64_t n_groups, int G, int bits,
+                       double rmin, double rdelta, int nstep, float* scale_out, float* zero_out) {
+    make_k_quants_r(x, n_groups, G, bits, rmin, rdelta, nstep, 0, scale_out, zero_out);
+}
+
 /* ---------------------------------------------------------- make_quants */
 
-void gqo_make_quants(const float* x, int64_t n_groups, int G, int bits, float* scale, float* zero) {
+static void make_quants_r(const float* x, int64_t n_groups, int G, int bits, int rmode, float* scale, float* zero) {
     const float maxq = (float)((1 << bits) - 1); /* quant_utils.py:74 */
 #pragma omp parallel for schedule(static)
     for (int64_t g = 0; g < n_groups; ++g) {
@@ -268,15 +287,19 @@ void gqo_make_quants(const float* x, int64_t n_groups, int G, int bits, float* s
             mn = -1.0f;
             mx = 1.0f;
         }
-        scale[g] = (mx - mn) / maxq; /* :161 */
-        zero[g] = 0.0f;              /* :195 */
+        scale[g] = R(R(mx - mn) / maxq); /* :161 */
+        zero[g] = 0.0f;                  /* :195 */
     }
+}
+
+void gqo_make_quants(const float* x, int64_t n_groups, int G, int bits, float* scale, float* zero) {
+    make_quants_r(x, n_groups, G, bits, 0, scale, zero);
 }
 
 /* --------------------------------------------------------- scale search */
 
 static void finish_super(const float* gscale, const float* gzero, int ng, int scale_maxq,
-                         uint16_t* d, uint8_t* s, uint16_t* dmin, uint8_t* m, int is_signed) {
+                         uint16_t* d, uint8_t* s, uint16_t* dmin, uint8_t* m, int is_signed, int rmode) {
     /* quant_utils.py:121-143 for one row */
     float max_scale = gscale[0], max_zero = gzero[0];
     for (int j = 1; j < ng; ++j) {
@@ -284,14 +307,14 @@ static void finish_super(const float* gscale, const float* gzero, int ng, int sc
         max_zero = gzero[j] > max_zero ? gzero[j] : max_zero;
     }
     const float smq = (float)scale_maxq;
-    *d = gqo_f32_to_f16(max_scale / smq);   /* :124 true divide */
-    *dmin = gqo_f32_to_f16(max_zero / smq); /* :125 */
+    *d = gqo_f32_to_f16(R(max_scale / smq));   /* :124 true divide, then .to(float16) */
+    *dmin = gqo_f32_to_f16(R(max_zero / smq)); /* :125 */
     /* :128-129  int / tensor == tensor.reciprocal() * int */
-    float inv_scale = max_scale > 0.0f ? (1.0f / max_scale) * smq : 0.0f;
-    float inv_zero = max_zero > 0.0f ? (1.0f / max_zero) * smq : 0.0f;
+    float inv_scale = max_scale > 0.0f ? R(R(1.0f / max_scale) * smq) : 0.0f;
+    float inv_zero = max_zero > 0.0f ? R(R(1.0f / max_zero) * smq) : 0.0f;
     for (int j = 0; j < ng; ++j) { /* :132-143 */
-        float a = clampf(rintf(inv_scale * gscale[j]), 0.0f, smq);
-        float b = clampf(rintf(inv_zero * gzero[j]), 0.0f, smq);
+        float a = clampf(rintf(R(inv_scale * gscale[j])), 0.0f, smq);
+        float b = clampf(rintf(R(inv_zero * gzero[j])), 0.0f, smq);
         if (is_signed) {
             s[j] = (uint8_t)(int8_t)a;
             m[j] = (uint8_t)(int8_t)b;
@@ -302,10 +325,10 @@ static void finish_super(const float* gscale, const float* gzero, int ng, int sc
     }
 }
 
-void gqo_scale_search(const float* x, int64_t rows, int64_t ld, int q_type,
-                      double rmin, double rdelta, int nstep,
-                      uint16_t* d, int64_t d_stride, uint8_t* s, int64_t s_ld,
-                      uint16_t* dmin, int64_t dmin_stride, uint8_t* m, int64_t m_ld) {
+static void scale_search_r(const float* x, int64_t rows, int64_t ld, int q_type,
+                           double rmin, double rdelta, int nstep, int rmode,
+                           uint16_t* d, int64_t d_stride, uint8_t* s, int64_t s_ld,
+                           uint16_t* dmin, int64_t dmin_stride, uint8_t* m, int64_t m_ld) {
     gqo_type_info_t ti;
     if (gqo_type_info(q_type, &ti)) return;
     const int G = ti.group, ng = 256 / G;
@@ -315,15 +338,22 @@ void gqo_scale_search(const float* x, int64_t rows, int64_t ld, int q_type,
     float* gz = (float*)malloc(sizeof(float) * (size_t)rows * ng);
     for (int64_t r = 0; r < rows; ++r) memcpy(xc + r * 256, x + r * ld, 256 * sizeof(float));
     if (ti.k_search)
-        gqo_make_k_quants(xc, rows * ng, G, ti.bits, rmin, rdelta, nstep, gs, gz);
+        make_k_quants_r(xc, rows * ng, G, ti.bits, rmin, rdelta, nstep, rmode, gs, gz);
     else
-        gqo_make_quants(xc, rows * ng, G, ti.bits, gs, gz);
+        make_quants_r(xc, rows * ng, G, ti.bits, rmode, gs, gz);
     for (int64_t r = 0; r < rows; ++r)
         finish_super(gs + r * ng, gz + r * ng, ng, ti.scale_maxq, d + r * d_stride, s + r * s_ld,
-                     dmin + r * dmin_stride, m + r * m_ld, ti.is_signed);
+                     dmin + r * dmin_stride, m + r * m_ld, ti.is_signed, rmode);
     free(xc);
     free(gs);
     free(gz);
+}
+
+void gqo_scale_search(const float* x, int64_t rows, int64_t ld, int q_type,
+                      double rmin, double rdelta, int nstep,
+                      uint16_t* d, int64_t d_stride, uint8_t* s, int64_t s_ld,
+                      uint16_t* dmin, int64_t dmin_stride, uint8_t* m, int64_t m_ld) {
+    scale_search_r(x, rows, ld, q_type, rmin, rdelta, nstep, 0, d, d_stride, s, s_ld, dmin, dmin_stride, m, m_ld);
 }
 
 /* --------------------------------------------------- quantize/dequantize */
@@ -442,6 +472,28 @@ void gqo_rtn_quantize(const float* W, int64_t R, int64_t C, int q_type,
             float q = gqo_quantize1(W[r * C + c], d[r * nsg + c / 256],
                                     (int)ival(s[r * ng + c / G], ti.is_signed), dmin[r * nsg + c / 256],
                                     (int)ival(m[r * ng + c / G], ti.is_signed), ti.qmin, ti.qmax);
+            qweight[r * C + c] = ti.is_signed ? (uint8_t)(int8_t)q : (uint8_t)q;
+        }
+}
+
+void gqo_rtn_quantize_lp(const float* W, int rmode, int64_t R_, int64_t C, int q_type,
+                         double rmin, double rdelta, int nstep,
+                         uint8_t* qweight, uint16_t* d, uint8_t* s, uint16_t* dmin, uint8_t* m) {
+    /* quantizer.py:278-330 with fp16 (rmode 1) / bf16 (rmode 2) weights: W holds the weight VALUES widened
+       to fp32; make_*quants and the super-group step run in the model dtype, the final quantize() in fp32. */
+    gqo_type_info_t ti;
+    if (gqo_type_info(q_type, &ti)) return;
+    const int G = ti.group, gps = 256 / G;
+    const int64_t ng = C / G, nsg = C / 256;
+    for (int64_t c = 0; c < C; c += 256)
+        scale_search_r(W + c, R_, C, q_type, rmin, rdelta, nstep, rmode, d + c / 256, nsg, s + (c / 256) * gps, ng,
+                       dmin + c / 256, nsg, m + (c / 256) * gps, ng);
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < R_; ++r)
+        for (int64_t c = 0; c < C; ++c) {
+            float q = gqo_quantize1(W[r * C + c], d[r * nsg + c / 256], (int)ival(s[r * ng + c / G], ti.is_signed),
+                                    dmin[r * nsg + c / 256], (int)ival(m[r * ng + c / G], ti.is_signed), ti.qmin,
+                                    ti.qmax);
             qweight[r * C + c] = ti.is_signed ? (uint8_t)(int8_t)q : (uint8_t)q;
         }
 }
@@ -667,4 +719,11 @@ int gqo_h_prepare(float* H, float* W, int64_t R, int64_t C, float rel_damp, floa
     free(A);
     free(Li);
     return bad;
+}
+
+/* make_k_quants / make_quants in fp16 (rmode 1) / bf16 (rmode 2): exposed for tests */
+void gqo_make_quants_lp(const float* x, int64_t n_groups, int G, int bits, int k_search, int rmode,
+                        double rmin, double rdelta, int nstep, float* scale, float* zero) {
+    if (k_search) make_k_quants_r(x, n_groups, G, bits, rmin, rdelta, nstep, rmode, scale, zero);
+    else make_quants_r(x, n_groups, G, bits, rmode, scale, zero);
 }

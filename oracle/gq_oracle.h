@@ -86,6 +86,13 @@ void gqo_rtn_quantize(const float* W, int64_t R, int64_t C, int q_type,
                       double rmin, double rdelta, int nstep,
                       uint8_t* qweight, uint16_t* d, uint8_t* s, uint16_t* dmin, uint8_t* m);
 
+/* the same with the weight held in fp16 (rmode 1) or bf16 (rmode 2) -- the reference hands module.weight
+   un-cast to get_scale_and_zero (quantizer.py:109,195), so make_*quants run in the model dtype.  W carries
+   the weight values widened to fp32. */
+void gqo_rtn_quantize_lp(const float* W, int rmode, int64_t R, int64_t C, int q_type,
+                         double rmin, double rdelta, int nstep,
+                         uint8_t* qweight, uint16_t* d, uint8_t* s, uint16_t* dmin, uint8_t* m);
+
 /* reference quant_utils.py:277-310 dequantize_linear_weight -> fp32 [R,C] */
 void gqo_dequantize(int q_type, const uint8_t* qweight, const uint16_t* d, const uint8_t* s,
                     const uint16_t* dmin, const uint8_t* m, int64_t R, int64_t C, float* out);

@@ -57,6 +57,8 @@ def lib():
         L.gqo_gptq_step.restype = None
         L.gqo_rtn_quantize.argtypes = [vp, i64, i64, ci, cd, cd, ci, vp, vp, vp, vp, vp]
         L.gqo_rtn_quantize.restype = None
+        L.gqo_rtn_quantize_lp.argtypes = [vp, ci, i64, i64, ci, cd, cd, ci, vp, vp, vp, vp, vp]
+        L.gqo_rtn_quantize_lp.restype = None
         L.gqo_dequantize.argtypes = [ci, vp, vp, vp, vp, vp, i64, i64, vp]
         L.gqo_dequantize.restype = None
         L.gqo_pack.argtypes = [ci, vp, vp, vp, vp, vp, i64, i64, vp]
@@ -144,6 +146,16 @@ def rtn_quantize(W, q_type, rmin=-1.0, rdelta=0.1, nstep=20):
     return q.view(t), d, s.view(t), dmin, m.view(t)
 
 
+def rtn_quantize_lp(W, rmode, q_type, rmin=-1.0, rdelta=0.1, nstep=20):
+    """RTN with make_*quants emulated in fp16 (rmode=1) / bf16 (rmode=2); W = weight values as fp32."""
+    W = np.ascontiguousarray(W, np.float32)
+    R, C = W.shape
+    q, d, s, dmin, m = _alloc_outs(R, C, q_type)
+    lib().gqo_rtn_quantize_lp(_p(W), rmode, R, C, q_type, rmin, rdelta, nstep, _p(q), _p(d), _p(s), _p(dmin), _p(m))
+    t = _idt(q_type)
+    return q.view(t), d, s.view(t), dmin, m.view(t)
+
+
 def _as_u8(a):
     return np.ascontiguousarray(a).view(np.uint8)
 
@@ -186,3 +198,19 @@ def h_prepare(H, W, rel_damp=0.01):
     U = np.empty((C, C), np.float32)
     bad = lib().gqo_h_prepare(_p(H), _p(W), R, C, rel_damp, _p(U))
     return U, H, W, bool(bad)
+
+
+def make_quants_lp(x, q_type, rmode, rmin=-1.0, rdelta=0.1, nstep=20):
+    """make_k_quants / make_quants on x[n,G] with fp16 (rmode=1) / bf16 (rmode=2) / fp32 (0) per-op rounding."""
+    ti = type_info(q_type)
+    x = np.ascontiguousarray(x, np.float32)
+    n, G = x.shape
+    assert G == ti["group"]
+    sc, ze = np.empty(n, np.float32), np.empty(n, np.float32)
+    L = lib()
+    L.gqo_make_quants_lp.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                     ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_void_p,
+                                     ctypes.c_void_p]
+    L.gqo_make_quants_lp.restype = None
+    L.gqo_make_quants_lp(_p(x), n, G, ti["bits"], ti["k_search"], rmode, rmin, rdelta, nstep, _p(sc), _p(ze))
+    return sc, ze

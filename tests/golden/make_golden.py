@@ -367,7 +367,7 @@ def g8_g9_rtn_dequant():
     for dt, tag in ((torch.float16, "f16"), (torch.bfloat16, "bf16")):
         Wl = W.to(dt)
         out[f"W_{tag}"] = Wl.float().numpy()
-        for qt in (T.Q4_K, T.Q6_K):
+        for qt in T:
             q, d, s, dmin, m = drv._quant_non_block_module(Wl.clone(), qt)
             out[f"{tag}_{qt.name}_q"] = q.numpy()
             out[f"{tag}_{qt.name}_d"], out[f"{tag}_{qt.name}_dmin"] = u16(d), u16(dmin)

@@ -183,10 +183,22 @@ def test_pack_ragged_and_roundtrip(ops, oracle, name):
         assert np.array_equal(d2, d) and np.array_equal(dm2, dmin) and np.array_equal(mn2, m.astype(np.int32))
 
 
-def test_rtn_reduced_precision_is_loud(ops):
-    from gptq_gguf_toolkit_amd import GQError
-    with pytest.raises(GQError, match="not implemented"):
-        ops.rtn_quantize(torch.zeros(8, 256, device="cuda", dtype=torch.bfloat16), 12)
+@pytest.mark.parametrize("tag,dt", [("f16", torch.float16), ("bf16", torch.bfloat16)])
+def test_rtn_model_dtype_golden(ops, oracle, tag, dt):
+    """embed/lm_head RTN with the weight in fp16/bf16: the reference runs make_*quants in the model dtype
+    (quantizer.py:109,195); G9 holds its outputs, the kernel rounds after every op like ATen does."""
+    g = load_golden("g8_g9_rtn_dequant")
+    W = dev(g[f"W_{tag}"]).to(dt)  # values are exactly representable
+    names = sorted({k.split("_", 1)[1].rsplit("_", 1)[0] for k in g.files if k.startswith(f"{tag}_") and k.endswith("_q")})
+    assert "Q4_K" in names and "Q6_K" in names
+    for name in names:
+        t = TYPES[name]
+        q, d, s, dmin, m = ops.rtn_quantize(W, t)
+        assert np.array_equal(npy(q), g[f"{tag}_{name}_q"]), f"{tag} {name}: {(npy(q) != g[f'{tag}_{name}_q']).mean():.4%}"
+        assert np.array_equal(u16(d), g[f"{tag}_{name}_d"]) and np.array_equal(u16(dmin), g[f"{tag}_{name}_dmin"])
+        assert np.array_equal(npy(s), g[f"{tag}_{name}_s"]) and np.array_equal(npy(m), g[f"{tag}_{name}_m"])
+        oq, od, os_, odm, om = oracle.rtn_quantize_lp(g[f"W_{tag}"], 1 if tag == "f16" else 2, t)
+        assert np.array_equal(oq, npy(q)) and np.array_equal(od, u16(d)) and np.array_equal(os_, npy(s))
 
 
 # ------------------------------------------------------------------ K1 Hessian

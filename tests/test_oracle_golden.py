@@ -191,3 +191,19 @@ def test_pack_does_not_mutate_inputs(oracle):
         q0, s0 = q.copy(), s.copy()
         oracle.pack(TYPES[name], q, d, s)
         assert np.array_equal(q, q0) and np.array_equal(s, s0)
+
+
+@pytest.mark.parametrize("tag,rmode", [("f16", 1), ("bf16", 2)])
+@pytest.mark.parametrize("name", list(TYPES))
+def test_g9_rtn_model_dtype(oracle, tag, rmode, name):
+    """quantizer.py:109,195: RTN of embed/lm_head runs make_*quants in the model dtype; the oracle rounds
+    after every op the way ATen's CPU fp16/bf16 kernels do (fp32 compute, round to the tensor dtype)."""
+    g = load_golden("g8_g9_rtn_dequant")
+    q, d, s, dmin, m = oracle.rtn_quantize_lp(g[f"W_{tag}"], rmode, TYPES[name])
+    assert np.array_equal(q, g[f"{tag}_{name}_q"]), f"{(q != g[f'{tag}_{name}_q']).mean():.4%} ints differ"
+    assert np.array_equal(d, g[f"{tag}_{name}_d"]) and np.array_equal(dmin, g[f"{tag}_{name}_dmin"])
+    assert np.array_equal(s, g[f"{tag}_{name}_s"]) and np.array_equal(m, g[f"{tag}_{name}_m"])
+    # and it is NOT what an fp32 search gives (SURVEY 8 a12: 7-10 % of Q4_K ints differ)
+    if name == "Q4_K":
+        q32, *_ = oracle.rtn_quantize(g[f"W_{tag}"], TYPES[name])
+        assert (q32 != q).mean() > 0.01
