@@ -13,6 +13,8 @@
 //           LDS and also inverts it; panel  A21 <- A21 * L11^-T  and the trailing
 //           symmetric update  A22 -= L21 L21^T  run on the fp32 matrix cores.
 //   trtri : recursive halving, X21 = -X22 * (M21 * X11), two GEMMs per node.
+#include <stdlib.h>
+
 #include "gq_common.hpp"
 #include "gq_gemm32.hpp"
 
@@ -230,6 +232,156 @@ __global__ __launch_bounds__(256) void diag_potrf_inv_kernel(float* __restrict__
     }
 }
 
+// --------------------------------------- diagonal block, blocked variant (default)
+// Same contract as diag_potrf_inv_kernel, ~5x shorter critical path: the 128x128 block is
+// processed as 4x4 sub-blocks of 32x32.
+//   * a 32x32 diagonal sub-block is factored AND inverted by ONE wave in registers: lane i holds
+//     row i (32 VGPRs); the pivot row / column entries other lanes need are wave-uniform and come
+//     through v_readlane (SGPR operands of the FMAs) -- no LDS, no barrier inside;
+//   * the panel below it (P = A_panel * Dinv^T) and the trailing update of the remaining
+//     sub-blocks (S_ij -= P_i P_j^T) are 32x32x32 products on v_mfma_f32_32x32x2_f32;
+//   * L^-1 of the whole block is assembled from the sub-block inverses by block forward
+//     substitution, again on the matrix cores (X_ij = -X_ii * sum_k L_ik X_kj).
+// LDS rows have an odd stride (129 floats): MFMA operand reads walk rows with stride-1 banks.
+constexpr int LDQ = NB + 1;
+constexpr int TQ = 33;  // wave-private 32x32 scratch tile stride
+constexpr size_t DIAG_BLK_LDS = (size_t)(2 * NB * LDQ + 4 * 32 * TQ) * sizeof(float);
+
+__device__ __forceinline__ float rdlane(float v, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+
+// C[32x32] (accumulator) = sum_k Arow[i][k] * Brow[j][k], k < 32*nk32: both operands row-major in LDS
+// (lane (i = l&31, kh = l>>5) reads A[i][2p+kh] and B[j=l&31][2p+kh]); strides in floats.
+__device__ __forceinline__ f32x16 mfma_nt_32(const float* Ap, int lda_, const float* Bp, int ldb_, int nk32, int lane) {
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+    const int li = lane & 31, lk = lane >> 5;
+    for (int p = 0; p < 16 * nk32; ++p)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ap[li * lda_ + 2 * p + lk], Bp[li * ldb_ + 2 * p + lk], acc, 0, 0, 0);
+    return acc;
+}
+
+__global__ __launch_bounds__(256) void diag_blk_kernel(float* __restrict__ A, int64_t lda, float* __restrict__ Xout,
+                                                       int64_t ldx, int* __restrict__ flag) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* S = smem;              // [NB][LDQ]  A (lower) -> L, zeros above the diagonal
+    float* X = smem + NB * LDQ;   // [NB][LDQ]  L^-1 (lower), zeros above
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    float* Tw = X + NB * LDQ + wid * 32 * TQ;  // wave-private scratch tile
+    for (int idx = tid; idx < NB * NB; idx += 256) {
+        const int r = idx / NB, c = idx % NB;
+        S[r * LDQ + c] = (c <= r) ? A[r * lda + c] : 0.0f;
+        X[r * LDQ + c] = 0.0f;
+    }
+    __syncthreads();
+    const int lc = lane & 31, lh = lane >> 5;  // MFMA D layout: col = lc, row = (e&3) + 8*(e>>2) + 4*lh
+    for (int sb = 0; sb < 4; ++sb) {
+        const int c0 = 32 * sb;
+        if (wid == 0) {
+            // ---- factor + invert the 32x32 diagonal sub-block in registers (lanes 32-63 mirror 0-31)
+            const int i = lane & 31;
+            float a[32], x[32];
+#pragma unroll
+            for (int c = 0; c < 32; ++c) a[c] = S[(c0 + i) * LDQ + c0 + c];
+            bool bad = false;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                float pj = rdlane(a[j], j);
+                if (!(pj > 0.0f)) {  // wave-uniform; also NaN
+                    bad = true;
+                    pj = 1.0f;
+                }
+                const float ljj = sqrtf(pj), inv = 1.0f / ljj;
+                a[j] = (i == j) ? ljj : a[j] * inv;
+#pragma unroll
+                for (int c = j + 1; c < 32; ++c) a[c] = fmaf(-a[j], rdlane(a[j], c), a[c]);
+            }
+#pragma unroll
+            for (int r = 0; r < 32; ++r) {  // lane i = column i of the inverse
+                const float lrr = rdlane(a[r], r);
+                float acc = 0.0f;
+#pragma unroll
+                for (int p = 0; p < r; ++p) acc = fmaf(rdlane(a[p], r), x[p], acc);
+                x[r] = (r < i) ? 0.0f : ((r == i) ? 1.0f / lrr : -acc / lrr);
+            }
+            if (lane < 32) {
+#pragma unroll
+                for (int c = 0; c < 32; ++c) {
+                    S[(c0 + i) * LDQ + c0 + c] = (c <= i) ? a[c] : 0.0f;
+                    X[(c0 + c) * LDQ + c0 + i] = x[c];
+                }
+                if (bad && lane == 0) *flag = 1;
+            }
+        }
+        __syncthreads();
+        // ---- panel: P_t = A_t * Dinv^T for the 32-row tiles below (one per wave)
+        const int ntile = 3 - sb;
+        if (wid < ntile) {
+            const int r0 = c0 + 32 * (wid + 1);
+            f32x16 acc = mfma_nt_32(S + r0 * LDQ + c0, LDQ, X + c0 * LDQ + c0, LDQ, 1, lane);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) S[(r0 + (e & 3) + 8 * (e >> 2) + 4 * lh) * LDQ + c0 + lc] = acc[e];
+        }
+        __syncthreads();
+        // ---- trailing update of the remaining lower sub-blocks: S_ij -= P_i P_j^T
+        int t = 0;
+        for (int bi = sb + 1; bi < 4; ++bi)
+            for (int bj = sb + 1; bj <= bi; ++bj, ++t) {
+                if ((t & 3) != wid) continue;
+                f32x16 acc = mfma_nt_32(S + (32 * bi) * LDQ + c0, LDQ, S + (32 * bj) * LDQ + c0, LDQ, 1, lane);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float* p = S + (32 * bi + (e & 3) + 8 * (e >> 2) + 4 * lh) * LDQ + 32 * bj + lc;
+                    *p = *p - acc[e];
+                }
+            }
+        __syncthreads();
+    }
+    // ---- L^-1 off-diagonal sub-blocks by block forward substitution, distance d = i - j
+    for (int d = 1; d < 4; ++d) {
+        const int bi = d + wid, bj = wid;  // one (bi, bj) pair per wave, 4 - d pairs
+        const bool mine = bi < 4;
+        if (mine) {
+            // T[r][c] = sum_{k = 32 bj .. 32 bi - 1} L[32bi + r][k] * X[k][32bj + c]
+            // (A operand: rows of L; B operand: row k of X, lanes along its columns)
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+            const int li = lane & 31, lk = lane >> 5;
+            for (int p = 0; p < 16 * d; ++p) {
+                const int k = 32 * bj + 2 * p + lk;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(S[(32 * bi + li) * LDQ + k], X[k * LDQ + 32 * bj + li], acc, 0,
+                                                           0, 0);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) Tw[((e & 3) + 8 * (e >> 2) + 4 * lh) * TQ + lc] = acc[e];
+        }
+        __syncthreads();
+        if (mine) {
+            // X_ij[r][c] = -sum_k X_ii[r][k] * T[k][c]
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+            const int li = lane & 31, lk = lane >> 5;
+            for (int p = 0; p < 16; ++p) {
+                const int k = 2 * p + lk;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(X[(32 * bi + li) * LDQ + 32 * bi + k], Tw[k * TQ + li], acc, 0, 0,
+                                                           0);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) X[(32 * bi + (e & 3) + 8 * (e >> 2) + 4 * lh) * LDQ + 32 * bj + lc] = -acc[e];
+        }
+        __syncthreads();
+    }
+    for (int idx = tid; idx < NB * NB; idx += 256) {
+        const int r = idx / NB, c = idx % NB;
+        if (c <= r) A[r * lda + c] = S[r * LDQ + c];
+        Xout[r * ldx + c] = X[r * LDQ + c];
+    }
+}
+
 size_t h_prepare_workspace_bytes(int64_t R, int64_t C) {
     (void)R;
     const size_t n2 = (size_t)C * (size_t)C * sizeof(float);
@@ -249,7 +401,10 @@ static int chol_inv_rec(float* A, float* X, float* Tmp, int* flag, int64_t n, in
     if (hi - lo == 1) {
         ProfScope ps(PT_DIAG_POTRF, st);
         const int64_t o = (lo * NB) * n + lo * NB;
-        hipLaunchKernelGGL(diag_potrf_inv_kernel, dim3(1), dim3(256), diag_lds, st, A + o, n, X + o, n, flag);
+        if (diag_lds == DIAG_BLK_LDS)
+            hipLaunchKernelGGL(diag_blk_kernel, dim3(1), dim3(256), diag_lds, st, A + o, n, X + o, n, flag);
+        else
+            hipLaunchKernelGGL(diag_potrf_inv_kernel, dim3(1), dim3(256), diag_lds, st, A + o, n, X + o, n, flag);
         GQ_LAUNCH_CHECK();
         return GQ_OK;
     }
@@ -310,10 +465,13 @@ int h_prepare(float* H, float* W, int64_t R, int64_t C, float rel_damp, float* U
     GQ_HIP(hipMemsetAsync(X, 0, (size_t)n * n * sizeof(float), st));
     }
     static bool attr_set = false;
-    const size_t diag_lds = (2 * NB * LDP + NB) * sizeof(float);
+    static const bool use_ref = getenv("GQ_DIAG_REF") != nullptr;  // A/B: the column-by-column kernel
+    const size_t diag_lds = use_ref ? (2 * NB * LDP + NB) * sizeof(float) : DIAG_BLK_LDS;
     if (!attr_set) {
         GQ_HIP(hipFuncSetAttribute((const void*)diag_potrf_inv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)diag_lds));
+                                   (int)((2 * NB * LDP + NB) * sizeof(float))));
+        GQ_HIP(hipFuncSetAttribute((const void*)diag_blk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)DIAG_BLK_LDS));
         attr_set = true;
     }
     if ((rc = chol_inv_rec(A, X, U, not_invertible, n, 0, nblk, diag_lds, st))) return rc;
