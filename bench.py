@@ -78,21 +78,31 @@ def make_weights(shapes, dev, seed=0):
 
 
 def quantize_block(shapes, W16, X, owners, rank, world, q_type=Q4_K, block_size=128, rel_damp=0.01, keep=None,
-                   hbatch=None, hws=None, streams=None):
+                   hbatch=None, hws=None, streams=None, row_chunks=1):
     dev = next(iter(W16.values())).device
     # ---- Hessians: one per distinct input.  The activations of `hbatch` sequences are folded in
     # per launch (beta = n/(n+b), alpha = 2/(n+b): the telescoped form of b single-sample updates of
     # gptq.py:106-112), all distinct inputs of the block in ONE grouped SYRK grid.
     H = {inp: torch.zeros(x.shape[-1], x.shape[-1], device=dev, dtype=torch.float32) for inp, x in X.items()}
-    names = list(X)
+    # Two grouped grids: the widest input first (its Hessian feeds the longest prepare -> column-loop
+    # chain, which then starts while the grid of the remaining inputs is still running).
+    names = sorted(X, key=lambda i: -X[i].shape[-1])
+    splits = [names[:1], names[1:]] if len(names) > 1 and world == 1 else [names]
     nseq = X[names[0]].shape[0]
     hb = hbatch or nseq
-    n = 0
-    while n < nseq:
-        b = min(hb, nseq - n)
-        ops.h_accumulate_grouped([H[i] for i in names], [X[i][n:n + b].reshape(-1, X[i].shape[-1]) for i in names],
-                                 [n / (n + b)] * len(names), [2.0 / (n + b)] * len(names), ws=hws)
-        n += b
+    ev_ready = {}
+    main = torch.cuda.current_stream(dev)
+    for grp in splits:
+        n = 0
+        while n < nseq:
+            b = min(hb, nseq - n)
+            ops.h_accumulate_grouped([H[i] for i in grp], [X[i][n:n + b].reshape(-1, X[i].shape[-1]) for i in grp],
+                                     [n / (n + b)] * len(grp), [2.0 / (n + b)] * len(grp), ws=hws)
+            n += b
+        ev = torch.cuda.Event()
+        ev.record(main)
+        for i in grp:
+            ev_ready[i] = ev
     if world > 1:
         for inp in sorted(H):
             dist.all_reduce(H[inp], op=dist.ReduceOp.AVG)  # RCCL over xGMI
@@ -102,9 +112,10 @@ def quantize_block(shapes, W16, X, owners, rank, world, q_type=Q4_K, block_size=
     # stream: the single-workgroup diagonal factorisations and the 64-wave column-loop kernels of one
     # chain overlap with the GEMMs of the others.
     out, pending = {}, []
-    main = torch.cuda.current_stream(dev)
-    ev_h = torch.cuda.Event()
-    ev_h.record(main)
+    if world > 1:  # the all-reduces above are on the main stream: one common event
+        ev = torch.cuda.Event()
+        ev.record(main)
+        ev_ready = {i: ev for i in H}
     groups = {}
     for name, (R, C, inp) in shapes.items():
         if owners[name] == rank:
@@ -112,7 +123,7 @@ def quantize_block(shapes, W16, X, owners, rank, world, q_type=Q4_K, block_size=
     order = sorted(groups, key=lambda g: -sum(shapes[n][0] * shapes[n][1] * shapes[n][1] for n in groups[g]))
     for gi, inp in enumerate(order):
         st = streams[gi % len(streams)] if streams else main
-        st.wait_event(ev_h)
+        st.wait_event(ev_ready[inp])
         with torch.cuda.stream(st):
             U = flag = cf = None
             for name in groups[inp]:
@@ -125,7 +136,9 @@ def quantize_block(shapes, W16, X, owners, rank, world, q_type=Q4_K, block_size=
                     del Hc
                 else:
                     mm = ops.w_prepare(cf, Wf)  # speculative reuse of the leader's U, verified below
-                q, d, s, dmin, m = ops.gptq_quantize(Wf, U, q_type, block_size)
+                # the widest Linear is the critical chain: its rows are split over side streams
+                chunks = row_chunks if (gi == 0 and len(groups[inp]) == 1) else 1
+                q, d, s, dmin, m = ops.gptq_quantize(Wf, U, q_type, block_size, row_chunks=chunks)
                 deq = ops.dequantize(q_type, q, d, s, dmin, m, torch.float16)
                 packed = ops.pack(q_type, q, d, s, dmin, m)
                 out[name] = deq
@@ -184,6 +197,8 @@ def main():
     ap.add_argument("--hessian-batch", type=int, default=None,
                     help="sequences folded into H per SYRK launch (default: all local sequences; 1 = reference cadence)")
     ap.add_argument("--streams", type=int, default=4, help="HIP streams for the independent per-input chains (0: one)")
+    ap.add_argument("--row-chunks", type=int, default=1,
+                    help="row chunks (side streams) for the column loop of the block's widest Linear")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="one extra profiled step: per-kernel ms to stderr")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -229,7 +244,7 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        quantize_block(shapes, W16, X, owners, rank, world, hbatch=hb, hws=hws, streams=streams)
+        quantize_block(shapes, W16, X, owners, rank, world, hbatch=hb, hws=hws, streams=streams, row_chunks=args.row_chunks)
     sync()
     # dominant kernel (the fp16 MFMA SYRK of the Hessian accumulation) timed live with HIP
     # events on its launch stream, inside the timed region
@@ -238,7 +253,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         quantize_block(shapes, W16, X, owners, rank, world, keep=keep if i == args.steps - 1 else None, hbatch=hb,
-                       hws=hws, streams=streams)
+                       hws=hws, streams=streams, row_chunks=args.row_chunks)
     sync()
     dt = time.perf_counter() - t0
     prof = _cabi.prof_collect()
@@ -250,7 +265,7 @@ def main():
 
     if args.breakdown and rank == 0:
         _cabi.prof_enable(None)
-        quantize_block(shapes, W16, X, owners, rank, world, hbatch=hb, hws=hws, streams=streams)
+        quantize_block(shapes, W16, X, owners, rank, world, hbatch=hb, hws=hws, streams=streams, row_chunks=args.row_chunks)
         torch.cuda.synchronize()
         bd = _cabi.prof_collect()
         _cabi.prof_enable([])

@@ -142,21 +142,64 @@ def _alloc_outs(R, C, q_type, dev):
             torch.empty(R, C // G, dtype=torch.uint8, device=dev))
 
 
+_side_streams = {}
+
+
+def _streams(device, n):
+    pool = _side_streams.setdefault(device, [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device))
+    return pool[:n]
+
+
 def gptq_quantize(W: torch.Tensor, U: torch.Tensor, q_type: int, block_size=128, static_groups=False, rmin=-1.0,
-                  rdelta=0.1, nstep=20, ws: Optional[torch.Tensor] = None):
+                  rdelta=0.1, nstep=20, ws: Optional[torch.Tensor] = None, row_chunks: Optional[int] = None):
     """GPTQ.step body.  W (fp32, contiguous) is updated IN PLACE to the dequantized matrix.
-    Returns (qweight, d, s, dmin, m)."""
+    Returns (qweight, d, s, dmin, m).
+
+    Rows of W are independent given U (gptq.py:222-270 never mixes rows), so a tall matrix is cut into
+    `row_chunks` contiguous row ranges, each a separate gq_gptq_quantize call on its own HIP stream: the
+    latency-bound column-loop kernel of one chunk overlaps with the trailing-update GEMM of another.
+    Results are identical to one call.  Default 1: every extra chunk multiplies the launch count, which only
+    pays on the critical chain of a block (bench.py / the driver pass it for the widest Linear)."""
     _need_cuda(W, U)
     assert W.dtype == torch.float32 and U.dtype == torch.float32 and W.is_contiguous() and U.is_contiguous()
     R, C = W.shape
     q, d, s, dmin, m = _alloc_outs(R, C, q_type, W.device)
     bs = int(block_size or 0)
-    need = workspace_bytes(_cabi.WS_GPTQ_QUANTIZE, R, C, 0, bs)
-    if ws is None or ws.numel() < need:
-        ws = _ws(need, W.device)
-    check(lib().gq_gptq_quantize(_ptr(W), _ptr(U), R, C, int(q_type), bs, int(bool(static_groups)),
-                                 _search(rmin, rdelta, nstep), _ptr(q), _ptr(d), _ptr(s), _ptr(dmin), _ptr(m),
-                                 _ptr(ws), ws.numel(), _stream(W)), "gq_gptq_quantize")
+    if row_chunks is None:
+        row_chunks = 1
+    if row_chunks > 1 and (R % (64 * row_chunks) or ws is not None):
+        row_chunks = 1
+
+    def one(r0, r1, wsbuf):
+        n = r1 - r0
+        need = workspace_bytes(_cabi.WS_GPTQ_QUANTIZE, n, C, 0, bs)
+        if wsbuf is None or wsbuf.numel() < need:
+            wsbuf = _ws(need, W.device)
+        check(lib().gq_gptq_quantize(_ptr(W[r0:r1]), _ptr(U), n, C, int(q_type), bs, int(bool(static_groups)),
+                                     _search(rmin, rdelta, nstep), _ptr(q[r0:r1]), _ptr(d[r0:r1]), _ptr(s[r0:r1]),
+                                     _ptr(dmin[r0:r1]), _ptr(m[r0:r1]), _ptr(wsbuf), wsbuf.numel(), _stream(W)),
+              "gq_gptq_quantize")
+        return wsbuf
+
+    if row_chunks == 1:
+        one(0, R, ws)
+    else:
+        cur = torch.cuda.current_stream(W.device)
+        fork = torch.cuda.Event()
+        fork.record(cur)
+        step = R // row_chunks
+        keep = []
+        for k, st in enumerate(_streams(W.device, row_chunks)):
+            st.wait_event(fork)
+            with torch.cuda.stream(st):
+                keep.append(one(k * step, (k + 1) * step, None))
+            ev = torch.cuda.Event()
+            ev.record(st)
+            cur.wait_event(ev)
+        for b in keep:  # scratch was allocated on side streams; it is dead once `cur` has passed the joins
+            b.record_stream(cur)
     t = _idt(q_type)
     return q.view(t), d, s.view(t), dmin, m.view(t)
 
