@@ -27,20 +27,23 @@ int launch_scale_search(const float* x, int64_t rows, int64_t ld, int q_type, co
 //   qparams d/dmin [R, C/256], s/m [R, C/G] already hold the super-group of `a`
 constexpr int SEG = 128;
 constexpr int SB = 16;  // register sub-block
-constexpr int SEG_LDS_BYTES = (SEG * 64 + SEG * SEG) * 4;
+constexpr int SEG_LDS_BYTES = (SEG * 64 + SEG * SEG + SB * 64) * 4;
 
-__global__ __launch_bounds__(64) void gptq_segment_kernel(
+__global__ __launch_bounds__(256) void gptq_segment_kernel(
     float* W, int64_t C, const float* src, int64_t ld_src,  // may alias (single-segment blocks)
     const float* __restrict__ U, int64_t a, int len, int64_t R,
     const uint16_t* __restrict__ d, const uint8_t* __restrict__ s, const uint16_t* __restrict__ dmin,
     const uint8_t* __restrict__ m, int G, int is_signed, float qmin, float qmax,
     uint8_t* __restrict__ qweight, float* __restrict__ Err, int64_t ld_err, int64_t err_col0) {
+    // One workgroup = 64 rows (lane = row) x 4 waves.  Wave 0 walks the columns (the dependent chain);
+    // after every 16-column sub-block all four waves share the rank-1 updates of the later columns.
     extern __shared__ __attribute__((aligned(16))) float seg_smem[];
-    float* wl = seg_smem;             // wl[j*64 + lane]: working copy, column-major per wave (32 KiB)
-    float* Us = seg_smem + SEG * 64;  // Us[i*SEG + j] = U[a+i, a+j]: the segment's diagonal block (64 KiB),
-                                      // read back with wave-uniform (broadcast) 16-byte LDS loads
-    const int lane = threadIdx.x;
-    for (int idx = lane; idx < len * (SEG / 4); idx += 64) {
+    float* wl = seg_smem;                   // wl[j*64 + lane]: working copy, column-major (32 KiB)
+    float* Us = seg_smem + SEG * 64;        // Us[i*SEG + j] = U[a+i, a+j]: diagonal block (64 KiB), read back
+                                            // with wave-uniform (broadcast) 16-byte LDS loads
+    float* ne = Us + SEG * SEG;             // ne[k*64 + lane]: -err of the current sub-block (4 KiB)
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    for (int idx = tid; idx < len * (SEG / 4); idx += 256) {
         const int i = idx / (SEG / 4), j4 = (idx % (SEG / 4)) * 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (j4 < len) v = *reinterpret_cast<const float4*>(U + (a + i) * C + a + j4);
@@ -50,10 +53,11 @@ __global__ __launch_bounds__(64) void gptq_segment_kernel(
     const bool live = row < R;
     const int64_t r = live ? row : 0;
 
-    // gptq.py:225 w_blk = w[:, c1:c2].clone()
+    // gptq.py:225 w_blk = w[:, c1:c2].clone()  (each wave brings in a quarter of the columns)
     {
         const float* sp = src + r * ld_src;
-        for (int j = 0; j < len; j += 4) {
+        const int q4 = len / 4;
+        for (int j = wid * q4; j < (wid + 1) * q4; j += 4) {
             float4 v = *reinterpret_cast<const float4*>(sp + j);
             wl[(j + 0) * 64 + lane] = v.x;
             wl[(j + 1) * 64 + lane] = v.y;
@@ -65,55 +69,67 @@ __global__ __launch_bounds__(64) void gptq_segment_kernel(
     __syncthreads();
 
     for (int i0 = 0; i0 < len; i0 += SB) {
-        const int64_t col0 = a + i0;
-        // group parameters are constant over a 16-aligned run of 16 columns
-        const float ds = h2f(d[r * nsg + col0 / 256]) * ival(s[r * ng + col0 / G], is_signed);
-        const float dm = h2f(dmin[r * nsg + col0 / 256]) * ival(m[r * ng + col0 / G], is_signed);
-        float wr[SB], nerr[SB], wq[SB];
-        uint32_t qpack[4] = {0, 0, 0, 0};
+        if (wid == 0) {
+            const int64_t col0 = a + i0;
+            // group parameters are constant over a 16-aligned run of 16 columns
+            const float ds = h2f(d[r * nsg + col0 / 256]) * ival(s[r * ng + col0 / G], is_signed);
+            const float dm = h2f(dmin[r * nsg + col0 / 256]) * ival(m[r * ng + col0 / G], is_signed);
+            float wr[SB], nerr[SB], wq[SB];
+            uint32_t qpack[4] = {0, 0, 0, 0};
 #pragma unroll
-        for (int k = 0; k < SB; ++k) wr[k] = wl[(i0 + k) * 64 + lane];
+            for (int k = 0; k < SB; ++k) wr[k] = wl[(i0 + k) * 64 + lane];
 #pragma unroll
-        for (int k = 0; k < SB; ++k) {
-            const float* urow = Us + (i0 + k) * SEG + i0;  // wave-uniform LDS address (broadcast)
-            const float dii = urow[k];
-            const float q = quantize1(wr[k], ds, dm, qmin, qmax);  // gptq.py:247-254
-            wq[k] = dequantize1(q, ds, dm);                        // :255-261
-            const float err = (wr[k] - wq[k]) / dii;               // :264
-            const uint8_t qb = is_signed ? (uint8_t)(int8_t)q : (uint8_t)q;
-            qpack[k >> 2] |= (uint32_t)qb << (8 * (k & 3));
-            // :267 addr_(err, U[i, i:], alpha=-1): self + (alpha*err)*u, two roundings
-            const float ne = -err;
-            nerr[k] = ne;
+            for (int k = 0; k < SB; ++k) {
+                const float* urow = Us + (i0 + k) * SEG + i0;  // wave-uniform LDS address (broadcast)
+                const float dii = urow[k];
+                const float q = quantize1(wr[k], ds, dm, qmin, qmax);  // gptq.py:247-254
+                wq[k] = dequantize1(q, ds, dm);                        // :255-261
+                const float err = (wr[k] - wq[k]) / dii;               // :264
+                const uint8_t qb = is_signed ? (uint8_t)(int8_t)q : (uint8_t)q;
+                qpack[k >> 2] |= (uint32_t)qb << (8 * (k & 3));
+                // :267 addr_(err, U[i, i:], alpha=-1): self + (alpha*err)*u, two roundings
+                const float nk = -err;
+                nerr[k] = nk;
+                ne[k * 64 + lane] = nk;
 #pragma unroll
-            for (int kk = k; kk < SB; ++kk) wr[kk] = wr[kk] + ne * urow[kk];
-        }
-        if (live) {
-            *reinterpret_cast<uint4*>(qweight + row * C + col0) = make_uint4(qpack[0], qpack[1], qpack[2], qpack[3]);
-            float* wp = W + row * C + col0;
-            float* ep = Err + row * ld_err + err_col0 + i0;
+                for (int kk = k; kk < SB; ++kk) wr[kk] = wr[kk] + nk * urow[kk];
+            }
+            if (live) {
+                *reinterpret_cast<uint4*>(qweight + row * C + col0) =
+                    make_uint4(qpack[0], qpack[1], qpack[2], qpack[3]);
+                float* wp = W + row * C + col0;
+                float* ep = Err + row * ld_err + err_col0 + i0;
 #pragma unroll
-            for (int k = 0; k < SB; k += 4) {
-                *reinterpret_cast<float4*>(wp + k) = make_float4(wq[k], wq[k + 1], wq[k + 2], wq[k + 3]);
-                *reinterpret_cast<float4*>(ep + k) = make_float4(-nerr[k], -nerr[k + 1], -nerr[k + 2], -nerr[k + 3]);
+                for (int k = 0; k < SB; k += 4) {
+                    *reinterpret_cast<float4*>(wp + k) = make_float4(wq[k], wq[k + 1], wq[k + 2], wq[k + 3]);
+                    *reinterpret_cast<float4*>(ep + k) =
+                        make_float4(-nerr[k], -nerr[k + 1], -nerr[k + 2], -nerr[k + 3]);
+                }
             }
         }
-        // rank-1 updates of the later columns of this segment, 16 columns at a time;
-        // each element sees the same sequence of (mul, add) pairs, in the same
-        // order of i, as the reference's 16 successive addr_ calls.
-        for (int j0 = i0 + SB; j0 < len; j0 += SB) {
-            float wt[SB];
+        __syncthreads();
+        // rank-1 updates of the later columns of this segment, 16 columns per tile, tiles dealt round-robin
+        // to the four waves; each element sees the same sequence of (mul, add) pairs, in the same order of
+        // i, as the reference's 16 successive addr_ calls.
+        // (packed v_pk_mul_f32 / v_pk_add_f32 were measured 35 % SLOWER here)
+        int t = 0;
+        for (int j0 = i0 + SB; j0 < len; j0 += SB, ++t) {
+            if ((t & 3) != wid) continue;
+            float wt[SB], nk[SB];
 #pragma unroll
             for (int jj = 0; jj < SB; ++jj) wt[jj] = wl[(j0 + jj) * 64 + lane];
+#pragma unroll
+            for (int k = 0; k < SB; ++k) nk[k] = ne[k * 64 + lane];
 #pragma unroll
             for (int k = 0; k < SB; ++k) {
                 const float* urow = Us + (i0 + k) * SEG + j0;
 #pragma unroll
-                for (int jj = 0; jj < SB; ++jj) wt[jj] = wt[jj] + nerr[k] * urow[jj];
+                for (int jj = 0; jj < SB; ++jj) wt[jj] = wt[jj] + nk[k] * urow[jj];
             }
 #pragma unroll
             for (int jj = 0; jj < SB; ++jj) wl[(j0 + jj) * 64 + lane] = wt[jj];
         }
+        __syncthreads();
     }
 }
 
@@ -187,7 +203,7 @@ int gptq_quantize(float* W, const float* U, int64_t R, int64_t C, int q_type, in
                                           dmin + c / 256, nsg, m + (c / 256) * gps, ng, st)))
                 return rc;
     }
-    const dim3 seg_grid((unsigned)((R + 63) / 64)), seg_block(64);
+    const dim3 seg_grid((unsigned)((R + 63) / 64)), seg_block(256);
     static bool seg_attr = false;
     if (!seg_attr) {
         GQ_HIP(hipFuncSetAttribute((const void*)gptq_segment_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
