@@ -17,7 +17,7 @@ WS_H_ACCUMULATE, WS_H_PREPARE, WS_GPTQ_QUANTIZE = 1, 2, 3
 EXPORTS = (
     "gq_abi_version", "gq_last_error", "gq_type_info", "gq_workspace_bytes", "gq_h_accumulate", "gq_h_accumulate_grouped", "gq_h_prepare", "gq_w_prepare",
     "gq_scale_search", "gq_group_search", "gq_gptq_quantize", "gq_rtn_quantize", "gq_dequantize", "gq_pack", "gq_trailing_update",
-    "gq_prof_enable", "gq_prof_ntags", "gq_prof_name", "gq_prof_collect",
+    "gq_prof_enable", "gq_prof_ntags", "gq_prof_name", "gq_prof_collect", "gq_prof_collect2",
 )
 
 
@@ -78,6 +78,8 @@ def lib():
     L.gq_prof_name.argtypes = [ci]
     L.gq_prof_name.restype = ctypes.c_char_p
     L.gq_prof_collect.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long)]
+    L.gq_prof_collect2.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long),
+                                   ctypes.POINTER(ctypes.c_double)]
     for name in EXPORTS:
         getattr(L, name)  # raises AttributeError if the .so lacks a declared symbol
     _lib = L
@@ -108,11 +110,16 @@ def prof_enable(tags=None):
     return names
 
 
-def prof_collect() -> dict:
-    """{tag: (total_ms, launches)} since the last collect (synchronises the recorded events)."""
+def prof_collect(busy: bool = False) -> dict:
+    """{tag: (total_ms, launches)} since the last collect (synchronises the recorded events); with busy=True
+    {tag: (total_ms, launches, busy_ms)}, busy_ms = union of the tag's launch intervals (overlapping launches
+    on different streams counted once)."""
     L = lib()
     n = L.gq_prof_ntags()
     ms = (ctypes.c_double * n)()
     cnt = (ctypes.c_long * n)()
-    check(L.gq_prof_collect(ms, cnt), "gq_prof_collect")
+    bz = (ctypes.c_double * n)()
+    check(L.gq_prof_collect2(ms, cnt, bz), "gq_prof_collect2")
+    if busy:
+        return {L.gq_prof_name(i).decode(): (ms[i], cnt[i], bz[i]) for i in range(n) if cnt[i]}
     return {L.gq_prof_name(i).decode(): (ms[i], cnt[i]) for i in range(n) if cnt[i]}

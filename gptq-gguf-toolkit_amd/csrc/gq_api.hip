@@ -30,7 +30,9 @@ int h_prepare(float*, float*, int64_t, int64_t, float, float*, int*, uint8_t*, v
 int w_prepare(const uint8_t*, float*, int64_t, int64_t, int*, hipStream_t);
 }  // namespace gq
 
+#include <algorithm>
 #include <mutex>
+#include <utility>
 #include <vector>
 
 namespace gq {
@@ -176,20 +178,38 @@ const char* gq_prof_name(int tag) {
                                           "block_far_update", "dequantize", "rtn_quantize", "pack"};
     return (tag >= 0 && tag < PT_COUNT) ? names[tag] : "?";
 }
-/* synchronises the recorded events; ms[tag], n[tag] accumulate; records are recycled */
-int gq_prof_collect(double* ms_host, long* n_host) {
+/* synchronises the recorded events; ms[tag], n[tag] accumulate; records are recycled.
+ * busy_ms[tag] (optional) accumulates the length of the UNION of the tag's launch intervals: launches of
+ * one tag that overlap on different streams are counted once (ms[tag] counts the overlap twice). */
+int gq_prof_collect2(double* ms_host, long* n_host, double* busy_ms_host) {
     std::lock_guard<std::mutex> lk(g_mu);
+    std::vector<std::pair<double, double>> iv[PT_COUNT];
     for (auto& r : g_recs) {
-        float t = 0.f;
+        float t = 0.f, t0 = 0.f;
         if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) {
             ms_host[r.tag] += t;
             n_host[r.tag] += 1;
+            if (busy_ms_host && hipEventElapsedTime(&t0, g_recs.front().a, r.a) == hipSuccess)
+                iv[r.tag].emplace_back((double)t0, (double)t0 + t);
         }
+    }
+    if (busy_ms_host)
+        for (int tag = 0; tag < PT_COUNT; ++tag) {
+            std::sort(iv[tag].begin(), iv[tag].end());
+            double end = -1e300;
+            for (auto& x : iv[tag]) {
+                if (x.second <= end) continue;
+                busy_ms_host[tag] += x.second - (x.first > end ? x.first : end);
+                end = x.second;
+            }
+        }
+    for (auto& r : g_recs) {
         g_pool.push_back(r.a);
         g_pool.push_back(r.b);
     }
     g_recs.clear();
     return GQ_OK;
 }
+int gq_prof_collect(double* ms_host, long* n_host) { return gq_prof_collect2(ms_host, n_host, nullptr); }
 
 }  // extern "C"

@@ -168,6 +168,9 @@ void gq_prof_enable(unsigned tag_mask);
 int gq_prof_ntags(void);
 const char* gq_prof_name(int tag);
 int gq_prof_collect(double* ms_host, long* n_host);
+/* as gq_prof_collect; busy_ms[tag] += length of the union of the tag's launch intervals (launches of one
+ * tag overlapping on different streams count once) */
+int gq_prof_collect2(double* ms_host, long* n_host, double* busy_ms_host);
 
 #ifdef __cplusplus
 }
