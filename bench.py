@@ -298,7 +298,7 @@ def main():
             nt = C // 128
             flops += x.shape[0] * args.steps * 2.0 * L * 128 * 128 * (nt * (nt + 1) // 2)  # all launches together
         ach = flops / (syrk_ms * 1e-3) / 1e12 if syrk_ms > 0 else None
-        roof = {"bound": "mfma", "kernel": "syrk16_256d_kernel<f16> (gq_h_accumulate_grouped)",
+        roof = {"bound": "mfma", "kernel": "syrk16_256e_kernel<f16> (gq_h_accumulate_grouped)",
                 "achieved": round(ach, 2) if ach else None, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_F16_MFMA_TFLOPS, 4) if ach else None, "traffic": None,
                 "launches": syrk_n, "busy_ms_per_step": round(syrk_ms / args.steps, 3),

@@ -21,6 +21,7 @@
 namespace gq {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -53,7 +54,8 @@ __global__ __launch_bounds__(256) void transpose16_kernel(const uint16_t* __rest
         if (half_mode) {  // p = h*512 + r*4 + c': half-stage h, stored chunk c' holds k-chunk 4h + (c' ^ ((r>>2)&3))
             const int h = p >> 9, q = p & 511;
             r = q >> 2;
-            kc = 4 * h + ((q & 3) ^ ((r >> 2) & 3));
+            const int g = (r >> 2) & 3;
+            kc = 4 * h + ((q & 3) ^ (half_mode == 2 ? (0x78 >> (2 * g)) & 3 : g));
         } else {
             r = p >> 3;
             kc = (p & 7) ^ ((r >> 1) & 7);  // stored chunk p holds k-chunk kc
@@ -598,6 +600,437 @@ __global__ __launch_bounds__(512, 2) void syrk16_256d_kernel(const SyrkGroup grp
         }
 }
 
+// ------------------------ 16-bit SYRK, 256x256 tiles, 4 waves x (128x128), direct-to-LDS operand ring
+// Same ring, operand image and hand-ordered stream as syrk16_256d_kernel, but ONE wave per SIMD with a
+// 128x128 wave tile: 16 accumulators (256 AGPRs), 8 LDS fragment reads per 16 MFMAs instead of 12 (the
+// chip is power-limited on this kernel -- ~1.45 GHz -- so LDS bytes per flop are clock), no co-resident
+// wave to share the matrix pipe with.  Per k16-step: 16 MFMAs, the 8 reads of the next step behind the
+// first 8, 4 of the half-stage's 8 DMA pieces behind MFMAs 8/10/12/14.
+template <bool BF16>
+__global__ __launch_bounds__(256, 1) void syrk16_256q_kernel(const SyrkGroup grp) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 1, wn = wid & 1;
+    const uint32_t ent = grp.table[(blockIdx.x & 7) * grp.per_xcd + (blockIdx.x >> 3)];
+    if (ent == 0xffffffffu) return;
+    const SyrkProblem& P = grp.p[ent >> 24];
+    const int64_t ti = (ent >> 12) & 0xfff, tj = ent & 0xfff;
+    const int64_t C = P.C, nhs = P.Tp / SK;
+    const uint16_t* __restrict__ Xt = P.Xt;
+    // half-stage image = 32 pieces of 1 KiB; wave w moves pieces u*4 + w, u = 0..7 (u>>1 = operand panel)
+    const char* sp0 = reinterpret_cast<const char*>(Xt + ((2 * ti) * nhs) * (HT * SK));
+    const char* sp1 = reinterpret_cast<const char*>(Xt + ((2 * ti + 1) * nhs) * (HT * SK));
+    const char* sp2 = reinterpret_cast<const char*>(Xt + ((2 * tj) * nhs) * (HT * SK));
+    const char* sp3 = reinterpret_cast<const char*>(Xt + ((2 * tj + 1) * nhs) * (HT * SK));
+    const unsigned voff0 = (unsigned)(wid * 1024 + lane * 16), voff1 = voff0 + 4096u;
+#ifdef GQ_D_NOLOAD
+#define GQ_QDL(sp, h, buf, u) (void)0
+#else
+#define GQ_QDL(sp, h, buf, u) GQ_QDL_(sp, h, buf, u)
+#endif
+#define GQ_QDL_(sp, h, buf, u)                                                                        \
+    __builtin_amdgcn_global_load_lds((glb_void*)((sp) + (int64_t)(h) * 8192 + (((u) & 1) ? voff1 : voff0)), \
+                                     (lds_void*)(smem + (buf) * S_BUF_BYTES + ((u) * 4 + wid) * 1024), 16, 0, 0)
+    const int li = lane & 31, lk = lane >> 5;
+    const unsigned lds0 = (unsigned)(uintptr_t)smem;
+    unsigned bA00, bA01, bA10, bA11, bB00, bB01, bB10, bB11;  // b<op><k16 step><+64 KiB>
+    {
+        const unsigned sw = (unsigned)((li >> 2) & 3);
+        const unsigned c0 = ((unsigned)lk ^ sw) << 4, c1 = ((2u + (unsigned)lk) ^ sw) << 4;
+        const unsigned ra = lds0 + (unsigned)(wm * 128 + li) * 64u, rb = lds0 + 16384u + (unsigned)(wn * 128 + li) * 64u;
+        bA00 = ra + c0; bA01 = bA00 + 65536u; bA10 = ra + c1; bA11 = bA10 + 65536u;
+        bB00 = rb + c0; bB01 = bB00 + 65536u; bB10 = rb + c1; bB11 = bB10 + 65536u;
+    }
+    f32x16 c00, c01, c02, c03, c10, c11, c12, c13, c20, c21, c22, c23, c30, c31, c32, c33;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        c00[e] = 0.f;
+        c01[e] = 0.f;
+        c02[e] = 0.f;
+        c03[e] = 0.f;
+        c10[e] = 0.f;
+        c11[e] = 0.f;
+        c12[e] = 0.f;
+        c13[e] = 0.f;
+        c20[e] = 0.f;
+        c21[e] = 0.f;
+        c22[e] = 0.f;
+        c23[e] = 0.f;
+        c30[e] = 0.f;
+        c31[e] = 0.f;
+        c32[e] = 0.f;
+        c33[e] = 0.f;
+    }
+    u32x4 pa0, pa1, pa2, pa3, pb0, pb1, pb2, pb3, qa0, qa1, qa2, qa3, qb0, qb1, qb2, qb3;
+#define GQ_QDSR(dst, base, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(base), "n"(off) : "memory")
+#define GQ_QLGKM1(N, x) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(x)::"memory")
+#define GQ_QLGKM2(N, x, y) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(x), "+v"(y)::"memory")
+#define GQ_QMF(c, a, b)                                                                               \
+    do {                                                                                              \
+        if constexpr (BF16) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b)); \
+        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));       \
+    } while (0)
+    // fragment reads of a set are issued a0,b0,b1,a1,b2,b3,a2,a3 and the MFMAs ordered so each needs at most
+    // one more of them; lgkmcnt(k) = "all but the youngest k LDS reads are back" (in-order return)
+#define GQ_QSTEP(X, Y, AY, BY, OFF, MID, L0, L1, L2, L3)                                              \
+    do {                                                                                              \
+        GQ_QLGKM2(6, X##a0, X##b0);                                                                   \
+        GQ_QMF(c00, X##a0, X##b0);                                                                    \
+        MID;                                                                                          \
+        GQ_QDSR(Y##a0, AY, (OFF) + 0);                                                                \
+        GQ_QLGKM1(6, X##b1);                                                                          \
+        GQ_QMF(c01, X##a0, X##b1);                                                                    \
+        GQ_QDSR(Y##b0, BY, (OFF) + 0);                                                                \
+        GQ_QLGKM1(6, X##a1);                                                                          \
+        GQ_QMF(c10, X##a1, X##b0);                                                                    \
+        GQ_QDSR(Y##b1, BY, (OFF) + 2048);                                                             \
+        GQ_QMF(c11, X##a1, X##b1);                                                                    \
+        GQ_QDSR(Y##a1, AY, (OFF) + 2048);                                                             \
+        GQ_QLGKM1(7, X##b2);                                                                          \
+        GQ_QMF(c02, X##a0, X##b2);                                                                    \
+        GQ_QDSR(Y##b2, BY, (OFF) + 4096);                                                             \
+        GQ_QLGKM1(7, X##b3);                                                                          \
+        GQ_QMF(c03, X##a0, X##b3);                                                                    \
+        GQ_QDSR(Y##b3, BY, (OFF) + 6144);                                                             \
+        GQ_QMF(c12, X##a1, X##b2);                                                                    \
+        GQ_QDSR(Y##a2, AY, (OFF) + 4096);                                                             \
+        GQ_QMF(c13, X##a1, X##b3);                                                                    \
+        GQ_QDSR(Y##a3, AY, (OFF) + 6144);                                                             \
+        GQ_QLGKM1(9, X##a2);                                                                          \
+        GQ_QMF(c20, X##a2, X##b0);                                                                    \
+        L0;                                                                                           \
+        GQ_QMF(c21, X##a2, X##b1);                                                                    \
+        GQ_QMF(c22, X##a2, X##b2);                                                                    \
+        L1;                                                                                           \
+        GQ_QMF(c23, X##a2, X##b3);                                                                    \
+        GQ_QLGKM1(8, X##a3);                                                                          \
+        GQ_QMF(c30, X##a3, X##b0);                                                                    \
+        L2;                                                                                           \
+        GQ_QMF(c31, X##a3, X##b1);                                                                    \
+        GQ_QMF(c32, X##a3, X##b2);                                                                    \
+        L3;                                                                                           \
+        GQ_QMF(c33, X##a3, X##b3);                                                                    \
+    } while (0)
+    // DMA schedule: pieces 0-3 (A panels) of half-stage n+3 in the odd step of interval n (after the
+    // barrier that retires their slot), pieces 4-7 (B panels) in the even step of interval n+1; at barrier n
+    // the loads younger than half-stage n+1's are the 8 of half-stage n+2 -> vmcnt(8).
+#define GQ_QINTERVAL(AE, BE, OFFE, AO, BO, OFFO, SLOT2, SLOT3)                                        \
+    {                                                                                                 \
+        const int64_t h2_ = n + 2 < nhs ? n + 2 : nhs - 1, h3_ = n + 3 < nhs ? n + 3 : nhs - 1;       \
+        GQ_QSTEP(p, q, AE, BE, OFFE, (void)0, GQ_QDL(sp2, h2_, SLOT2, 4), GQ_QDL(sp2, h2_, SLOT2, 5), \
+                 GQ_QDL(sp3, h2_, SLOT2, 6), GQ_QDL(sp3, h2_, SLOT2, 7));                             \
+        GQ_QSTEP(q, p, AO, BO, OFFO, asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory"),     \
+                 GQ_QDL(sp0, h3_, SLOT3, 0), GQ_QDL(sp0, h3_, SLOT3, 1), GQ_QDL(sp1, h3_, SLOT3, 2),  \
+                 GQ_QDL(sp1, h3_, SLOT3, 3));                                                         \
+        ++n;                                                                                          \
+    }
+    for (int h = 0; h < 2; ++h) {
+        const int64_t hc = h < nhs ? h : nhs - 1;
+        GQ_QDL_(sp0, hc, h, 0); GQ_QDL_(sp0, hc, h, 1); GQ_QDL_(sp1, hc, h, 2); GQ_QDL_(sp1, hc, h, 3);
+        GQ_QDL_(sp2, hc, h, 4); GQ_QDL_(sp2, hc, h, 5); GQ_QDL_(sp3, hc, h, 6); GQ_QDL_(sp3, hc, h, 7);
+    }
+    {
+        const int64_t hc = 2 < nhs ? 2 : nhs - 1;
+        GQ_QDL_(sp0, hc, 2, 0); GQ_QDL_(sp0, hc, 2, 1); GQ_QDL_(sp1, hc, 2, 2); GQ_QDL_(sp1, hc, 2, 3);
+    }
+    asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+    GQ_QDSR(pa0, bA00, 0); GQ_QDSR(pb0, bB00, 0); GQ_QDSR(pb1, bB00, 2048); GQ_QDSR(pa1, bA00, 2048);
+    GQ_QDSR(pb2, bB00, 4096); GQ_QDSR(pb3, bB00, 6144); GQ_QDSR(pa2, bA00, 4096); GQ_QDSR(pa3, bA00, 6144);
+    for (int64_t n = 0; n < nhs;) {  // nhs % 4 == 0 (Tp is padded to 128 tokens)
+        GQ_QINTERVAL(bA10, bB10, 0, bA00, bB00, 32768, 2, 3)      // slot 0, next slot 1
+        GQ_QINTERVAL(bA10, bB10, 32768, bA01, bB01, 0, 3, 0)      // slot 1, next slot 2
+        GQ_QINTERVAL(bA11, bB11, 0, bA01, bB01, 32768, 0, 1)      // slot 2, next slot 3
+        GQ_QINTERVAL(bA11, bB11, 32768, bA00, bB00, 0, 1, 2)      // slot 3, next slot 0
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+#undef GQ_QDL
+#undef GQ_QDL_
+#undef GQ_QDSR
+#undef GQ_QLGKM1
+#undef GQ_QLGKM2
+#undef GQ_QMF
+#undef GQ_QSTEP
+#undef GQ_QINTERVAL
+#ifdef GQ_D_NOEPI
+    if (P.alpha != 12345.f) return;
+#endif
+    float* __restrict__ H = P.H;
+    const float beta = P.beta, alpha = P.alpha;
+    const int lc = lane & 31, lh = lane >> 5;
+    const int64_t i0 = ti * BT + wm * 128, j0 = tj * BT + wn * 128;
+#define GQ_QSTORE(c, i, j)                                                                            \
+    do {                                                                                              \
+        const int64_t col = j0 + (j) * 32 + lc;                                                       \
+        _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                              \
+            const int64_t row = i0 + (i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;                      \
+            const float h = beta * H[row * C + col] + alpha * c[e];                                   \
+            H[row * C + col] = h;                                                                     \
+            if (ti != tj) H[col * C + row] = h;                                                       \
+        }                                                                                             \
+    } while (0)
+    GQ_QSTORE(c00, 0, 0);
+    GQ_QSTORE(c01, 0, 1);
+    GQ_QSTORE(c02, 0, 2);
+    GQ_QSTORE(c03, 0, 3);
+    GQ_QSTORE(c10, 1, 0);
+    GQ_QSTORE(c11, 1, 1);
+    GQ_QSTORE(c12, 1, 2);
+    GQ_QSTORE(c13, 1, 3);
+    GQ_QSTORE(c20, 2, 0);
+    GQ_QSTORE(c21, 2, 1);
+    GQ_QSTORE(c22, 2, 2);
+    GQ_QSTORE(c23, 2, 3);
+    GQ_QSTORE(c30, 3, 0);
+    GQ_QSTORE(c31, 3, 1);
+    GQ_QSTORE(c32, 3, 2);
+    GQ_QSTORE(c33, 3, 3);
+#undef GQ_QSTORE
+}
+
+// ------------------ 16-bit SYRK, 256x256 tiles, 16x16x32 MFMA, direct-to-LDS operand ring (default)
+// profiles/micro/mfma_power.hip: with random fp16 operands the chip is POWER-limited on MFMA work -- a
+// register-resident loop sustains 1.70 PFLOP/s with v_mfma_f32_32x32x16_f16 and 1.95 PFLOP/s with
+// v_mfma_f32_16x16x32_f16 at two waves per SIMD (2.48 PFLOP/s on all-zero data), and the SYRK kernels run
+// at 1.3-1.45 GHz.  This is syrk16_256d_kernel with the cheaper instruction: 8 waves (2 x 4), wave tile
+// 128 x 64 = 8 x 4 accumulators of 16x16 (128 VGPRs); one ds_read_b128 now returns a whole 16-row x 32-k
+// fragment (lane = row & 15, k-chunk = lane >> 4), so a k32 half-stage is ONE step of 32 MFMAs with the
+// 12 fragment reads of the next half-stage behind MFMAs 1,3,...,23, the barrier behind MFMA 0 and the 4 DMA
+// pieces of half-stage n+3 behind MFMAs 13/17/21/25.  At barrier n the loads younger than half-stage
+// n+1's are the 4 of half-stage n+2 -> vmcnt(4).  Operand image: transpose16_kernel mode 2 (chunk kc of
+// row r at kc ^ f((r >> 2) & 3), f = 0,2,3,1: conflict-free for this fragment shape).
+template <bool BF16>
+__global__ __launch_bounds__(512, 2) void syrk16_256e_kernel(const SyrkGroup grp) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 2, wn = wid & 3;
+    const uint32_t ent = grp.table[(blockIdx.x & 7) * grp.per_xcd + (blockIdx.x >> 3)];
+    if (ent == 0xffffffffu) return;
+    const SyrkProblem& P = grp.p[ent >> 24];
+    const int64_t ti = (ent >> 12) & 0xfff, tj = ent & 0xfff;
+    const int64_t C = P.C;
+    const int nhs = (int)(P.Tp / SK);
+    const uint16_t* __restrict__ Xt = P.Xt;
+    // wave-uniform panel streams (SGPR pairs) + one 32-bit per-lane byte offset that advances 8 KiB per
+    // half-stage and is clamped to the last one (keeps the vmcnt arithmetic valid in the tail)
+    const char* sp0 = reinterpret_cast<const char*>(Xt + ((2 * ti) * (int64_t)nhs) * (HT * SK));
+    const char* sp1 = reinterpret_cast<const char*>(Xt + ((2 * ti + 1) * (int64_t)nhs) * (HT * SK));
+    const char* sp2 = reinterpret_cast<const char*>(Xt + ((2 * tj) * (int64_t)nhs) * (HT * SK));
+    const char* sp3 = reinterpret_cast<const char*>(Xt + ((2 * tj + 1) * (int64_t)nhs) * (HT * SK));
+    const unsigned lds0 = (unsigned)(uintptr_t)smem;
+    const unsigned vlast = (unsigned)(nhs - 1) * 8192u + (unsigned)tid * 16u;
+    unsigned voff = (unsigned)tid * 16u;
+    const unsigned ldsw = lds0 + (unsigned)wid * 1024u;  // + slot * 32 KiB + piece * 8 KiB; hardware adds lane * 16
+#ifdef GQ_D_NOLOAD
+#define GQ_EDL(sp, slot, part) (void)0
+#else
+#define GQ_EDL(sp, slot, part) GQ_EDL_(sp, slot, part)
+#endif
+#define GQ_EDL_(sp, slot, part)                                                                       \
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"                      \
+                 :: "v"(voff), "s"(sp), "s"(ldsw + (unsigned)((slot) * S_BUF_BYTES + (part) * 8192)) : "memory")
+#define GQ_EADV() voff = voff + 8192u < vlast ? voff + 8192u : vlast
+    const int lr = lane & 15, lk = lane >> 4;
+    unsigned bA0, bA1, bB0, bB1;  // b<op><+64 KiB>
+    {
+        const unsigned sw = (0x78u >> (2 * ((lr >> 2) & 3))) & 3u;
+        const unsigned ch = ((unsigned)lk ^ sw) << 4;
+        bA0 = lds0 + (unsigned)(wm * 128 + lr) * 64u + ch;
+        bB0 = lds0 + 16384u + (unsigned)(wn * 64 + lr) * 64u + ch;
+        bA1 = bA0 + 65536u;
+        bB1 = bB0 + 65536u;
+    }
+    f32x4 c00, c01, c02, c03, c10, c11, c12, c13, c20, c21, c22, c23, c30, c31, c32, c33, c40, c41, c42, c43, c50, c51, c52, c53, c60, c61, c62, c63, c70, c71, c72, c73;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        c00[e] = 0.f;
+        c01[e] = 0.f;
+        c02[e] = 0.f;
+        c03[e] = 0.f;
+        c10[e] = 0.f;
+        c11[e] = 0.f;
+        c12[e] = 0.f;
+        c13[e] = 0.f;
+        c20[e] = 0.f;
+        c21[e] = 0.f;
+        c22[e] = 0.f;
+        c23[e] = 0.f;
+        c30[e] = 0.f;
+        c31[e] = 0.f;
+        c32[e] = 0.f;
+        c33[e] = 0.f;
+        c40[e] = 0.f;
+        c41[e] = 0.f;
+        c42[e] = 0.f;
+        c43[e] = 0.f;
+        c50[e] = 0.f;
+        c51[e] = 0.f;
+        c52[e] = 0.f;
+        c53[e] = 0.f;
+        c60[e] = 0.f;
+        c61[e] = 0.f;
+        c62[e] = 0.f;
+        c63[e] = 0.f;
+        c70[e] = 0.f;
+        c71[e] = 0.f;
+        c72[e] = 0.f;
+        c73[e] = 0.f;
+    }
+    u32x4 pa0, pa1, pa2, pa3, pa4, pa5, pa6, pa7, pb0, pb1, pb2, pb3;
+    u32x4 qa0, qa1, qa2, qa3, qa4, qa5, qa6, qa7, qb0, qb1, qb2, qb3;
+#define GQ_EDSR(dst, base, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(base), "n"(off) : "memory")
+#define GQ_ELGKM1(N, x) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(x)::"memory")
+#define GQ_ELGKM2(N, x, y) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(x), "+v"(y)::"memory")
+#define GQ_EMF(c, a, b)                                                                               \
+    do {                                                                                              \
+        if constexpr (BF16) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b)); \
+        else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));       \
+    } while (0)
+    // reads of a set are issued a0,b0,b1,b2,b3,a1..a7; lgkmcnt(k) = all but the youngest k LDS reads are back
+#define GQ_ESTEP(X, Y, AY, BY, OFF, MID, L0, L1, L2, L3)                                              \
+    do {                                                                                              \
+        GQ_ELGKM2(10, X##a0, X##b0);                                                                  \
+        GQ_EMF(c00, X##a0, X##b0);                                                                    \
+        MID;                                                                                          \
+        GQ_ELGKM1(9, X##b1);                                                                          \
+        GQ_EMF(c01, X##a0, X##b1);                                                                    \
+        GQ_EDSR(Y##a0, AY, (OFF) + 0);                                                                \
+        GQ_ELGKM1(9, X##b2);                                                                          \
+        GQ_EMF(c02, X##a0, X##b2);                                                                    \
+        GQ_ELGKM1(8, X##b3);                                                                          \
+        GQ_EMF(c03, X##a0, X##b3);                                                                    \
+        GQ_EDSR(Y##b0, BY, (OFF) + 0);                                                                \
+        GQ_ELGKM1(8, X##a1);                                                                          \
+        GQ_EMF(c10, X##a1, X##b0);                                                                    \
+        GQ_EMF(c11, X##a1, X##b1);                                                                    \
+        GQ_EDSR(Y##b1, BY, (OFF) + 1024);                                                             \
+        GQ_EMF(c12, X##a1, X##b2);                                                                    \
+        GQ_EMF(c13, X##a1, X##b3);                                                                    \
+        GQ_EDSR(Y##b2, BY, (OFF) + 2048);                                                             \
+        GQ_ELGKM1(9, X##a2);                                                                          \
+        GQ_EMF(c20, X##a2, X##b0);                                                                    \
+        GQ_EMF(c21, X##a2, X##b1);                                                                    \
+        GQ_EDSR(Y##b3, BY, (OFF) + 3072);                                                             \
+        GQ_EMF(c22, X##a2, X##b2);                                                                    \
+        GQ_EMF(c23, X##a2, X##b3);                                                                    \
+        GQ_EDSR(Y##a1, AY, (OFF) + 1024);                                                             \
+        GQ_ELGKM1(10, X##a3);                                                                         \
+        GQ_EMF(c30, X##a3, X##b0);                                                                    \
+        GQ_EMF(c31, X##a3, X##b1);                                                                    \
+        GQ_EDSR(Y##a2, AY, (OFF) + 2048);                                                             \
+        L0;                                                                                           \
+        GQ_EMF(c32, X##a3, X##b2);                                                                    \
+        GQ_EMF(c33, X##a3, X##b3);                                                                    \
+        GQ_EDSR(Y##a3, AY, (OFF) + 3072);                                                             \
+        GQ_ELGKM1(11, X##a4);                                                                         \
+        GQ_EMF(c40, X##a4, X##b0);                                                                    \
+        GQ_EMF(c41, X##a4, X##b1);                                                                    \
+        GQ_EDSR(Y##a4, AY, (OFF) + 4096);                                                             \
+        L1;                                                                                           \
+        GQ_EMF(c42, X##a4, X##b2);                                                                    \
+        GQ_EMF(c43, X##a4, X##b3);                                                                    \
+        GQ_EDSR(Y##a5, AY, (OFF) + 5120);                                                             \
+        GQ_ELGKM1(12, X##a5);                                                                         \
+        GQ_EMF(c50, X##a5, X##b0);                                                                    \
+        GQ_EMF(c51, X##a5, X##b1);                                                                    \
+        GQ_EDSR(Y##a6, AY, (OFF) + 6144);                                                             \
+        L2;                                                                                           \
+        GQ_EMF(c52, X##a5, X##b2);                                                                    \
+        GQ_EMF(c53, X##a5, X##b3);                                                                    \
+        GQ_EDSR(Y##a7, AY, (OFF) + 7168);                                                             \
+        GQ_ELGKM1(13, X##a6);                                                                         \
+        GQ_EMF(c60, X##a6, X##b0);                                                                    \
+        GQ_EMF(c61, X##a6, X##b1);                                                                    \
+        L3;                                                                                           \
+        GQ_EMF(c62, X##a6, X##b2);                                                                    \
+        GQ_EMF(c63, X##a6, X##b3);                                                                    \
+        GQ_ELGKM1(12, X##a7);                                                                         \
+        GQ_EMF(c70, X##a7, X##b0);                                                                    \
+        GQ_EMF(c71, X##a7, X##b1);                                                                    \
+        GQ_EMF(c72, X##a7, X##b2);                                                                    \
+        GQ_EMF(c73, X##a7, X##b3);                                                                    \
+    } while (0)
+#define GQ_EINTERVAL(X, Y, AY, BY, OFF, SLOT3)                                                        \
+    GQ_ESTEP(X, Y, AY, BY, OFF, asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory"),          \
+             GQ_EDL(sp0, SLOT3, 0), GQ_EDL(sp1, SLOT3, 1), GQ_EDL(sp2, SLOT3, 2), GQ_EDL(sp3, SLOT3, 3)); \
+    GQ_EADV();
+
+    for (int h = 0; h < 3; ++h) {
+        GQ_EDL_(sp0, h, 0); GQ_EDL_(sp1, h, 1); GQ_EDL_(sp2, h, 2); GQ_EDL_(sp3, h, 3);
+        GQ_EADV();
+    }
+    asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    GQ_EDSR(pa0, bA0, 0); GQ_EDSR(pb0, bB0, 0); GQ_EDSR(pb1, bB0, 1024); GQ_EDSR(pb2, bB0, 2048); GQ_EDSR(pb3, bB0, 3072);
+    GQ_EDSR(pa1, bA0, 1024); GQ_EDSR(pa2, bA0, 2048); GQ_EDSR(pa3, bA0, 3072); GQ_EDSR(pa4, bA0, 4096);
+    GQ_EDSR(pa5, bA0, 5120); GQ_EDSR(pa6, bA0, 6144); GQ_EDSR(pa7, bA0, 7168);
+    for (int n = 0; n < nhs; n += 4) {  // nhs % 4 == 0; interval n: multiply slot n & 3, read slot (n+1) & 3
+        GQ_EINTERVAL(p, q, bA0, bB0, 32768, 3)
+        GQ_EINTERVAL(q, p, bA1, bB1, 0, 0)
+        GQ_EINTERVAL(p, q, bA1, bB1, 32768, 1)
+        GQ_EINTERVAL(q, p, bA0, bB0, 0, 2)
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+#undef GQ_EDL
+#undef GQ_EDL_
+#undef GQ_EADV
+#undef GQ_EDSR
+#undef GQ_ELGKM1
+#undef GQ_ELGKM2
+#undef GQ_EMF
+#undef GQ_ESTEP
+#undef GQ_EINTERVAL
+#ifdef GQ_D_NOEPI
+    if (P.alpha != 12345.f) return;
+#endif
+    float* __restrict__ H = P.H;
+    const float beta = P.beta, alpha = P.alpha;
+    const int64_t i0 = ti * BT + wm * 128 + 4 * lk, j0 = tj * BT + wn * 64 + lr;
+#define GQ_ESTORE(c, i, j)                                                                            \
+    do {                                                                                              \
+        const int64_t col = j0 + (j) * 16;                                                            \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                               \
+            const int64_t row = i0 + (i) * 16 + e;                                                    \
+            const float h = beta * H[row * C + col] + alpha * c[e];                                   \
+            H[row * C + col] = h;                                                                     \
+            if (ti != tj) H[col * C + row] = h;                                                       \
+        }                                                                                             \
+    } while (0)
+    GQ_ESTORE(c00, 0, 0);
+    GQ_ESTORE(c01, 0, 1);
+    GQ_ESTORE(c02, 0, 2);
+    GQ_ESTORE(c03, 0, 3);
+    GQ_ESTORE(c10, 1, 0);
+    GQ_ESTORE(c11, 1, 1);
+    GQ_ESTORE(c12, 1, 2);
+    GQ_ESTORE(c13, 1, 3);
+    GQ_ESTORE(c20, 2, 0);
+    GQ_ESTORE(c21, 2, 1);
+    GQ_ESTORE(c22, 2, 2);
+    GQ_ESTORE(c23, 2, 3);
+    GQ_ESTORE(c30, 3, 0);
+    GQ_ESTORE(c31, 3, 1);
+    GQ_ESTORE(c32, 3, 2);
+    GQ_ESTORE(c33, 3, 3);
+    GQ_ESTORE(c40, 4, 0);
+    GQ_ESTORE(c41, 4, 1);
+    GQ_ESTORE(c42, 4, 2);
+    GQ_ESTORE(c43, 4, 3);
+    GQ_ESTORE(c50, 5, 0);
+    GQ_ESTORE(c51, 5, 1);
+    GQ_ESTORE(c52, 5, 2);
+    GQ_ESTORE(c53, 5, 3);
+    GQ_ESTORE(c60, 6, 0);
+    GQ_ESTORE(c61, 6, 1);
+    GQ_ESTORE(c62, 6, 2);
+    GQ_ESTORE(c63, 6, 3);
+    GQ_ESTORE(c70, 7, 0);
+    GQ_ESTORE(c71, 7, 1);
+    GQ_ESTORE(c72, 7, 2);
+    GQ_ESTORE(c73, 7, 3);
+#undef GQ_ESTORE
+}
+
 // --------------------------------------------------------------- fp32 SYRK
 // H tile = sum_t X[t, i] X[t, j]: both operands are read straight from X rows
 // (lanes walk channels), no transpose needed for one-float MFMA operands.
@@ -707,6 +1140,7 @@ int h_accumulate_grouped(int n, float* const* H, const void* const* X, const int
     bool big = getenv("GQ_SYRK_128") == nullptr;
     for (int i = 0; i < n; ++i) big = big && (C[i] % BT == 0);
     const bool direct = big && getenv("GQ_SYRK_REGSTAGE") == nullptr;  // register-staged 256 kernel: comparison only
+    const bool use_e = direct && !getenv("GQ_SYRK_Q") && !getenv("GQ_SYRK_D");  // 16x16x32 MFMA kernel (default)
     int tiles = 0;
     unsigned char* wp = reinterpret_cast<unsigned char*>(((uintptr_t)ws + 255) & ~(uintptr_t)255);
     for (int i = 0; i < n; ++i) {
@@ -717,7 +1151,7 @@ int h_accumulate_grouped(int n, float* const* H, const void* const* X, const int
             ProfScope ps(PT_TRANSPOSE, st);
             dim3 tg((unsigned)(Tp / HK), (unsigned)(C[i] / HT));
             hipLaunchKernelGGL(transpose16_kernel, tg, block, 0, st, (const uint16_t*)X[i], T[i], C[i], Xt, Tp / HK,
-                               direct ? 1 : 0);
+                               direct ? (use_e ? 2 : 1) : 0);
             GQ_LAUNCH_CHECK();
         }
         if (big) {
@@ -742,6 +1176,10 @@ int h_accumulate_grouped(int n, float* const* H, const void* const* X, const int
         GQ_HIP(hipFuncSetAttribute((const void*)syrk16_256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * B_STAGE_BYTES));
         GQ_HIP(hipFuncSetAttribute((const void*)syrk16_256d_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES));
         GQ_HIP(hipFuncSetAttribute((const void*)syrk16_256d_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES));
+        GQ_HIP(hipFuncSetAttribute((const void*)syrk16_256e_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES));
+        GQ_HIP(hipFuncSetAttribute((const void*)syrk16_256e_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES));
+        GQ_HIP(hipFuncSetAttribute((const void*)syrk16_256q_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES));
+        GQ_HIP(hipFuncSetAttribute((const void*)syrk16_256q_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES));
         attr_set = true;
     }
     std::vector<uint32_t> table;
@@ -776,7 +1214,15 @@ int h_accumulate_grouped(int n, float* const* H, const void* const* X, const int
         grp.per_xcd = per_xcd;
     }
     ProfScope ps(PT_SYRK, st);
-    if (direct) {
+    if (use_e) {
+        const dim3 grid((unsigned)(8 * grp.per_xcd)), blk(512);
+        if (x_dtype == GQ_BF16) hipLaunchKernelGGL(syrk16_256e_kernel<true>, grid, blk, S_LDS_BYTES, st, grp);
+        else hipLaunchKernelGGL(syrk16_256e_kernel<false>, grid, blk, S_LDS_BYTES, st, grp);
+    } else if (direct && getenv("GQ_SYRK_Q")) {
+        const dim3 grid((unsigned)(8 * grp.per_xcd)), blk(256);
+        if (x_dtype == GQ_BF16) hipLaunchKernelGGL(syrk16_256q_kernel<true>, grid, blk, S_LDS_BYTES, st, grp);
+        else hipLaunchKernelGGL(syrk16_256q_kernel<false>, grid, blk, S_LDS_BYTES, st, grp);
+    } else if (direct) {
         const dim3 grid((unsigned)(8 * grp.per_xcd)), blk(512);
         if (x_dtype == GQ_BF16) hipLaunchKernelGGL(syrk16_256d_kernel<true>, grid, blk, S_LDS_BYTES, st, grp);
         else hipLaunchKernelGGL(syrk16_256d_kernel<false>, grid, blk, S_LDS_BYTES, st, grp);
