@@ -134,7 +134,11 @@ def quantize_block(shapes, W16, X, owners, rank, world, q_type=Q4_K, block_size=
         if owners[name] == rank:
             groups.setdefault(inp, []).append(name)
     order = sorted(groups, key=lambda g: -sum(shapes[n][0] * shapes[n][1] * shapes[n][1] for n in groups[g]))
+    host_trace = os.environ.get("GQ_BENCH_TRACE_HOST")
+    t_host0 = time.perf_counter()
     for gi, inp in enumerate(order):
+        if host_trace:
+            print(f"  [host] +{1e3 * (time.perf_counter() - t_host0):7.2f} ms: enqueue chain {gi} ({inp}: {groups[inp]})", file=sys.stderr)
         st = streams[gi % len(streams)] if streams else main
         st.wait_event(ev_ready[inp])
         with torch.cuda.stream(st):

@@ -10,6 +10,9 @@
 //   KR:      k-range restriction for triangular operands (zeros are skipped, not multiplied):
 //            0 full; 1: k < n0+128 (B^T lower-triangular); 2: k >= n0 (B lower-triangular);
 //            3: k < m0+128 (A lower-triangular)
+//   CHAIN:   (MODE 0 only) the accumulation chain restarts every CHAIN k:  C = (..((C - A_0 B_0) - A_1 B_1)..)
+//            with A_i B_i the i-th CHAIN-wide slice of the product -- bit-identical to K/CHAIN separate
+//            MODE-0 launches, with ONE read and write of C (the GPTQ look-ahead trailing update)
 //
 // Workgroup = 256 threads = 4 waves (2x2); tile 128x128; each wave owns 64x64 = 2x2
 // MFMA tiles (64 accumulator VGPRs).  K streams in chunks of 32 through a double-buffered
@@ -84,7 +87,7 @@ __device__ __forceinline__ void g32_store_kn(const float4 (&v)[4], float* S, int
     }
 }
 
-template <bool TRANS_B, int MODE, bool LOWER, int KR = 0>
+template <bool TRANS_B, int MODE, bool LOWER, int KR = 0, int CHAIN = 0>
 __global__ __launch_bounds__(256, 2) void gemm32_kernel(float* Cmat, int64_t ldc, const float* A, int64_t lda,
                                                         const float* B, int64_t ldb, int64_t M, int64_t N, int64_t K) {
     extern __shared__ __attribute__((aligned(16))) float g32_smem[];
@@ -100,6 +103,22 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(float* Cmat, int64_t ldc
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
+    static_assert(CHAIN == 0 || (MODE == 0 && CHAIN % TK == 0 && KR == 0), "CHAIN: MODE 0, whole stages");
+    const int lc = lane & 31, lh = lane >> 5;
+    f32x16 cv[CHAIN ? 2 : 1][CHAIN ? 2 : 1];
+    if constexpr (CHAIN != 0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int64_t col = n0 + wn * 64 + j * 32 + lc;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int64_t rowi = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    cv[i][j][e] = (rowi < M && col < N) ? Cmat[rowi * ldc + col] : 0.f;
+                }
+            }
+    }
     float4 va[4], vb[4];
     auto fetch = [&](int64_t k0) {
         g32_load_rows(va, A, lda, m0, M, k0, K, tid);
@@ -144,11 +163,23 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(float* Cmat, int64_t ldc
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
+        if constexpr (CHAIN != 0) {
+            if (((t + 1) * TK) % CHAIN == 0) {  // end of a slice: one subtraction, new chain
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            cv[i][j][e] = cv[i][j][e] - acc[i][j][e];
+                            acc[i][j][e] = 0.0f;
+                        }
+            }
+        }
         if (t + 1 < nk) commit((int)((t + 1) & 1));  // the other buffer: its readers passed the last barrier
         __syncthreads();
     }
     // D layout: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
-    const int lc = lane & 31, lh = lane >> 5;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -159,7 +190,8 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(float* Cmat, int64_t ldc
                 const int64_t rowi = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
                 if (rowi < M && col < N) {
                     float* p = Cmat + rowi * ldc + col;
-                    if constexpr (MODE == 0) *p = *p - acc[i][j][e];
+                    if constexpr (CHAIN != 0) *p = cv[i][j][e];
+                    else if constexpr (MODE == 0) *p = *p - acc[i][j][e];
                     else if constexpr (MODE == 1) *p = acc[i][j][e];
                     else *p = -acc[i][j][e];
                 }
@@ -167,20 +199,21 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(float* Cmat, int64_t ldc
         }
 }
 
-template <bool TRANS_B, int MODE, bool LOWER, int KR = 0>
+template <bool TRANS_B, int MODE, bool LOWER, int KR = 0, int CHAIN = 0>
 inline int launch_gemm32(float* Cmat, int64_t ldc, const float* A, int64_t lda, const float* B, int64_t ldb, int64_t M,
                          int64_t N, int64_t K, hipStream_t st) {
     if (M <= 0 || N <= 0 || K <= 0) return GQ_OK;
     if ((lda % 4) || (ldb % 4) || ((uintptr_t)A % 16) || ((uintptr_t)B % 16))
         GQ_FAIL(GQ_E_BAD_SHAPE, "gemm32: A/B must be 16-byte aligned with ld %% 4 == 0");
+    if (CHAIN != 0 && (K % CHAIN)) GQ_FAIL(GQ_E_BAD_SHAPE, "gemm32: K=%ld is not a multiple of the chain length %d", (long)K, CHAIN);
     static bool attr_set = false;
     if (!attr_set) {
-        GQ_HIP(hipFuncSetAttribute((const void*)gemm32_kernel<TRANS_B, MODE, LOWER, KR>,
+        GQ_HIP(hipFuncSetAttribute((const void*)gemm32_kernel<TRANS_B, MODE, LOWER, KR, CHAIN>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, G32_LDS_BYTES));
         attr_set = true;
     }
     dim3 grid((unsigned)((N + TN - 1) / TN), (unsigned)((M + TM - 1) / TM)), block(256);
-    hipLaunchKernelGGL((gemm32_kernel<TRANS_B, MODE, LOWER, KR>), grid, block, G32_LDS_BYTES, st, Cmat, ldc, A, lda, B, ldb,
+    hipLaunchKernelGGL((gemm32_kernel<TRANS_B, MODE, LOWER, KR, CHAIN>), grid, block, G32_LDS_BYTES, st, Cmat, ldc, A, lda, B, ldb,
                        M, N, K);
     GQ_LAUNCH_CHECK();
     return GQ_OK;

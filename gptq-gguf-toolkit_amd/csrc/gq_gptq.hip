@@ -9,6 +9,7 @@
 // sgemm computes per element -- verified bit-for-bit in tests/golden G6).
 #include "gq_common.hpp"
 #include "gq_gemm32.hpp"
+#include <stdlib.h>
 
 namespace gq {
 
@@ -172,9 +173,14 @@ int launch_trailing_update(float* Cmat, int64_t ldc, const float* A, int64_t lda
 }
 
 // ------------------------------------------------------------- orchestration
+// Look-ahead depth of the trailing update (blocks of 128 columns per super-block), see gptq_quantize.
+constexpr int LA = 8;
+constexpr int LA_B = 128;  // only this block size takes the look-ahead path (the chain length is a template constant)
+
 size_t gptq_workspace_bytes(int64_t R, int64_t C, int block_size) {
     int64_t B = block_size <= 0 || block_size > C ? C : block_size;
     size_t err = (size_t)R * (size_t)B * sizeof(float);
+    if (B == LA_B) err *= LA;  // super-block error buffer [R, LA * B]
     size_t blk = B > SEG ? (size_t)R * (size_t)B * sizeof(float) : 0;
     return err + blk + 256;
 }
@@ -191,8 +197,21 @@ int gptq_quantize(float* W, const float* U, int64_t R, int64_t C, int q_type, in
     if (q_type == GQ_Q3_K) static_groups = 0;  // gptq.py:204-206
     const size_t need = gptq_workspace_bytes(R, C, (int)B);
     if (!ws || ws_bytes < need) GQ_FAIL(GQ_E_WORKSPACE, "gq_gptq_quantize: workspace %zu < %zu bytes", ws_bytes, need);
+    // Look-ahead trailing update (B == 128): the blocks of a super-block of LA blocks write their errors
+    // side by side into one [R, LA*128] buffer.  After each block only the REST OF THE SUPER-BLOCK is
+    // updated (a small GEMM); at the end of the super-block everything beyond it is updated by ONE chained
+    // GEMM (CHAIN = 128): per element ((w - E_0 U_0) - E_1 U_1) - ..., the same operations in the same
+    // order as gptq.py:270 applied block after block, with one read and one write of W instead of LA.
+    // (Deferring the far part to a helper stream, to overlap it with the next super-block's column loop,
+    // measured no gain alone and -8 % inside a block's multi-stream schedule: its long K = 1024 tiles keep
+    // the column-loop workgroups, which need a whole CU's LDS, waiting.)
+    const bool lookahead = (B == LA_B) && getenv("GQ_NO_LOOKAHEAD") == nullptr;
+    int la = LA;
+    // tuning knob; even only: a 256-column scale-search group must not straddle two super-blocks
+    if (const char* e = getenv("GQ_LA")) la = (atoi(e) >= 2 && atoi(e) <= LA && atoi(e) % 2 == 0) ? atoi(e) : LA;
+    const int64_t ldE = lookahead ? (int64_t)LA * B : B;
     float* Err = reinterpret_cast<float*>(((uintptr_t)ws + 255) & ~(uintptr_t)255);
-    float* Wblk = Err + (size_t)R * B;
+    float* Wblk = Err + (size_t)R * B * (lookahead ? LA : 1);
     const int64_t ng = C / ti.group, nsg = C / 256;
     const int gps = 256 / ti.group;
     int rc;
@@ -215,6 +234,7 @@ int gptq_quantize(float* W, const float* U, int64_t R, int64_t C, int q_type, in
         // one segment iff the block fits in LDS and stays inside one 256-column super-group
         const bool single = (c2 - c1) <= SEG && (c1 / 256 == (c2 - 1) / 256);
         const int64_t ncols = c2 - c1;
+        const int64_t bi = c1 / B, sb = bi / la, pos = lookahead ? bi % la : 0;  // block, super-block, slot
         if (!single) {  // w_blk lives in scratch
             ProfScope ps(PT_BLOCK_FAR, st);
             hipLaunchKernelGGL(copy2d_kernel, dim3(2048), dim3(256), 0, st, Wblk, B, W + c1, C, R, ncols);
@@ -241,21 +261,36 @@ int gptq_quantize(float* W, const float* U, int64_t R, int64_t C, int q_type, in
             {
                 ProfScope ps(PT_GPTQ_SEGMENT, st);
                 hipLaunchKernelGGL(gptq_segment_kernel, seg_grid, seg_block, SEG_LDS_BYTES, st, W, C, srcp, ld_src, U, a, len, R, d,
-                                   s, dmin, m, ti.group, ti.is_signed, (float)ti.qmin, (float)ti.qmax, qweight, Err, B,
-                                   a - c1);
+                                   s, dmin, m, ti.group, ti.is_signed, (float)ti.qmin, (float)ti.qmax, qweight, Err, ldE,
+                                   pos * B + (a - c1));
                 GQ_LAUNCH_CHECK();
             }
             if (e < c2) {  // push this segment's rank-1 updates into the rest of the block
                 ProfScope ps(PT_BLOCK_FAR, st);
                 hipLaunchKernelGGL(block_far_update_kernel, dim3(2048), dim3(256), 0, st, Wblk + (e - c1), B,
-                                   c2 - e, R, Err, B, a - c1, len, U, C, a, e);
+                                   c2 - e, R, Err, ldE, a - c1, len, U, C, a, e);
                 GQ_LAUNCH_CHECK();
             }
             a = e;
         }
         // gptq.py:270
-        if (c2 < C)
+        if (c2 >= C) break;
+        if (!lookahead) {
             if ((rc = launch_trailing_update(W + c2, C, Err, B, U + c1 * C + c2, C, R, C - c2, ncols, st))) return rc;
+            continue;
+        }
+        const int64_t S0 = sb * la * B, S1 = (S0 + la * B < C) ? S0 + la * B : C;  // this super-block
+        if (c2 < S1) {  // rest of the super-block, this block's errors only
+            if ((rc = launch_trailing_update(W + c2, C, Err + pos * B, ldE, U + c1 * C + c2, C, R, S1 - c2, ncols, st)))
+                return rc;
+            continue;
+        }
+        // end of the super-block: all its blocks at once, every later column
+        {
+            ProfScope ps(PT_TRAILING, st);
+            if ((rc = launch_gemm32<false, 0, false, 0, LA_B>(W + S1, C, Err, ldE, U + S0 * C + S1, C, R, C - S1, S1 - S0, st)))
+                return rc;
+        }
     }
     return GQ_OK;
 }
