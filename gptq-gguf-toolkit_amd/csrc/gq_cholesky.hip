@@ -17,6 +17,7 @@
 
 #include "gq_common.hpp"
 #include "gq_gemm32.hpp"
+#include "gq_gemm3b.hpp"
 
 namespace gq {
 
@@ -413,15 +414,22 @@ static int chol_inv_rec(float* A, float* X, float* Tmp, int* flag, int64_t n, in
     if ((rc = chol_inv_rec(A, X, Tmp, flag, n, lo, mid, diag_lds, st))) return rc;
     const int64_t n1 = (mid - lo) * NB, n2 = (hi - mid) * NB;
     const int64_t o21 = (mid * NB) * n + lo * NB, o11 = (lo * NB) * n + lo * NB, o22 = (mid * NB) * n + mid * NB;
+    // large nodes: fp32-accurate products on the bf16 matrix cores (gq_gemm3b.hpp); small ones are
+    // latency-bound and stay on the fp32 instruction
+    static const int64_t min3b = getenv("GQ_CHOL_FP32") ? (int64_t)1 << 40 : (getenv("GQ_CHOL_3B_MIN") ? atol(getenv("GQ_CHOL_3B_MIN")) : 512);
+    const bool big = n1 >= min3b && n2 >= min3b;
+#define GQ_CHOL_GEMM(TB, MODE, LOW, KRV, ...) \
+    (big ? launch_gemm3b<TB, MODE, LOW, KRV>(__VA_ARGS__) : launch_gemm32<TB, MODE, LOW, KRV>(__VA_ARGS__))
     {
         ProfScope ps(PT_CHOL_GEMM, st);
-        if ((rc = launch_gemm32<true, 1, false, 1>(Tmp + o21, n, A + o21, n, X + o11, n, n2, n1, n1, st))) return rc;
-        if ((rc = launch_gemm32<true, 0, true, 0>(A + o22, n, Tmp + o21, n, Tmp + o21, n, n2, n2, n1, st))) return rc;
+        if ((rc = GQ_CHOL_GEMM(true, 1, false, 1, Tmp + o21, n, A + o21, n, X + o11, n, n2, n1, n1, st))) return rc;
+        if ((rc = GQ_CHOL_GEMM(true, 0, true, 0, A + o22, n, Tmp + o21, n, Tmp + o21, n, n2, n2, n1, st))) return rc;
     }
     if ((rc = chol_inv_rec(A, X, Tmp, flag, n, mid, hi, diag_lds, st))) return rc;
     ProfScope ps(PT_TRTRI_GEMM, st);
-    if ((rc = launch_gemm32<false, 1, false, 2>(A + o21, n, Tmp + o21, n, X + o11, n, n2, n1, n1, st))) return rc;
-    return launch_gemm32<false, 2, false, 3>(X + o21, n, X + o22, n, A + o21, n, n2, n1, n2, st);
+    if ((rc = GQ_CHOL_GEMM(false, 1, false, 2, A + o21, n, Tmp + o21, n, X + o11, n, n2, n1, n1, st))) return rc;
+    return GQ_CHOL_GEMM(false, 2, false, 3, X + o21, n, X + o22, n, A + o21, n, n2, n1, n2, st);
+#undef GQ_CHOL_GEMM
 }
 
 int w_prepare(const uint8_t* flags, float* W, int64_t R, int64_t C, int* mismatch, hipStream_t st) {

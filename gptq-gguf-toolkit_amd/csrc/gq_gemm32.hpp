@@ -91,10 +91,13 @@ template <bool TRANS_B, int MODE, bool LOWER, int KR = 0, int CHAIN = 0>
 __global__ __launch_bounds__(256, 2) void gemm32_kernel(float* Cmat, int64_t ldc, const float* A, int64_t lda,
                                                         const float* B, int64_t ldb, int64_t M, int64_t N, int64_t K) {
     extern __shared__ __attribute__((aligned(16))) float g32_smem[];
-    if (LOWER && blockIdx.x > blockIdx.y) return;
+    // triangular k-ranges make tile cost grow with n0 (KR 1) or m0 (KR 3): dispatch the long tiles first
+    const unsigned bx = (KR == 1) ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
+    const unsigned by = (KR == 3) ? gridDim.y - 1 - blockIdx.y : blockIdx.y;
+    if (LOWER && bx > by) return;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
-    const int64_t m0 = (int64_t)blockIdx.y * TM, n0 = (int64_t)blockIdx.x * TN;
+    const int64_t m0 = (int64_t)by * TM, n0 = (int64_t)bx * TN;
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
