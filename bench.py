@@ -38,6 +38,7 @@ sys.path.insert(0, ROOT)
 from gptq_gguf_toolkit_amd import _cabi, dist_utils, ops  # noqa: E402
 
 Q4_K = 12
+SYRK_TRAFFIC_GB_PER_LAUNCH = 70.85  # (117.9 + 23.8) / 2, see profiles/r01_syrk_pmc.txt
 # Llama-3-8B block: name -> (R, C, input group)
 LLAMA3_8B = {
     "q_proj": (4096, 4096, "attn_in"), "k_proj": (1024, 4096, "attn_in"), "v_proj": (1024, 4096, "attn_in"),
@@ -304,7 +305,12 @@ def main():
         ach = flops / (syrk_ms * 1e-3) / 1e12 if syrk_ms > 0 else None
         roof = {"bound": "mfma", "kernel": "syrk16_256e_kernel<f16> (gq_h_accumulate_grouped)",
                 "achieved": round(ach, 2) if ach else None, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_F16_MFMA_TFLOPS, 4) if ach else None, "traffic": None,
+                "frac": round(ach / PEAK_F16_MFMA_TFLOPS, 4) if ach else None,
+                # PMC cannot be read live: L2-miss reads per SYRK launch (rocprofv3 --pmc FETCH_SIZE on this very
+                # command, x2 gfx950 correction; profiles/r01_syrk_pmc.txt), average of the step's two launches
+                "traffic": SYRK_TRAFFIC_GB_PER_LAUNCH if (args.workload == "llama3-8b-block-q4k" and world == 1
+                                                          and not args.calib_seqs and not args.seq_len) else None,
+                "traffic_unit": "GB/launch",
                 "launches": syrk_n, "busy_ms_per_step": round(syrk_ms / args.steps, 3),
                 "avg_launch_ms": round(syrk_sum_ms / max(syrk_n, 1), 4),
                 "share_of_step": round(syrk_ms / 1e3 / dt, 3)}
