@@ -8,8 +8,8 @@
 // first; each bf16 x bf16 product is exact in fp32).  The dropped terms are <= 2^-23 |a b|, the size of
 // one fp32 rounding, so the result has fp32-GEMM accuracy at 6/16 of the MFMA cost of the fp32
 // instruction.  NOT bit-identical to gq_gemm32.hpp: the GPTQ trailing update (parity gate: bit-exact
-// against the reference's sgemm chain) never uses this file; U = chol(H^-1) is checked against the
-// fp64 oracle with an fp32 tolerance (tests/test_gpu_parity.py).
+// against the reference's sgemm chain) never uses this file; U = chol(H^-1) is checked in fp64
+// with an fp32 tolerance (tests/test_gpu_parity.py).
 //
 // Same interface and modes as gemm32_kernel (MODE 0/1/2, TRANS_B, LOWER, KR; no CHAIN).
 // Workgroup = 256 threads = 4 waves (2x2), tile 128x128, wave tile 64x64 = 2x2 MFMA tiles.  K streams in
