@@ -20,7 +20,7 @@ int launch_trailing_update(float*, int64_t, const float*, int64_t, const float*,
                            hipStream_t);
 size_t gptq_workspace_bytes(int64_t, int64_t, int);
 int gptq_quantize(float*, const float*, int64_t, int64_t, int, int, int, const gq_search_t*, uint8_t*, uint16_t*,
-                  uint8_t*, uint16_t*, uint8_t*, void*, size_t, hipStream_t);
+                  uint8_t*, uint16_t*, uint8_t*, void*, size_t, hipStream_t, const int32_t*);
 size_t h_accumulate_workspace_bytes(int64_t, int64_t);
 int h_accumulate(float*, const void*, int, int64_t, int64_t, float, float, void*, size_t, hipStream_t);
 int h_accumulate_grouped(int, float* const*, const void* const*, const int64_t*, const int64_t*, const float*, const float*,
@@ -126,7 +126,15 @@ int gq_gptq_quantize(float* W, const float* U, int64_t R, int64_t C, int q_type,
                      const gq_search_t* p, uint8_t* qweight, uint16_t* d, uint8_t* s, uint16_t* dmin, uint8_t* m,
                      void* ws, size_t ws_bytes, void* stream) {
     return gptq_quantize(W, U, R, C, q_type, block_size, static_groups, p, qweight, d, s, dmin, m, ws, ws_bytes,
-                         (hipStream_t)stream);
+                         (hipStream_t)stream, nullptr);
+}
+
+int gq_gptq_quantize_perm(float* W, const float* U, int64_t R, int64_t C, int q_type, int block_size, const int32_t* perm,
+                          const uint16_t* d, const uint8_t* s, const uint16_t* dmin, const uint8_t* m, uint8_t* qweight,
+                          void* ws, size_t ws_bytes, void* stream) {
+    if (!perm) GQ_FAIL(GQ_E_NULL, "gq_gptq_quantize_perm: null perm");
+    return gptq_quantize(W, U, R, C, q_type, block_size, 1, nullptr, qweight, const_cast<uint16_t*>(d), const_cast<uint8_t*>(s),
+                         const_cast<uint16_t*>(dmin), const_cast<uint8_t*>(m), ws, ws_bytes, (hipStream_t)stream, perm);
 }
 
 int gq_rtn_quantize(const void* W, int w_dtype, int64_t R, int64_t C, int q_type, const gq_search_t* p,

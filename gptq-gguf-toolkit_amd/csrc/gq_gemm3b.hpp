@@ -80,7 +80,7 @@ __device__ __forceinline__ void g3_store_kn(const float (&v)[16], unsigned char*
 }
 
 template <bool TRANS_B, int MODE, bool LOWER, int KR = 0>
-__global__ __launch_bounds__(256, 2) void gemm3b_kernel(float* Cmat, int64_t ldc, const float* A, int64_t lda,
+__global__ __launch_bounds__(256, TRANS_B ? 3 : 2) void gemm3b_kernel(float* Cmat, int64_t ldc, const float* A, int64_t lda,
                                                         const float* B, int64_t ldb, int64_t M, int64_t N, int64_t K) {
     extern __shared__ __attribute__((aligned(16))) unsigned char g3_smem[];
     const unsigned bx = (KR == 1) ? gridDim.x - 1 - blockIdx.x : blockIdx.x;  // long tiles first

@@ -30,12 +30,15 @@ constexpr int SEG = 128;
 constexpr int SB = 16;  // register sub-block
 constexpr int SEG_LDS_BYTES = (SEG * 64 + SEG * SEG + SB * 64) * 4;
 
+template <bool PERM>
 __global__ __launch_bounds__(256) void gptq_segment_kernel(
     float* W, int64_t C, const float* src, int64_t ld_src,  // may alias (single-segment blocks)
     const float* __restrict__ U, int64_t a, int len, int64_t R,
     const uint16_t* __restrict__ d, const uint8_t* __restrict__ s, const uint16_t* __restrict__ dmin,
     const uint8_t* __restrict__ m, int G, int is_signed, float qmin, float qmax,
-    uint8_t* __restrict__ qweight, float* __restrict__ Err, int64_t ld_err, int64_t err_col0) {
+    uint8_t* __restrict__ qweight, float* __restrict__ Err, int64_t ld_err, int64_t err_col0,
+    const int32_t* __restrict__ perm) {  // PERM (act_order, gptq.py:211-216): column j takes the parameters of
+                                         // the group of its ORIGINAL column perm[j]
     // One workgroup = 64 rows (lane = row) x 4 waves.  Wave 0 walks the columns (the dependent chain);
     // after every 16-column sub-block all four waves share the rank-1 updates of the later columns.
     extern __shared__ __attribute__((aligned(16))) float seg_smem[];
@@ -73,8 +76,18 @@ __global__ __launch_bounds__(256) void gptq_segment_kernel(
         if (wid == 0) {
             const int64_t col0 = a + i0;
             // group parameters are constant over a 16-aligned run of 16 columns
-            const float ds = h2f(d[r * nsg + col0 / 256]) * ival(s[r * ng + col0 / G], is_signed);
-            const float dm = h2f(dmin[r * nsg + col0 / 256]) * ival(m[r * ng + col0 / G], is_signed);
+            float ds = 0.f, dm = 0.f, dsv[PERM ? SB : 1], dmv[PERM ? SB : 1];
+            if constexpr (PERM) {
+#pragma unroll
+                for (int k = 0; k < SB; ++k) {
+                    const int64_t pc = perm[col0 + k];
+                    dsv[k] = h2f(d[r * nsg + pc / 256]) * ival(s[r * ng + pc / G], is_signed);
+                    dmv[k] = h2f(dmin[r * nsg + pc / 256]) * ival(m[r * ng + pc / G], is_signed);
+                }
+            } else {
+                ds = h2f(d[r * nsg + col0 / 256]) * ival(s[r * ng + col0 / G], is_signed);
+                dm = h2f(dmin[r * nsg + col0 / 256]) * ival(m[r * ng + col0 / G], is_signed);
+            }
             float wr[SB], nerr[SB], wq[SB];
             uint32_t qpack[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -83,6 +96,7 @@ __global__ __launch_bounds__(256) void gptq_segment_kernel(
             for (int k = 0; k < SB; ++k) {
                 const float* urow = Us + (i0 + k) * SEG + i0;  // wave-uniform LDS address (broadcast)
                 const float dii = urow[k];
+                if constexpr (PERM) { ds = dsv[k]; dm = dmv[k]; }
                 const float q = quantize1(wr[k], ds, dm, qmin, qmax);  // gptq.py:247-254
                 wq[k] = dequantize1(q, ds, dm);                        // :255-261
                 const float err = (wr[k] - wq[k]) / dii;               // :264
@@ -185,16 +199,21 @@ size_t gptq_workspace_bytes(int64_t R, int64_t C, int block_size) {
     return err + blk + 256;
 }
 
+// perm != nullptr: act_order (gptq.py:208-216, 233-235, 272-276).  W and U are already in permuted
+// order, d/s/dmin/m are INPUTS (the static scales of the original column groups, gptq.py:184-196) and
+// qweight comes back in permuted positions; the caller un-permutes it.
 int gptq_quantize(float* W, const float* U, int64_t R, int64_t C, int q_type, int block_size, int static_groups,
                   const gq_search_t* p, uint8_t* qweight, uint16_t* d, uint8_t* s, uint16_t* dmin, uint8_t* m,
-                  void* ws, size_t ws_bytes, hipStream_t st) {
+                  void* ws, size_t ws_bytes, hipStream_t st, const int32_t* perm) {
     TypeInfo ti;
     if (!type_info(q_type, ti)) GQ_FAIL(GQ_E_BAD_TYPE, "gq_gptq_quantize: unknown q_type %d", q_type);
     if (R <= 0 || C <= 0 || C % 256) GQ_FAIL(GQ_E_BAD_SHAPE, "gq_gptq_quantize: R=%ld C=%ld (C %% 256 != 0)", (long)R, (long)C);
     if (!W || !U || !qweight || !d || !s || !dmin || !m) GQ_FAIL(GQ_E_NULL, "gq_gptq_quantize: null pointer");
     const int64_t B = block_size <= 0 || block_size > C ? C : block_size;  // gptq.py:54
     if (B % SB) GQ_FAIL(GQ_E_UNSUPPORTED, "gq_gptq_quantize: block_size %ld is not a multiple of 16", (long)B);
+    if (q_type == GQ_Q3_K && perm) GQ_FAIL(GQ_E_UNSUPPORTED, "gq_gptq_quantize_perm: Q3_K forces act_order off (gptq.py:204-206)");
     if (q_type == GQ_Q3_K) static_groups = 0;  // gptq.py:204-206
+    if (perm) static_groups = 2;  // scales are inputs: neither the up-front nor the lazy search runs
     const size_t need = gptq_workspace_bytes(R, C, (int)B);
     if (!ws || ws_bytes < need) GQ_FAIL(GQ_E_WORKSPACE, "gq_gptq_quantize: workspace %zu < %zu bytes", ws_bytes, need);
     // Look-ahead trailing update (B == 128): the blocks of a super-block of LA blocks write their errors
@@ -216,7 +235,7 @@ int gptq_quantize(float* W, const float* U, int64_t R, int64_t C, int q_type, in
     const int gps = 256 / ti.group;
     int rc;
 
-    if (static_groups) {  // gptq.py:184-196: all scales from the ORIGINAL W
+    if (static_groups == 1) {  // gptq.py:184-196: all scales from the ORIGINAL W
         for (int64_t c = 0; c < C; c += 256)
             if ((rc = launch_scale_search(W + c, R, C, q_type, p, d + c / 256, nsg, s + (c / 256) * gps, ng,
                                           dmin + c / 256, nsg, m + (c / 256) * gps, ng, st)))
@@ -225,7 +244,9 @@ int gptq_quantize(float* W, const float* U, int64_t R, int64_t C, int q_type, in
     const dim3 seg_grid((unsigned)((R + 63) / 64)), seg_block(256);
     static bool seg_attr = false;
     if (!seg_attr) {
-        GQ_HIP(hipFuncSetAttribute((const void*)gptq_segment_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+        GQ_HIP(hipFuncSetAttribute((const void*)gptq_segment_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   SEG_LDS_BYTES));
+        GQ_HIP(hipFuncSetAttribute((const void*)gptq_segment_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    SEG_LDS_BYTES));
         seg_attr = true;
     }
@@ -260,9 +281,14 @@ int gptq_quantize(float* W, const float* U, int64_t R, int64_t C, int q_type, in
             const int64_t ld_src = single ? C : B;
             {
                 ProfScope ps(PT_GPTQ_SEGMENT, st);
-                hipLaunchKernelGGL(gptq_segment_kernel, seg_grid, seg_block, SEG_LDS_BYTES, st, W, C, srcp, ld_src, U, a, len, R, d,
-                                   s, dmin, m, ti.group, ti.is_signed, (float)ti.qmin, (float)ti.qmax, qweight, Err, ldE,
-                                   pos * B + (a - c1));
+                if (perm)
+                    hipLaunchKernelGGL(gptq_segment_kernel<true>, seg_grid, seg_block, SEG_LDS_BYTES, st, W, C, srcp, ld_src, U, a,
+                                       len, R, d, s, dmin, m, ti.group, ti.is_signed, (float)ti.qmin, (float)ti.qmax, qweight, Err,
+                                       ldE, pos * B + (a - c1), perm);
+                else
+                    hipLaunchKernelGGL(gptq_segment_kernel<false>, seg_grid, seg_block, SEG_LDS_BYTES, st, W, C, srcp, ld_src, U, a,
+                                       len, R, d, s, dmin, m, ti.group, ti.is_signed, (float)ti.qmin, (float)ti.qmax, qweight, Err,
+                                       ldE, pos * B + (a - c1), perm);
                 GQ_LAUNCH_CHECK();
             }
             if (e < c2) {  // push this segment's rank-1 updates into the rest of the block

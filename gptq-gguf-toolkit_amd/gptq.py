@@ -166,10 +166,35 @@ class GPTQ:
             self.act_order = False
             self.static_groups = False
         if self.act_order:
-            raise NotImplementedError("act_order (gptq.py:211-216, off in run_quant.sh) is not implemented")
+            return self._compute_act_order(q_type)
         U = self._prepare()
         return _ops.gptq_quantize(self.W, U, int(q_type), self.block_size, self.static_groups, self.rmin,
                                   self.rdelta, self.nstep)
+
+    @torch.no_grad()
+    def _compute_act_order(self, q_type: GGMLQuantizationType):
+        """act_order=True (reference gptq.py:208-216, 233-235, 272-276; implies static_groups, :45-46).
+        Columns are walked in descending diag(H) order; every column keeps the STATIC scale of its original
+        group.  The reference permutes after quantization_pre_step, i.e. dead channels already count with
+        H_ii = 1 and their weights are 0 (gptq.py:133-137) -- both done here before the permutation because
+        gq_h_prepare, which normally applies them, only sees the permuted operands."""
+        H = self.H
+        diag = torch.diagonal(H).clone()
+        dead = diag == 0
+        diag[dead] = 1.0                                   # gptq.py:134
+        self.W[:, dead] = 0                                # gptq.py:136
+        # torch.argsort is not stable in the reference either; ties only occur between dead channels, whose
+        # rows/columns of H and columns of W are identical, so their relative order cannot change a result
+        perm = torch.argsort(diag, descending=True, stable=True)
+        _, d, s, dmin, m = _ops.rtn_quantize(self.W, int(q_type), self.rmin, self.rdelta, self.nstep)  # :184-196
+        Wp = self.W[:, perm].contiguous()                  # :213
+        Hp = H[perm][:, perm].contiguous()                 # :214 (a copy: shared Hessians stay untouched)
+        U, self._flag = _ops.h_prepare(Hp, Wp, self.rel_damp)
+        qp = _ops.gptq_quantize_perm(Wp, U, int(q_type), perm.to(torch.int32).contiguous(), d, s, dmin, m,
+                                     block_size=self.block_size)
+        self.W = Wp                                        # the reference leaves self.W permuted
+        q = qp[:, torch.argsort(perm)].contiguous()        # :274-276
+        return q, d, s, dmin, m
 
     def _empty_result(self, q_type):
         bits, clamp, scale_maxq, group_size, supergroup_size, sz_dtype, q_dtype = GGML_QUANT_SIZES[q_type]

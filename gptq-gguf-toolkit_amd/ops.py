@@ -204,6 +204,26 @@ def gptq_quantize(W: torch.Tensor, U: torch.Tensor, q_type: int, block_size=128,
     return q.view(t), d, s.view(t), dmin, m.view(t)
 
 
+def gptq_quantize_perm(W: torch.Tensor, U: torch.Tensor, q_type: int, perm: torch.Tensor, d, s, dmin, m, block_size=128,
+                       ws: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """GPTQ.step body with act_order (gptq.py:208-216, 233-235).  W (fp32) and U are already permuted by `perm`
+    (int32 [C], original column of each position); (d, s, dmin, m) are the static scales of the ORIGINAL column
+    groups.  W becomes the dequantized matrix (permuted); returns qweight in permuted positions."""
+    _need_cuda(W, U, perm, d, s, dmin, m)
+    assert W.dtype == torch.float32 and U.dtype == torch.float32 and W.is_contiguous() and U.is_contiguous()
+    assert perm.dtype == torch.int32 and perm.is_contiguous() and perm.numel() == W.shape[1]
+    R, C = W.shape
+    q = torch.empty(R, C, dtype=torch.uint8, device=W.device)
+    bs = int(block_size or 0)
+    need = workspace_bytes(_cabi.WS_GPTQ_QUANTIZE, R, C, 0, bs)
+    if ws is None or ws.numel() < need:
+        ws = _ws(need, W.device)
+    check(lib().gq_gptq_quantize_perm(_ptr(W), _ptr(U), R, C, int(q_type), bs, _ptr(perm), _ptr(d.contiguous()),
+                                      _ptr(s.contiguous()), _ptr(dmin.contiguous()), _ptr(m.contiguous()), _ptr(q),
+                                      _ptr(ws), ws.numel(), _stream(W)), "gq_gptq_quantize_perm")
+    return q.view(_idt(q_type))
+
+
 def rtn_quantize(W: torch.Tensor, q_type: int, rmin=-1.0, rdelta=0.1, nstep=20):
     _need_cuda(W)
     assert W.is_contiguous() and W.dim() == 2 and W.dtype in _DT

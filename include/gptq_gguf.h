@@ -128,12 +128,21 @@ int gq_group_search(const void* x, int x_dtype, int64_t rows, int64_t ld, int q_
 /* replaces gptq.py:145-276 (the rank-0 body of GPTQ.step): blocked column-wise
    quantize + error feedback + trailing update.  W (fp32 working copy) becomes the
    dequantized matrix; U is chol_upper(H^-1).  block_size <= 0 means C.
-   Requires block_size % 16 == 0.  act_order (gptq.py:211-216) is a host-side
-   permutation of W/H/qweight and is done by the caller. */
+   Requires block_size % 16 == 0.  act_order: gq_gptq_quantize_perm below. */
 int gq_gptq_quantize(float* W, const float* U, int64_t R, int64_t C, int q_type,
                      int block_size, int static_groups, const gq_search_t* p_host,
                      uint8_t* qweight, uint16_t* d, uint8_t* s, uint16_t* dmin, uint8_t* m,
                      void* ws, size_t ws_bytes, void* stream);
+
+/* GPTQ.step with act_order=True (gptq.py:208-216, 233-235, 272-276; implies static_groups, gptq.py:45-46;
+   not for Q3_K, gptq.py:204-206).  The caller permutes: perm = argsort(diag(H), descending) (int32 [C], on the
+   device), W <- W[:, perm], H <- H[perm][:, perm], U = gq_h_prepare(H, W).  d/s/dmin/m are INPUTS: the static
+   scales of the ORIGINAL column groups (gq_scale_search on the unpermuted W, gptq.py:184-196); column j is
+   quantized with the parameters of group perm[j]/G of super-group perm[j]/256.  qweight comes back in
+   permuted positions (the caller applies argsort(perm)); W becomes the dequantized matrix, permuted. */
+int gq_gptq_quantize_perm(float* W, const float* U, int64_t R, int64_t C, int q_type, int block_size,
+                          const int32_t* perm, const uint16_t* d, const uint8_t* s, const uint16_t* dmin,
+                          const uint8_t* m, uint8_t* qweight, void* ws, size_t ws_bytes, void* stream);
 
 /* replaces quantizer.py:278-330 (_quant_non_block_module, RTN for embed/lm_head).
    W in w_dtype; GQ_F32 follows the fp32 arithmetic of the reference run with

@@ -378,10 +378,14 @@ float gqo_dequantize1(float q, uint16_t d, int s, uint16_t dmin, int m) {
 
 /* ------------------------------------------------------------ GPTQ step */
 
-void gqo_gptq_step(float* W, const float* U, int64_t R, int64_t C, int q_type,
-                   int block_size, int static_groups,
-                   double rmin, double rdelta, int nstep,
-                   uint8_t* qweight, uint16_t* d, uint8_t* s, uint16_t* dmin, uint8_t* m) {
+/* perm != NULL: act_order (gptq.py:208-216): W/U are in permuted order, d/s/dmin/m hold the static scales of
+   the ORIGINAL column groups (inputs), column `col` uses the groups of original column perm[col]
+   (group_idx / super_group_idx of gptq.py:215-216, looked up at :233-235). */
+static void gptq_step_impl(float* W, const float* U, int64_t R, int64_t C, int q_type,
+                           int block_size, int static_groups,
+                           double rmin, double rdelta, int nstep,
+                           uint8_t* qweight, uint16_t* d, uint8_t* s, uint16_t* dmin, uint8_t* m,
+                           const int32_t* perm) {
     gqo_type_info_t ti;
     if (gqo_type_info(q_type, &ti)) return;
     const int G = ti.group;
@@ -389,8 +393,9 @@ void gqo_gptq_step(float* W, const float* U, int64_t R, int64_t C, int q_type,
     const int gps = 256 / G;
     if (block_size <= 0) block_size = (int)C; /* gptq.py:54 */
     if (q_type == GQO_Q3_K) static_groups = 0; /* gptq.py:204-206 */
+    if (perm) static_groups = 2;
 
-    if (static_groups) { /* gptq.py:184-196 */
+    if (static_groups == 1) { /* gptq.py:184-196 */
         for (int64_t c = 0; c < C; c += 256)
             gqo_scale_search(W + c, R, C, q_type, rmin, rdelta, nstep, d + c / 256, nsg,
                              s + (c / 256) * gps, ng, dmin + c / 256, nsg, m + (c / 256) * gps, ng);
@@ -406,7 +411,7 @@ void gqo_gptq_step(float* W, const float* U, int64_t R, int64_t C, int q_type,
             memcpy(w_blk + r * ncols, W + r * C + c1, sizeof(float) * ncols); /* :225 clone */
         for (int i = 0; i < ncols; ++i) { /* :229 */
             int64_t col = c1 + i;
-            int64_t g_idx = col / G, sg_idx = col / 256;
+            int64_t g_idx = (perm ? perm[col] : col) / G, sg_idx = (perm ? perm[col] : col) / 256; /* :233-238 */
             if (!static_groups && (col % 256) == 0) /* :240-245 reads w, NOT w_blk */
                 gqo_scale_search(W + col, R, C, q_type, rmin, rdelta, nstep, d + sg_idx, nsg,
                                  s + g_idx, ng, dmin + sg_idx, nsg, m + g_idx, ng);
@@ -451,6 +456,20 @@ void gqo_gptq_step(float* W, const float* U, int64_t R, int64_t C, int q_type,
     }
     free(w_blk);
     free(errs);
+}
+
+void gqo_gptq_step(float* W, const float* U, int64_t R, int64_t C, int q_type,
+                   int block_size, int static_groups,
+                   double rmin, double rdelta, int nstep,
+                   uint8_t* qweight, uint16_t* d, uint8_t* s, uint16_t* dmin, uint8_t* m) {
+    gptq_step_impl(W, U, R, C, q_type, block_size, static_groups, rmin, rdelta, nstep, qweight, d, s, dmin, m, NULL);
+}
+
+void gqo_gptq_step_perm(float* W, const float* U, int64_t R, int64_t C, int q_type, int block_size,
+                        const int32_t* perm, const uint16_t* d, const uint8_t* s, const uint16_t* dmin,
+                        const uint8_t* m, uint8_t* qweight) {
+    gptq_step_impl(W, U, R, C, q_type, block_size, 1, 0.0, 0.0, 0, qweight, (uint16_t*)d, (uint8_t*)s,
+                   (uint16_t*)dmin, (uint8_t*)m, perm);
 }
 
 /* ------------------------------------------------------------------ RTN */

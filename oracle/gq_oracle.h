@@ -81,6 +81,13 @@ void gqo_gptq_step(float* W, const float* U, int64_t R, int64_t C, int q_type,
                    double rmin, double rdelta, int nstep,
                    uint8_t* qweight, uint16_t* d, uint8_t* s, uint16_t* dmin, uint8_t* m);
 
+/* GPTQ.step with act_order=True (gptq.py:208-216, 233-235): W, U already permuted by
+   perm = argsort(diag(H), descending); d/s/dmin/m = static scales of the ORIGINAL column groups (inputs);
+   qweight is produced in permuted positions (the reference un-permutes at :272-276). */
+void gqo_gptq_step_perm(float* W, const float* U, int64_t R, int64_t C, int q_type, int block_size,
+                        const int32_t* perm, const uint16_t* d, const uint8_t* s, const uint16_t* dmin,
+                        const uint8_t* m, uint8_t* qweight);
+
 /* reference quantizer.py:278-330 (_quant_non_block_module), fp32 weights. */
 void gqo_rtn_quantize(const float* W, int64_t R, int64_t C, int q_type,
                       double rmin, double rdelta, int nstep,

@@ -54,6 +54,8 @@ def lib():
         L.gqo_scale_search.argtypes = [vp, i64, i64, ci, cd, cd, ci, vp, i64, vp, i64, vp, i64, vp, i64]
         L.gqo_scale_search.restype = None
         L.gqo_gptq_step.argtypes = [vp, vp, i64, i64, ci, ci, ci, cd, cd, ci, vp, vp, vp, vp, vp]
+        L.gqo_gptq_step_perm.argtypes = [vp, vp, i64, i64, ci, ci, vp, vp, vp, vp, vp, vp]
+        L.gqo_gptq_step_perm.restype = None
         L.gqo_gptq_step.restype = None
         L.gqo_rtn_quantize.argtypes = [vp, i64, i64, ci, cd, cd, ci, vp, vp, vp, vp, vp]
         L.gqo_rtn_quantize.restype = None
@@ -135,6 +137,22 @@ def gptq_step(W, U, q_type, block_size=128, static_groups=False, rmin=-1.0, rdel
                         rmin, rdelta, nstep, _p(q), _p(d), _p(s), _p(dmin), _p(m))
     t = _idt(q_type)
     return W, q.view(t), d, s.view(t), dmin, m.view(t)
+
+
+def gptq_step_perm(W, U, q_type, perm, d, s, dmin, m, block_size=128):
+    """GPTQ.step with act_order: W/U permuted, (d, s, dmin, m) = static scales of the original groups.
+    Returns (W_dequantized_permuted, qweight_in_permuted_positions)."""
+    W = np.array(W, np.float32, order="C", copy=True)
+    U = np.ascontiguousarray(U, np.float32)
+    R, C = W.shape
+    perm = np.ascontiguousarray(perm, np.int32)
+    q = np.zeros((R, C), np.uint8)
+    d = np.ascontiguousarray(d).view(np.uint16)
+    dmin = np.ascontiguousarray(dmin).view(np.uint16)
+    s8 = np.ascontiguousarray(s).view(np.uint8)
+    m8 = np.ascontiguousarray(m).view(np.uint8)
+    lib().gqo_gptq_step_perm(_p(W), _p(U), R, C, q_type, block_size or 0, _p(perm), _p(d), _p(s8), _p(dmin), _p(m8), _p(q))
+    return W, q.view(_idt(q_type))
 
 
 def rtn_quantize(W, q_type, rmin=-1.0, rdelta=0.1, nstep=20):

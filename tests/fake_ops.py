@@ -53,6 +53,13 @@ def gptq_quantize(W, U, q_type, block_size=128, static_groups=False, rmin=-1.0, 
     return torch.from_numpy(q), _f16(d), torch.from_numpy(s), _f16(dmin), torch.from_numpy(m)
 
 
+def gptq_quantize_perm(W, U, q_type, perm, d, s, dmin, m, block_size=128, ws=None):
+    calls["gptq_quantize"] += 1
+    Wd, q = O.gptq_step_perm(W.numpy(), U.numpy(), q_type, perm.numpy(), _bits(d), s.numpy(), _bits(dmin), m.numpy(), block_size)
+    W.copy_(torch.from_numpy(Wd))
+    return torch.from_numpy(q)
+
+
 def rtn_quantize(W, q_type, rmin=-1.0, rdelta=0.1, nstep=20):
     q, d, s, dmin, m = O.rtn_quantize(W.float().numpy(), q_type, rmin, rdelta, nstep)
     return torch.from_numpy(q), _f16(d), torch.from_numpy(s), _f16(dmin), torch.from_numpy(m)

@@ -375,10 +375,49 @@ def g8_g9_rtn_dequant():
     save("g8_g9_rtn_dequant", **out)
 
 
+def g11_act_order():
+    """GPTQ.step with act_order=True (implies static_groups, gptq.py:45-46): inputs (W after pre_step, H after
+    pre_step), the permutation and the permuted U the reference used, outputs in ORIGINAL column order."""
+    out = {}
+    R, C = 64, 512
+    layer = _mk_layer(R, C, 110)
+    xs = _calib(C, 4, 256, 111)
+    for qt, block in ((T.Q4_K, 128), (T.Q2_K, 128), (T.Q6_K, 64), (T.Q5_K, 128)):
+        set_sqrt("ieee")
+        g = RefGPTQ(layer, rel_damp=0.01, block_size=block, static_groups=True, act_order=True)
+        for x in xs:
+            g.update(x)
+        g.quantization_pre_step()
+        W0, H0 = g.W.numpy().copy(), g.H.numpy().copy()
+        cap = {}
+        orig = g._prepare
+
+        def prep():
+            cap["Wp"] = g.W.numpy().copy()   # permuted W entering _prepare
+            u = orig()
+            cap["U"] = u.clone()
+            return u
+
+        g._prepare = prep
+        q, d, s, dmin, m = g.step(qt)
+        perm = np.argsort(-np.diag(H0), kind="stable").astype(np.int32)
+        assert np.array_equal(cap["Wp"], W0[:, perm]), "reference perm != stable descending argsort of diag(H)"
+        tag = f"{qt.name}_b{block}"
+        if "W0" not in out:
+            out["W0"], out["H0"], out["perm"] = W0, H0, perm
+        if "U_triu" not in out:  # U depends on (H[perm][:, perm], zero columns of W) only
+            out["U_triu"] = _triu_pack(cap["U"].numpy())
+        else:
+            assert np.array_equal(out["U_triu"], _triu_pack(cap["U"].numpy()))
+        for k, v in zip(("q", "d", "s", "dmin", "m"), (q.numpy(), u16(d), s.numpy(), u16(dmin), m.numpy())):
+            out[f"{tag}_{k}"] = v
+    save("g11_act_order", **out)
+
+
 def _main_all():
     torch.set_num_threads(8)
     for fn in (g1_make_quants, g2_scale_search, g3_elementwise, g4_g5_hessian, g6_g7_step_and_pack,
-               g8_g9_rtn_dequant):
+               g8_g9_rtn_dequant, g11_act_order):
         print(fn.__name__)
         fn()
     g10_driver()
@@ -437,5 +476,7 @@ def g10_driver():
 if __name__ == "__main__":
     if "g10" in sys.argv[1:]:
         g10_driver()
+    elif "g11" in sys.argv[1:]:
+        g11_act_order()
     else:
         _main_all()

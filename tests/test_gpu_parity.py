@@ -102,6 +102,24 @@ def test_gptq_step_golden(ops, tag):
         assert np.array_equal(npy(ops.pack(TYPES[name], q, d, s, dmin, m)), g[f"{tag}_packed"])
 
 
+@pytest.mark.parametrize("tag", ["Q4_K_b128", "Q2_K_b128", "Q6_K_b64", "Q5_K_b128"])
+def test_gptq_step_act_order_golden(ops, tag):
+    """act_order (gptq.py:208-216): permuted (W, U) + static scales of the original groups -> the reference's ints."""
+    g = load_golden("g11_act_order")
+    name, b = tag[:4], int(tag.split("_b")[1])
+    t = TYPES[name]
+    W0, perm = g["W0"], g["perm"]
+    U = triu_unpack(g["U_triu"], W0.shape[1])
+    _, d, s, dmin, m = ops.rtn_quantize(dev(W0), t)  # static scales (gptq.py:184-196) == fp32 RTN search
+    assert np.array_equal(u16(d), g[f"{tag}_d"]) and np.array_equal(npy(s), g[f"{tag}_s"])
+    Wp = dev(np.ascontiguousarray(W0[:, perm]))
+    qp = ops.gptq_quantize_perm(Wp, dev(U), t, torch.from_numpy(perm).cuda(), d, s, dmin, m, block_size=b)
+    q = npy(qp)[:, np.argsort(perm)]
+    assert np.array_equal(q, g[f"{tag}_q"]), f"{(q != g[f'{tag}_q']).mean():.4%} ints differ"
+    deq = npy(ops.dequantize(t, dev(q), d, s, dmin, m))
+    assert np.array_equal(npy(Wp)[:, np.argsort(perm)], deq)
+
+
 @pytest.mark.parametrize("name,R,C,block", [("Q4_K", 96, 1024, 128), ("Q2_K", 200, 512, 128), ("Q3_K", 64, 768, 64),
                                             ("Q5_K", 130, 512, 256), ("Q6_K", 64, 512, 96), ("Q4_K", 64, 768, 32)])
 def test_gptq_step_vs_oracle(ops, oracle, name, R, C, block):

@@ -142,6 +142,33 @@ def test_driver_walk_schema_and_hessian_sharing(tmp_path):
     assert worst < 0.05, f"worst per-module int mismatch rate {worst:.3%}"
 
 
+def test_handle_act_order_matches_reference():
+    """GPTQ(act_order=True, static_groups=True).compute: the handle's permutation logic (dead-channel fix before the
+    permutation, static scales of the ORIGINAL groups, qweight un-permuted) against the reference run G11.  U here
+    comes from the fp64 oracle, the reference's from fp32 LAPACK, so near-ties may flip: a RATE is asserted; the
+    scales have no Hessian in them and must be exact."""
+    import fake_ops
+    from gptq_gguf_toolkit_amd.gptq import GPTQ
+    from gptq_gguf_toolkit_amd.quant_utils import GGMLQuantizationType as T
+    fake_ops.install()
+    g = load_golden("g11_act_order")
+    W0, H0 = g["W0"], g["H0"]
+    R, C = W0.shape
+    for tag, qt, b in (("Q4_K_b128", T.Q4_K, 128), ("Q6_K_b64", T.Q6_K, 64)):
+        layer = torch.nn.Linear(C, R, bias=False)
+        layer.weight.data = torch.from_numpy(W0.copy())
+        h = GPTQ(layer, rel_damp=0.01, block_size=b, static_groups=True, act_order=True)
+        h.H = torch.from_numpy(H0.copy())
+        h.make_working_copy()
+        q, d, s, dmin, m = h.compute(qt)
+        assert np.array_equal(d.view(torch.int16).numpy().view(np.uint16), g[f"{tag}_d"])
+        assert np.array_equal(s.numpy(), g[f"{tag}_s"]) and np.array_equal(m.numpy(), g[f"{tag}_m"])
+        mism = float((q.numpy() != g[f"{tag}_q"]).mean())
+        assert mism < 0.02, f"{tag}: {mism:.3%} ints differ from the reference's act_order run"
+    with pytest.raises(AssertionError):
+        GPTQ(torch.nn.Linear(C, R, bias=False), act_order=True, static_groups=False)  # gptq.py:45-46
+
+
 def _worker(rank, world, port, tmp, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist

@@ -170,6 +170,26 @@ def test_g6_step(oracle, tag):
         assert flips < 0.05, f"{flips:.3%} ints differ vs the stock-MKL-sqrt reference run"
 
 
+@pytest.mark.parametrize("tag", ["Q4_K_b128", "Q2_K_b128", "Q6_K_b64", "Q5_K_b128"])
+def test_g11_act_order(oracle, tag):
+    """GPTQ.step with act_order=True (gptq.py:208-216, 233-235, 272-276): static scales of the original column
+    groups, columns walked in descending-diag(H) order, qweight un-permuted at the end."""
+    g = load_golden("g11_act_order")
+    name, b = tag[:4], int(tag.split("_b")[1])
+    t = TYPES[name]
+    W0, perm = g["W0"], g["perm"]
+    U = triu_unpack(g["U_triu"], W0.shape[1])
+    # gptq.py:184-196: static scales from the unpermuted W == the fp32 RTN scale search
+    _, d, sc, dmin, m = oracle.rtn_quantize(W0, t)
+    assert np.array_equal(d, g[f"{tag}_d"]) and np.array_equal(dmin, g[f"{tag}_dmin"])
+    assert np.array_equal(sc, g[f"{tag}_s"]) and np.array_equal(m, g[f"{tag}_m"])
+    Wd, qp = oracle.gptq_step_perm(W0[:, perm], U, t, perm, d, sc, dmin, m, block_size=b)
+    q = qp[:, np.argsort(perm)]
+    assert np.array_equal(q, g[f"{tag}_q"]), f"{(q != g[f'{tag}_q']).mean():.4%} ints differ"
+    # the working copy ends as the dequantized matrix, still permuted (the reference never un-permutes W)
+    assert np.array_equal(Wd[:, np.argsort(perm)], oracle.dequantize(t, q, d, sc, dmin, m))
+
+
 @pytest.mark.parametrize("name", list(TYPES))
 def test_g8_g9_rtn_dequant_pack(oracle, name):
     g = load_golden("g8_g9_rtn_dequant")
