@@ -254,13 +254,20 @@ __device__ __forceinline__ float rdlane(float v, int l) {
 
 // C[32x32] (accumulator) = sum_k Arow[i][k] * Brow[j][k], k < 32*nk32: both operands row-major in LDS
 // (lane (i = l&31, kh = l>>5) reads A[i][2p+kh] and B[j=l&31][2p+kh]); strides in floats.
-__device__ __forceinline__ f32x16 mfma_nt_32(const float* Ap, int lda_, const float* Bp, int ldb_, int nk32, int lane) {
+__device__ __forceinline__ f32x16 mfma_nt_32(const float* Ap, int lda_, const float* Bp, int ldb_, int lane) {
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
     const int li = lane & 31, lk = lane >> 5;
-    for (int p = 0; p < 16 * nk32; ++p)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ap[li * lda_ + 2 * p + lk], Bp[li * ldb_ + 2 * p + lk], acc, 0, 0, 0);
+    // all 32 operand reads are issued before the first MFMA: one LDS latency per product instead of 16
+    float av[16], bv[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+        av[p] = Ap[li * lda_ + 2 * p + lk];
+        bv[p] = Bp[li * ldb_ + 2 * p + lk];
+    }
+#pragma unroll
+    for (int p = 0; p < 16; ++p) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p], bv[p], acc, 0, 0, 0);
     return acc;
 }
 
@@ -271,10 +278,14 @@ __global__ __launch_bounds__(256) void diag_blk_kernel(float* __restrict__ A, in
     float* X = smem + NB * LDQ;   // [NB][LDQ]  L^-1 (lower), zeros above
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     float* Tw = X + NB * LDQ + wid * 32 * TQ;  // wave-private scratch tile
-    for (int idx = tid; idx < NB * NB; idx += 256) {
-        const int r = idx / NB, c = idx % NB;
-        S[r * LDQ + c] = (c <= r) ? A[r * lda + c] : 0.0f;
-        X[r * LDQ + c] = 0.0f;
+    for (int idx = tid; idx < NB * NB / 4; idx += 256) {  // 16-byte global accesses (lda % 4 == 0)
+        const int r = idx / (NB / 4), c = (idx % (NB / 4)) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(A + r * lda + c);
+        S[r * LDQ + c + 0] = (c + 0 <= r) ? v.x : 0.0f;
+        S[r * LDQ + c + 1] = (c + 1 <= r) ? v.y : 0.0f;
+        S[r * LDQ + c + 2] = (c + 2 <= r) ? v.z : 0.0f;
+        S[r * LDQ + c + 3] = (c + 3 <= r) ? v.w : 0.0f;
+        X[r * LDQ + c + 0] = 0.0f; X[r * LDQ + c + 1] = 0.0f; X[r * LDQ + c + 2] = 0.0f; X[r * LDQ + c + 3] = 0.0f;
     }
     __syncthreads();
     const int lc = lane & 31, lh = lane >> 5;  // MFMA D layout: col = lc, row = (e&3) + 8*(e>>2) + 4*lh
@@ -321,7 +332,7 @@ __global__ __launch_bounds__(256) void diag_blk_kernel(float* __restrict__ A, in
         const int ntile = 3 - sb;
         if (wid < ntile) {
             const int r0 = c0 + 32 * (wid + 1);
-            f32x16 acc = mfma_nt_32(S + r0 * LDQ + c0, LDQ, X + c0 * LDQ + c0, LDQ, 1, lane);
+            f32x16 acc = mfma_nt_32(S + r0 * LDQ + c0, LDQ, X + c0 * LDQ + c0, LDQ, lane);
 #pragma unroll
             for (int e = 0; e < 16; ++e) S[(r0 + (e & 3) + 8 * (e >> 2) + 4 * lh) * LDQ + c0 + lc] = acc[e];
         }
@@ -331,7 +342,7 @@ __global__ __launch_bounds__(256) void diag_blk_kernel(float* __restrict__ A, in
         for (int bi = sb + 1; bi < 4; ++bi)
             for (int bj = sb + 1; bj <= bi; ++bj, ++t) {
                 if ((t & 3) != wid) continue;
-                f32x16 acc = mfma_nt_32(S + (32 * bi) * LDQ + c0, LDQ, S + (32 * bj) * LDQ + c0, LDQ, 1, lane);
+                f32x16 acc = mfma_nt_32(S + (32 * bi) * LDQ + c0, LDQ, S + (32 * bj) * LDQ + c0, LDQ, lane);
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     float* p = S + (32 * bi + (e & 3) + 8 * (e >> 2) + 4 * lh) * LDQ + 32 * bj + lc;
@@ -351,10 +362,16 @@ __global__ __launch_bounds__(256) void diag_blk_kernel(float* __restrict__ A, in
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
             const int li = lane & 31, lk = lane >> 5;
-            for (int p = 0; p < 16 * d; ++p) {
-                const int k = 32 * bj + 2 * p + lk;
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(S[(32 * bi + li) * LDQ + k], X[k * LDQ + 32 * bj + li], acc, 0,
-                                                           0, 0);
+            for (int c = 0; c < d; ++c) {  // 32 k per chunk, operands read ahead of the MFMAs
+                float av[16], bv[16];
+#pragma unroll
+                for (int p = 0; p < 16; ++p) {
+                    const int k = 32 * (bj + c) + 2 * p + lk;
+                    av[p] = S[(32 * bi + li) * LDQ + k];
+                    bv[p] = X[k * LDQ + 32 * bj + li];
+                }
+#pragma unroll
+                for (int p = 0; p < 16; ++p) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p], bv[p], acc, 0, 0, 0);
             }
 #pragma unroll
             for (int e = 0; e < 16; ++e) Tw[((e & 3) + 8 * (e >> 2) + 4 * lh) * TQ + lc] = acc[e];
@@ -366,20 +383,29 @@ __global__ __launch_bounds__(256) void diag_blk_kernel(float* __restrict__ A, in
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
             const int li = lane & 31, lk = lane >> 5;
+            float av[16], bv[16];
+#pragma unroll
             for (int p = 0; p < 16; ++p) {
                 const int k = 2 * p + lk;
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(X[(32 * bi + li) * LDQ + 32 * bi + k], Tw[k * TQ + li], acc, 0, 0,
-                                                           0);
+                av[p] = X[(32 * bi + li) * LDQ + 32 * bi + k];
+                bv[p] = Tw[k * TQ + li];
             }
+#pragma unroll
+            for (int p = 0; p < 16; ++p) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p], bv[p], acc, 0, 0, 0);
 #pragma unroll
             for (int e = 0; e < 16; ++e) X[(32 * bi + (e & 3) + 8 * (e >> 2) + 4 * lh) * LDQ + 32 * bj + lc] = -acc[e];
         }
         __syncthreads();
     }
-    for (int idx = tid; idx < NB * NB; idx += 256) {
-        const int r = idx / NB, c = idx % NB;
-        if (c <= r) A[r * lda + c] = S[r * LDQ + c];
-        Xout[r * ldx + c] = X[r * LDQ + c];
+    for (int idx = tid; idx < NB * NB / 4; idx += 256) {
+        const int r = idx / (NB / 4), c = (idx % (NB / 4)) * 4;
+        const float* sr = S + r * LDQ + c;
+        const float* xr = X + r * LDQ + c;
+        if (c + 3 <= r) *reinterpret_cast<float4*>(A + r * lda + c) = make_float4(sr[0], sr[1], sr[2], sr[3]);
+        else
+            for (int u = 0; u < 4; ++u)
+                if (c + u <= r) A[r * lda + c + u] = sr[u];
+        *reinterpret_cast<float4*>(Xout + r * ldx + c) = make_float4(xr[0], xr[1], xr[2], xr[3]);
     }
 }
 

@@ -33,8 +33,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // Tokens t >= T are zero padding.  One workgroup = one block; 16-byte global accesses on both sides.
 __global__ __launch_bounds__(256) void transpose16_kernel(const uint16_t* __restrict__ X, int64_t T, int64_t C,
                                                           uint16_t* __restrict__ Xb, int64_t nstage, int half_mode) {
-    // half_mode: Xb[panel][Tp/32 half-stages][128 rows][32 k] (8 KiB blocks, 16-byte chunk kc of row r at
-    // chunk kc ^ ((r >> 2) & 3)) for the staggered 256x256 kernel
+    // half_mode (syrk16_256e_kernel): Xb[panel][Tp/32 half-stages][128 rows][32 k] (8 KiB blocks, 16-byte chunk
+    // kc of row r at chunk kc ^ f((r >> 2) & 3), f = 0,2,3,1)
     __shared__ __attribute__((aligned(16))) uint16_t tile[64][128 + 8];  // [t][c], row = 272 B
     const int64_t st = blockIdx.x, pn = blockIdx.y;
     const int64_t t0 = st * 64, c0 = pn * 128;
@@ -54,8 +54,7 @@ __global__ __launch_bounds__(256) void transpose16_kernel(const uint16_t* __rest
         if (half_mode) {  // p = h*512 + r*4 + c': half-stage h, stored chunk c' holds k-chunk 4h + (c' ^ ((r>>2)&3))
             const int h = p >> 9, q = p & 511;
             r = q >> 2;
-            const int g = (r >> 2) & 3;
-            kc = 4 * h + ((q & 3) ^ (half_mode == 2 ? (0x78 >> (2 * g)) & 3 : g));
+            kc = 4 * h + ((q & 3) ^ ((0x78 >> (2 * ((r >> 2) & 3))) & 3));
         } else {
             r = p >> 3;
             kc = (p & 7) ^ ((r >> 1) & 7);  // stored chunk p holds k-chunk kc
@@ -97,7 +96,7 @@ struct SyrkProblem {
 struct SyrkGroup {
     int n, total_tiles;
     SyrkProblem p[H_MAX_GROUP];
-    // direct kernel only: balanced tile table, entry = problem << 24 | ti << 12 | tj (0xffffffff: none),
+    // syrk16_256e_kernel only: balanced tile table, entry = problem << 24 | ti << 12 | tj (0xffffffff: none),
     // row x holds the tiles workgroups with blockIdx % 8 == x (= XCD x) process, in order
     const uint32_t* table;
     int per_xcd;
@@ -260,544 +259,27 @@ __global__ __launch_bounds__(256, 2) void syrk16_kernel(const SyrkGroup grp) {
         }
 }
 
-// ------------------------------------------------------ 16-bit SYRK, 256x256 tiles
-// Measured on MI355X (profiles/): the 128x128-tile kernel above is bound by the L2 -> CU operand
-// stream (64 flop per operand byte; removing its global loads takes it from 690 to 1230 TFLOP/s).
-// This variant doubles the arithmetic intensity: workgroup = 512 threads = 8 waves (2 x 4), tile
-// 256x256, wave tile 128x64 = 4x2 MFMA tiles (128 accumulator VGPRs), one workgroup per CU with a
-// double-buffered 128 KiB LDS image (two 16 KiB pre-swizzled blocks per operand and stage, fetched
-// through registers one stage ahead).  The 32 workgroups of an XCD form one 4x8 super-tile.
-constexpr int BT = 256;
-constexpr int B_STAGE_BYTES = 2 * BT * HK * 2;  // A 32 KiB | B 32 KiB
-
-template <bool BF16>
-__global__ __launch_bounds__(512, 2) void syrk16_256_kernel(const SyrkGroup grp) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 2, wn = wid & 3;
-    const int xcd = blockIdx.x & 7, kx = blockIdx.x >> 3;
-    const int g = (kx >> 5) * 8 + xcd, slot = kx & 31;
-    if (g >= grp.total_tiles) return;  // total_tiles counts 4x8 SUPER-tiles
-    int pi = 0;
-    for (int i = 1; i < grp.n; ++i)
-        if (g >= grp.p[i].tile_begin) pi = i;
-    const SyrkProblem& P = grp.p[pi];
-    // super-tiles: rows of 4 tiles, columns of 8 tiles, enumerated over the band sJ*8+7 >= sI*4
-    const int nt = P.nt;  // 256-tiles per dimension
-    const int nsc = (nt + 7) >> 3;
-    int rem = g - P.tile_begin, sI = 0;
-    for (;; ++sI) {
-        const int first = (sI * 4) >> 3;  // first super-column touching the upper triangle
-        const int cnt = nsc - first;
-        if (rem < cnt) { rem += first; break; }
-        rem -= cnt;
-    }
-    const int64_t ti = sI * 4 + (slot >> 3), tj = (int64_t)rem * 8 + (slot & 7);
-    if (ti >= nt || tj >= nt || ti > tj) return;
-    const int64_t Tp = P.Tp, C = P.C, nk = Tp / HK;
-    const uint16_t* __restrict__ Xt = P.Xt;
-
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-
-    // chunk q = u*512 + tid (u = 0..3) of the 2048 16-byte chunks of an operand stage (two 128-row blocks)
-    const uint4* srcA[4];
-    const uint4* srcB[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int q = u * 512 + tid;
-        srcA[u] = reinterpret_cast<const uint4*>(Xt + ((2 * ti + (q >> 10)) * nk) * (HT * HK)) + (q & 1023);
-        srcB[u] = reinterpret_cast<const uint4*>(Xt + ((2 * tj + (q >> 10)) * nk) * (HT * HK)) + (q & 1023);
-    }
-    uint4 fa0, fa1, fa2, fa3, fb0, fb1, fb2, fb3;
-#define GQ_FETCH256(s)                                                                           \
-    do {                                                                                         \
-        fa0 = srcA[0][(s) * 1024]; fa1 = srcA[1][(s) * 1024]; fa2 = srcA[2][(s) * 1024];         \
-        fa3 = srcA[3][(s) * 1024]; fb0 = srcB[0][(s) * 1024]; fb1 = srcB[1][(s) * 1024];         \
-        fb2 = srcB[2][(s) * 1024]; fb3 = srcB[3][(s) * 1024];                                    \
-    } while (0)
-#define GQ_COMMIT256(buf)                                                                        \
-    do {                                                                                         \
-        uint4* la_ = reinterpret_cast<uint4*>(smem + (buf) * B_STAGE_BYTES) + tid;               \
-        la_[0] = fa0; la_[512] = fa1; la_[1024] = fa2; la_[1536] = fa3;                          \
-        la_[2048] = fb0; la_[2560] = fb1; la_[3072] = fb2; la_[3584] = fb3;                      \
-    } while (0)
-    const int li = lane & 31, lk = lane >> 5;
-    int offA[4], offB[2], swA[4], swB[2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = wm * 128 + i * 32 + li;  // row in the 256-row A image = 2 blocks of [128][128 B]
-        offA[i] = r * 128;
-        swA[i] = (r >> 1) & 7;
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int r = wn * 64 + j * 32 + li;
-        offB[j] = BT * HK * 2 + r * 128;
-        swB[j] = (r >> 1) & 7;
-    }
-    GQ_FETCH256(0);
-    GQ_COMMIT256(0);
-    __syncthreads();
-    for (int64_t t = 0; t < nk; ++t) {
-        if (t + 1 < nk) GQ_FETCH256(t + 1);
-        const unsigned char* base = smem + (t & 1) * B_STAGE_BYTES;
-        // fragments of k16-step s4+1 are read while the 8 MFMAs of step s4 run (register double buffer;
-        // sched_group_barrier pins "6 LDS reads, then 8 MFMAs" so the reads are not sunk to their use)
-        uint4 a[2][4], b[2][2];
-#define GQ_FRAGS(S, D)                                                                                      \
-    do {                                                                                                    \
-        const int kc_ = (S) * 2 + lk;                                                                       \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                       \
-            a[D][i] = *reinterpret_cast<const uint4*>(base + offA[i] + ((kc_ ^ swA[i]) << 4));              \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                       \
-            b[D][j] = *reinterpret_cast<const uint4*>(base + offB[j] + ((kc_ ^ swB[j]) << 4));              \
-    } while (0)
-#define GQ_MFMAS(D)                                                                                         \
-    do {                                                                                                    \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                       \
-            _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] = mfma16<BF16>(a[D][i], b[D][j], acc[i][j]); \
-    } while (0)
-        GQ_FRAGS(0, 0);
-        GQ_FRAGS(1, 1);
-        __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
-        GQ_MFMAS(0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-        GQ_FRAGS(2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
-        GQ_MFMAS(1);
-        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-        GQ_FRAGS(3, 1);
-        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
-        GQ_MFMAS(0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-        GQ_MFMAS(1);
-        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-#undef GQ_FRAGS
-#undef GQ_MFMAS
-        if (t + 1 < nk) GQ_COMMIT256((int)((t + 1) & 1));
-        __syncthreads();
-    }
-#undef GQ_FETCH256
-#undef GQ_COMMIT256
-    float* __restrict__ H = P.H;
-    const float beta = P.beta, alpha = P.alpha;
-    const int lc = lane & 31, lh = lane >> 5;
-    const int64_t i0 = ti * BT, j0 = tj * BT;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int64_t col = j0 + wn * 64 + j * 32 + lc;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int64_t row = i0 + wm * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                float h = beta * H[row * C + col] + alpha * acc[i][j][e];
-                H[row * C + col] = h;
-                if (ti != tj) H[col * C + row] = h;
-            }
-        }
-}
-
-// ------------------------------------ 16-bit SYRK, 256x256 tiles, direct-to-LDS operand ring
-// PMC on syrk16_256_kernel: MFMA busy 39 %, nothing saturated, 38 % of wave time in waits; without its
-// global loads it runs at 1230 TFLOP/s.  Its operand stream goes HBM/L2 -> VGPR -> ds_write_b128 -> LDS
-// only ONE stage (64 KiB per CU) ahead, and the wide LDS stores cost 13 cycles per wave instruction.
-// Here K advances in half-stages of 32 (one 32 KiB LDS image: A 256 rows x 64 B | B 256 rows x 64 B)
-// through a ring of FOUR buffers filled by global_load_lds_dwordx4 (no VGPR round trip, no ds_write):
-// the fetch of half-stage n+4 is issued right after the barrier that retires half-stage n, three full
-// intervals (96 KiB per CU) ahead of its first use.  The compiler serialises every ds_read behind
-// vmcnt(0) once an LDS-DMA load is in flight, so fragment reads, s_waitcnt and s_barrier are inline asm
-// and the counters are managed by hand:
-//   loads are issued in half-stage order, 4 per thread and half-stage; at the barrier of interval n the
-//   half-stages n+2 and n+3 may still be in flight -> s_waitcnt vmcnt(8) (vmcnt(0) in the last 3
-//   intervals, where fewer are outstanding).
-// The operand image is transpose16_kernel's half_mode layout: Xb[panel][Tp/32][128 rows][32 k], 16-byte
-// chunk kc of row r stored at chunk kc ^ ((r >> 2) & 3) -- a ds_read_b128 lane group (16 lanes: four
-// runs of 4 consecutive rows) then covers all 16 slots of a 256-byte bank row.
+// ------------------------------------------ 16-bit SYRK, 256x256 tiles, direct-to-LDS operand ring
+constexpr int BT = 256;                         // tile
 constexpr int SK = 32;                          // k per half-stage
-constexpr int S_BUF_BYTES = 2 * BT * SK * 2;    // A 16 KiB | B 16 KiB
+constexpr int S_BUF_BYTES = 2 * BT * SK * 2;    // one ring slot: A 16 KiB | B 16 KiB
 constexpr int S_NBUF = 4;
 constexpr int S_LDS_BYTES = S_NBUF * S_BUF_BYTES;  // 128 KiB
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) void lds_void;
-typedef const __attribute__((address_space(1))) void glb_void;
 
-template <bool BF16>
-__device__ __forceinline__ f32x16 mfma16v(u32x4 a, u32x4 b, f32x16 c) {
-    if constexpr (BF16)
-        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0,
-                                                       0, 0);
-    else
-        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0,
-                                                      0);
-}
-
-template <bool BF16>
-__global__ __launch_bounds__(512, 2) void syrk16_256d_kernel(const SyrkGroup grp) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wid >> 2, wn = wid & 3;
-    const uint32_t ent = grp.table[(blockIdx.x & 7) * grp.per_xcd + (blockIdx.x >> 3)];
-    if (ent == 0xffffffffu) return;
-    const SyrkProblem& P = grp.p[ent >> 24];
-    const int64_t ti = (ent >> 12) & 0xfff, tj = ent & 0xfff;
-    const int64_t C = P.C, nhs = P.Tp / SK;  // half-stages
-    const uint16_t* __restrict__ Xt = P.Xt;
-
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-
-    // a half-stage = 2048 chunks of 16 B: chunk u*512 + tid, u = 0,1 -> A panels 2ti, 2ti+1; u = 2,3 -> B.
-    // Wave-uniform panel bases + a constant per-lane byte offset (saddr + voffset addressing).
-    const char* sp0 = reinterpret_cast<const char*>(Xt + ((2 * ti) * nhs) * (HT * SK));
-    const char* sp1 = reinterpret_cast<const char*>(Xt + ((2 * ti + 1) * nhs) * (HT * SK));
-    const char* sp2 = reinterpret_cast<const char*>(Xt + ((2 * tj) * nhs) * (HT * SK));
-    const char* sp3 = reinterpret_cast<const char*>(Xt + ((2 * tj + 1) * nhs) * (HT * SK));
-    const unsigned voff = (unsigned)tid * 16u;
-    // LDS destination = wave-uniform base (M0); the hardware adds lane * 16
-#ifdef GQ_D_NOLOAD  // ablation build (profiles/): no operand stream in the main loop
-#define GQ_DL1(sp, h, buf, part) (void)0
-#else
-#define GQ_DL1(sp, h, buf, part) GQ_DL1_(sp, h, buf, part)
-#endif
-#define GQ_DL1_(sp, h, buf, part)                                                                     \
-    __builtin_amdgcn_global_load_lds((glb_void*)((sp) + (int64_t)(h) * 8192 + voff),                  \
-                                     (lds_void*)(smem + (buf) * S_BUF_BYTES + (part) * 8192 + wid * 1024), 16, 0, 0)
-    // Fragment addresses: row r = base row + i*32 + li, k-chunk kc = s2*2 + lk stored at chunk
-    // kc ^ ((li >> 2) & 3).  Everything but the lane term is an instruction immediate: i*2048, the B image
-    // (+16 KiB, folded into the base), the ring slot (slot & 1) * 32 KiB; slots 2,3 use the "+64 KiB" bases.
-    const int li = lane & 31, lk = lane >> 5;
-    const unsigned lds0 = (unsigned)(uintptr_t)smem;
-    unsigned bA00, bA01, bA10, bA11, bB00, bB01, bB10, bB11;  // b<op><s2><hi>
-    {
-        const unsigned sw = (unsigned)((li >> 2) & 3);
-        const unsigned c0 = ((unsigned)lk ^ sw) << 4, c1 = ((2u + (unsigned)lk) ^ sw) << 4;
-        const unsigned ra = lds0 + (unsigned)(wm * 128 + li) * 64u, rb = lds0 + 16384u + (unsigned)(wn * 64 + li) * 64u;
-        bA00 = ra + c0; bA01 = bA00 + 65536u; bA10 = ra + c1; bA11 = bA10 + 65536u;
-        bB00 = rb + c0; bB01 = bB00 + 65536u; bB10 = rb + c1; bB11 = bB10 + 65536u;
-    }
-    f32x16 c00 = acc[0][0], c01 = acc[0][1], c10 = acc[1][0], c11 = acc[1][1], c20 = acc[2][0], c21 = acc[2][1],
-           c30 = acc[3][0], c31 = acc[3][1];
-    u32x4 pa0, pa1, pa2, pa3, pb0, pb1, qa0, qa1, qa2, qa3, qb0, qb1;
-    // Everything in the main loop is asm volatile so that the instruction ORDER is exactly the one written:
-    // every LDS read, wait, barrier and DMA load sits in the 32-cycle shadow of an MFMA (<= 5 issue slots).
-#define GQ_DSR(dst, base, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(base), "n"(off) : "memory")
-#define GQ_LGKM1(N, x) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(x)::"memory")
-#define GQ_LGKM2(N, x, y) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(x), "+v"(y)::"memory")
-#define GQ_MF(c, a, b)                                                                                \
-    do {                                                                                              \
-        if constexpr (BF16) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b)); \
-        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));       \
-    } while (0)
-    // One k16-step: multiply fragment set X (its 6 reads were issued a0,b0,b1,a1,a2,a3 during the previous
-    // step and are the only LDS reads in flight on entry) while issuing the 6 reads of set Y from bases
-    // AY/BY at immediate OFF.  lgkmcnt returns in order, so "lgkmcnt(k)" = all but the youngest k are back.
-    // MID runs after the first MFMA (vmcnt wait + barrier on odd steps); L1/L2 are one DMA load each --
-    // a 1 KiB LDS-DMA piece costs 60-185 cycles of issue, so the four of a half-stage are spread over two
-    // steps instead of bursting after the barrier.
-#define GQ_STEP(X, Y, AY, BY, OFF, MID, L1, L2)                                                             \
-    do {                                                                                              \
-        GQ_LGKM2(4, X##a0, X##b0);                                                                    \
-        GQ_MF(c00, X##a0, X##b0);                                                                     \
-        MID;                                                                                          \
-        GQ_DSR(Y##a0, AY, (OFF));                                                                     \
-        GQ_LGKM1(4, X##b1);                                                                           \
-        GQ_MF(c01, X##a0, X##b1);                                                                     \
-        GQ_DSR(Y##b0, BY, (OFF));                                                                     \
-        GQ_LGKM1(4, X##a1);                                                                           \
-        GQ_MF(c10, X##a1, X##b0);                                                                     \
-        GQ_DSR(Y##b1, BY, (OFF) + 2048);                                                              \
-        GQ_MF(c11, X##a1, X##b1);                                                                     \
-        GQ_DSR(Y##a1, AY, (OFF) + 2048);                                                              \
-        L1;                                                                                           \
-        GQ_LGKM1(5, X##a2);                                                                           \
-        GQ_MF(c20, X##a2, X##b0);                                                                     \
-        GQ_DSR(Y##a2, AY, (OFF) + 4096);                                                              \
-        GQ_MF(c21, X##a2, X##b1);                                                                     \
-        GQ_DSR(Y##a3, AY, (OFF) + 6144);                                                              \
-        GQ_LGKM1(6, X##a3);                                                                           \
-        GQ_MF(c30, X##a3, X##b0);                                                                     \
-        L2;                                                                                           \
-        GQ_MF(c31, X##a3, X##b1);                                                                     \
-    } while (0)
-    // Half-stage n lives in ring slot n & 3.  Even step: multiply (n, k16 0), read (n, k16 1).  Odd step:
-    // multiply (n, k16 1); after its first MFMA every wave has all of half-stage n-1 in registers and
-    // waits (vmcnt(4), see below) until ITS pieces of half-stage n+1 have landed; the barrier makes that
-    // true for all pieces and retires slot (n-1) & 3; then read (n+1, k16 0).
-    // DMA schedule: pieces 0,1 (A panels) of half-stage n+3 in the odd step of interval n, pieces 2,3 (B
-    // panels) in the even step of interval n+1, both into the slot retired by barrier n.  At barrier n the
-    // only loads younger than half-stage n+1's are the four of half-stage n+2 -> vmcnt(4); sources are
-    // clamped to the last half-stage so the count also holds in the tail.
-#define GQ_INTERVAL(AE, BE, OFFE, AO, BO, OFFO, SLOT2, SLOT3)                                         \
-    {                                                                                                 \
-        const int64_t h2_ = n + 2 < nhs ? n + 2 : nhs - 1, h3_ = n + 3 < nhs ? n + 3 : nhs - 1;       \
-        GQ_STEP(p, q, AE, BE, OFFE, (void)0, GQ_DL1(sp2, h2_, SLOT2, 2), GQ_DL1(sp3, h2_, SLOT2, 3)); \
-        GQ_STEP(q, p, AO, BO, OFFO, asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory"),     \
-                GQ_DL1(sp0, h3_, SLOT3, 0), GQ_DL1(sp1, h3_, SLOT3, 1));                              \
-        ++n;                                                                                          \
-    }
-
-    for (int h = 0; h < 2; ++h) {
-        const int64_t hc = h < nhs ? h : nhs - 1;
-        GQ_DL1_(sp0, hc, h, 0); GQ_DL1_(sp1, hc, h, 1); GQ_DL1_(sp2, hc, h, 2); GQ_DL1_(sp3, hc, h, 3);
-    }
-    {
-        const int64_t hc = 2 < nhs ? 2 : nhs - 1;
-        GQ_DL1_(sp0, hc, 2, 0); GQ_DL1_(sp1, hc, 2, 1);
-    }
-    asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
-    GQ_DSR(pa0, bA00, 0); GQ_DSR(pb0, bB00, 0); GQ_DSR(pb1, bB00, 2048);
-    GQ_DSR(pa1, bA00, 2048); GQ_DSR(pa2, bA00, 4096); GQ_DSR(pa3, bA00, 6144);
-    for (int64_t n = 0; n < nhs;) {  // nhs % 4 == 0 (Tp is padded to 128 tokens)
-        GQ_INTERVAL(bA10, bB10, 0, bA00, bB00, 32768, 2, 3)      // slot 0, next slot 1
-        GQ_INTERVAL(bA10, bB10, 32768, bA01, bB01, 0, 3, 0)      // slot 1, next slot 2
-        GQ_INTERVAL(bA11, bB11, 0, bA01, bB01, 32768, 0, 1)      // slot 2, next slot 3
-        GQ_INTERVAL(bA11, bB11, 32768, bA00, bB00, 0, 1, 2)      // slot 3, next slot 0
-    }
-    // drain the (unused) look-ahead reads and DMA loads; MFMA results need >= 10 wait states before VALU reads
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-    acc[0][0] = c00; acc[0][1] = c01; acc[1][0] = c10; acc[1][1] = c11;
-    acc[2][0] = c20; acc[2][1] = c21; acc[3][0] = c30; acc[3][1] = c31;
-#undef GQ_DL1
-#undef GQ_DL1_
-#undef GQ_DSR
-#undef GQ_LGKM1
-#undef GQ_LGKM2
-#undef GQ_MF
-#undef GQ_STEP
-#undef GQ_INTERVAL
-#ifdef GQ_D_NOEPI
-    if (P.alpha != 12345.f) return;
-#endif
-    float* __restrict__ H = P.H;
-    const float beta = P.beta, alpha = P.alpha;
-    const int lc = lane & 31, lh = lane >> 5;
-    const int64_t i0 = ti * BT, j0 = tj * BT;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int64_t col = j0 + wn * 64 + j * 32 + lc;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int64_t row = i0 + wm * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                float h = beta * H[row * C + col] + alpha * acc[i][j][e];
-                H[row * C + col] = h;
-                if (ti != tj) H[col * C + row] = h;
-            }
-        }
-}
-
-// ------------------------ 16-bit SYRK, 256x256 tiles, 4 waves x (128x128), direct-to-LDS operand ring
-// Same ring, operand image and hand-ordered stream as syrk16_256d_kernel, but ONE wave per SIMD with a
-// 128x128 wave tile: 16 accumulators (256 AGPRs), 8 LDS fragment reads per 16 MFMAs instead of 12 (the
-// chip is power-limited on this kernel -- ~1.45 GHz -- so LDS bytes per flop are clock), no co-resident
-// wave to share the matrix pipe with.  Per k16-step: 16 MFMAs, the 8 reads of the next step behind the
-// first 8, 4 of the half-stage's 8 DMA pieces behind MFMAs 8/10/12/14.
-template <bool BF16>
-__global__ __launch_bounds__(256, 1) void syrk16_256q_kernel(const SyrkGroup grp) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wid >> 1, wn = wid & 1;
-    const uint32_t ent = grp.table[(blockIdx.x & 7) * grp.per_xcd + (blockIdx.x >> 3)];
-    if (ent == 0xffffffffu) return;
-    const SyrkProblem& P = grp.p[ent >> 24];
-    const int64_t ti = (ent >> 12) & 0xfff, tj = ent & 0xfff;
-    const int64_t C = P.C, nhs = P.Tp / SK;
-    const uint16_t* __restrict__ Xt = P.Xt;
-    // half-stage image = 32 pieces of 1 KiB; wave w moves pieces u*4 + w, u = 0..7 (u>>1 = operand panel)
-    const char* sp0 = reinterpret_cast<const char*>(Xt + ((2 * ti) * nhs) * (HT * SK));
-    const char* sp1 = reinterpret_cast<const char*>(Xt + ((2 * ti + 1) * nhs) * (HT * SK));
-    const char* sp2 = reinterpret_cast<const char*>(Xt + ((2 * tj) * nhs) * (HT * SK));
-    const char* sp3 = reinterpret_cast<const char*>(Xt + ((2 * tj + 1) * nhs) * (HT * SK));
-    const unsigned voff0 = (unsigned)(wid * 1024 + lane * 16), voff1 = voff0 + 4096u;
-#ifdef GQ_D_NOLOAD
-#define GQ_QDL(sp, h, buf, u) (void)0
-#else
-#define GQ_QDL(sp, h, buf, u) GQ_QDL_(sp, h, buf, u)
-#endif
-#define GQ_QDL_(sp, h, buf, u)                                                                        \
-    __builtin_amdgcn_global_load_lds((glb_void*)((sp) + (int64_t)(h) * 8192 + (((u) & 1) ? voff1 : voff0)), \
-                                     (lds_void*)(smem + (buf) * S_BUF_BYTES + ((u) * 4 + wid) * 1024), 16, 0, 0)
-    const int li = lane & 31, lk = lane >> 5;
-    const unsigned lds0 = (unsigned)(uintptr_t)smem;
-    unsigned bA00, bA01, bA10, bA11, bB00, bB01, bB10, bB11;  // b<op><k16 step><+64 KiB>
-    {
-        const unsigned sw = (unsigned)((li >> 2) & 3);
-        const unsigned c0 = ((unsigned)lk ^ sw) << 4, c1 = ((2u + (unsigned)lk) ^ sw) << 4;
-        const unsigned ra = lds0 + (unsigned)(wm * 128 + li) * 64u, rb = lds0 + 16384u + (unsigned)(wn * 128 + li) * 64u;
-        bA00 = ra + c0; bA01 = bA00 + 65536u; bA10 = ra + c1; bA11 = bA10 + 65536u;
-        bB00 = rb + c0; bB01 = bB00 + 65536u; bB10 = rb + c1; bB11 = bB10 + 65536u;
-    }
-    f32x16 c00, c01, c02, c03, c10, c11, c12, c13, c20, c21, c22, c23, c30, c31, c32, c33;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        c00[e] = 0.f;
-        c01[e] = 0.f;
-        c02[e] = 0.f;
-        c03[e] = 0.f;
-        c10[e] = 0.f;
-        c11[e] = 0.f;
-        c12[e] = 0.f;
-        c13[e] = 0.f;
-        c20[e] = 0.f;
-        c21[e] = 0.f;
-        c22[e] = 0.f;
-        c23[e] = 0.f;
-        c30[e] = 0.f;
-        c31[e] = 0.f;
-        c32[e] = 0.f;
-        c33[e] = 0.f;
-    }
-    u32x4 pa0, pa1, pa2, pa3, pb0, pb1, pb2, pb3, qa0, qa1, qa2, qa3, qb0, qb1, qb2, qb3;
-#define GQ_QDSR(dst, base, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(base), "n"(off) : "memory")
-#define GQ_QLGKM1(N, x) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(x)::"memory")
-#define GQ_QLGKM2(N, x, y) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(x), "+v"(y)::"memory")
-#define GQ_QMF(c, a, b)                                                                               \
-    do {                                                                                              \
-        if constexpr (BF16) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b)); \
-        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));       \
-    } while (0)
-    // fragment reads of a set are issued a0,b0,b1,a1,b2,b3,a2,a3 and the MFMAs ordered so each needs at most
-    // one more of them; lgkmcnt(k) = "all but the youngest k LDS reads are back" (in-order return)
-#define GQ_QSTEP(X, Y, AY, BY, OFF, MID, L0, L1, L2, L3)                                              \
-    do {                                                                                              \
-        GQ_QLGKM2(6, X##a0, X##b0);                                                                   \
-        GQ_QMF(c00, X##a0, X##b0);                                                                    \
-        MID;                                                                                          \
-        GQ_QDSR(Y##a0, AY, (OFF) + 0);                                                                \
-        GQ_QLGKM1(6, X##b1);                                                                          \
-        GQ_QMF(c01, X##a0, X##b1);                                                                    \
-        GQ_QDSR(Y##b0, BY, (OFF) + 0);                                                                \
-        GQ_QLGKM1(6, X##a1);                                                                          \
-        GQ_QMF(c10, X##a1, X##b0);                                                                    \
-        GQ_QDSR(Y##b1, BY, (OFF) + 2048);                                                             \
-        GQ_QMF(c11, X##a1, X##b1);                                                                    \
-        GQ_QDSR(Y##a1, AY, (OFF) + 2048);                                                             \
-        GQ_QLGKM1(7, X##b2);                                                                          \
-        GQ_QMF(c02, X##a0, X##b2);                                                                    \
-        GQ_QDSR(Y##b2, BY, (OFF) + 4096);                                                             \
-        GQ_QLGKM1(7, X##b3);                                                                          \
-        GQ_QMF(c03, X##a0, X##b3);                                                                    \
-        GQ_QDSR(Y##b3, BY, (OFF) + 6144);                                                             \
-        GQ_QMF(c12, X##a1, X##b2);                                                                    \
-        GQ_QDSR(Y##a2, AY, (OFF) + 4096);                                                             \
-        GQ_QMF(c13, X##a1, X##b3);                                                                    \
-        GQ_QDSR(Y##a3, AY, (OFF) + 6144);                                                             \
-        GQ_QLGKM1(9, X##a2);                                                                          \
-        GQ_QMF(c20, X##a2, X##b0);                                                                    \
-        L0;                                                                                           \
-        GQ_QMF(c21, X##a2, X##b1);                                                                    \
-        GQ_QMF(c22, X##a2, X##b2);                                                                    \
-        L1;                                                                                           \
-        GQ_QMF(c23, X##a2, X##b3);                                                                    \
-        GQ_QLGKM1(8, X##a3);                                                                          \
-        GQ_QMF(c30, X##a3, X##b0);                                                                    \
-        L2;                                                                                           \
-        GQ_QMF(c31, X##a3, X##b1);                                                                    \
-        GQ_QMF(c32, X##a3, X##b2);                                                                    \
-        L3;                                                                                           \
-        GQ_QMF(c33, X##a3, X##b3);                                                                    \
-    } while (0)
-    // DMA schedule: pieces 0-3 (A panels) of half-stage n+3 in the odd step of interval n (after the
-    // barrier that retires their slot), pieces 4-7 (B panels) in the even step of interval n+1; at barrier n
-    // the loads younger than half-stage n+1's are the 8 of half-stage n+2 -> vmcnt(8).
-#define GQ_QINTERVAL(AE, BE, OFFE, AO, BO, OFFO, SLOT2, SLOT3)                                        \
-    {                                                                                                 \
-        const int64_t h2_ = n + 2 < nhs ? n + 2 : nhs - 1, h3_ = n + 3 < nhs ? n + 3 : nhs - 1;       \
-        GQ_QSTEP(p, q, AE, BE, OFFE, (void)0, GQ_QDL(sp2, h2_, SLOT2, 4), GQ_QDL(sp2, h2_, SLOT2, 5), \
-                 GQ_QDL(sp3, h2_, SLOT2, 6), GQ_QDL(sp3, h2_, SLOT2, 7));                             \
-        GQ_QSTEP(q, p, AO, BO, OFFO, asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory"),     \
-                 GQ_QDL(sp0, h3_, SLOT3, 0), GQ_QDL(sp0, h3_, SLOT3, 1), GQ_QDL(sp1, h3_, SLOT3, 2),  \
-                 GQ_QDL(sp1, h3_, SLOT3, 3));                                                         \
-        ++n;                                                                                          \
-    }
-    for (int h = 0; h < 2; ++h) {
-        const int64_t hc = h < nhs ? h : nhs - 1;
-        GQ_QDL_(sp0, hc, h, 0); GQ_QDL_(sp0, hc, h, 1); GQ_QDL_(sp1, hc, h, 2); GQ_QDL_(sp1, hc, h, 3);
-        GQ_QDL_(sp2, hc, h, 4); GQ_QDL_(sp2, hc, h, 5); GQ_QDL_(sp3, hc, h, 6); GQ_QDL_(sp3, hc, h, 7);
-    }
-    {
-        const int64_t hc = 2 < nhs ? 2 : nhs - 1;
-        GQ_QDL_(sp0, hc, 2, 0); GQ_QDL_(sp0, hc, 2, 1); GQ_QDL_(sp1, hc, 2, 2); GQ_QDL_(sp1, hc, 2, 3);
-    }
-    asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
-    GQ_QDSR(pa0, bA00, 0); GQ_QDSR(pb0, bB00, 0); GQ_QDSR(pb1, bB00, 2048); GQ_QDSR(pa1, bA00, 2048);
-    GQ_QDSR(pb2, bB00, 4096); GQ_QDSR(pb3, bB00, 6144); GQ_QDSR(pa2, bA00, 4096); GQ_QDSR(pa3, bA00, 6144);
-    for (int64_t n = 0; n < nhs;) {  // nhs % 4 == 0 (Tp is padded to 128 tokens)
-        GQ_QINTERVAL(bA10, bB10, 0, bA00, bB00, 32768, 2, 3)      // slot 0, next slot 1
-        GQ_QINTERVAL(bA10, bB10, 32768, bA01, bB01, 0, 3, 0)      // slot 1, next slot 2
-        GQ_QINTERVAL(bA11, bB11, 0, bA01, bB01, 32768, 0, 1)      // slot 2, next slot 3
-        GQ_QINTERVAL(bA11, bB11, 32768, bA00, bB00, 0, 1, 2)      // slot 3, next slot 0
-    }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-#undef GQ_QDL
-#undef GQ_QDL_
-#undef GQ_QDSR
-#undef GQ_QLGKM1
-#undef GQ_QLGKM2
-#undef GQ_QMF
-#undef GQ_QSTEP
-#undef GQ_QINTERVAL
-#ifdef GQ_D_NOEPI
-    if (P.alpha != 12345.f) return;
-#endif
-    float* __restrict__ H = P.H;
-    const float beta = P.beta, alpha = P.alpha;
-    const int lc = lane & 31, lh = lane >> 5;
-    const int64_t i0 = ti * BT + wm * 128, j0 = tj * BT + wn * 128;
-#define GQ_QSTORE(c, i, j)                                                                            \
-    do {                                                                                              \
-        const int64_t col = j0 + (j) * 32 + lc;                                                       \
-        _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                              \
-            const int64_t row = i0 + (i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;                      \
-            const float h = beta * H[row * C + col] + alpha * c[e];                                   \
-            H[row * C + col] = h;                                                                     \
-            if (ti != tj) H[col * C + row] = h;                                                       \
-        }                                                                                             \
-    } while (0)
-    GQ_QSTORE(c00, 0, 0);
-    GQ_QSTORE(c01, 0, 1);
-    GQ_QSTORE(c02, 0, 2);
-    GQ_QSTORE(c03, 0, 3);
-    GQ_QSTORE(c10, 1, 0);
-    GQ_QSTORE(c11, 1, 1);
-    GQ_QSTORE(c12, 1, 2);
-    GQ_QSTORE(c13, 1, 3);
-    GQ_QSTORE(c20, 2, 0);
-    GQ_QSTORE(c21, 2, 1);
-    GQ_QSTORE(c22, 2, 2);
-    GQ_QSTORE(c23, 2, 3);
-    GQ_QSTORE(c30, 3, 0);
-    GQ_QSTORE(c31, 3, 1);
-    GQ_QSTORE(c32, 3, 2);
-    GQ_QSTORE(c33, 3, 3);
-#undef GQ_QSTORE
-}
-
-// ------------------ 16-bit SYRK, 256x256 tiles, 16x16x32 MFMA, direct-to-LDS operand ring (default)
 // profiles/micro/mfma_power.hip: with random fp16 operands the chip is POWER-limited on MFMA work -- a
 // register-resident loop sustains 1.70 PFLOP/s with v_mfma_f32_32x32x16_f16 and 1.95 PFLOP/s with
 // v_mfma_f32_16x16x32_f16 at two waves per SIMD (2.48 PFLOP/s on all-zero data), and the SYRK kernels run
-// at 1.3-1.45 GHz.  This is syrk16_256d_kernel with the cheaper instruction: 8 waves (2 x 4), wave tile
-// 128 x 64 = 8 x 4 accumulators of 16x16 (128 VGPRs); one ds_read_b128 now returns a whole 16-row x 32-k
+// at 1.3-1.45 GHz -- hence the cheaper instruction.  8 waves (2 x 4), wave tile 128 x 64 = 8 x 4
+// accumulators of 16x16 (128 VGPRs), one workgroup per CU.  K advances in half-stages of 32 (one 32 KiB LDS
+// image: A 256 rows x 64 B | B 256 rows x 64 B) through a ring of FOUR slots filled by
+// global_load_lds_dwordx4 (no VGPR round trip, no ds_write).  The compiler serialises every ds_read behind
+// vmcnt(0) once an LDS-DMA load is in flight, so the main loop is inline asm in exactly the written order
+// and the counters are managed by hand.  One ds_read_b128 returns a whole 16-row x 32-k
 // fragment (lane = row & 15, k-chunk = lane >> 4), so a k32 half-stage is ONE step of 32 MFMAs with the
 // 12 fragment reads of the next half-stage behind MFMAs 1,3,...,23, the barrier behind MFMA 0 and the 4 DMA
 // pieces of half-stage n+3 behind MFMAs 13/17/21/25.  At barrier n the loads younger than half-stage
-// n+1's are the 4 of half-stage n+2 -> vmcnt(4).  Operand image: transpose16_kernel mode 2 (chunk kc of
+// n+1's are the 4 of half-stage n+2 -> vmcnt(4).  Operand image: transpose16_kernel half_mode (chunk kc of
 // row r at kc ^ f((r >> 2) & 3), f = 0,2,3,1: conflict-free for this fragment shape).
 template <bool BF16>
 __global__ __launch_bounds__(512, 2) void syrk16_256e_kernel(const SyrkGroup grp) {
@@ -1106,7 +588,7 @@ __global__ __launch_bounds__(256) void syrk32_kernel(float* __restrict__ H, int6
 
 size_t h_accumulate_workspace_bytes(int64_t T, int64_t C) {
     const int64_t Tp = (T + 2 * HK - 1) / (2 * HK) * (2 * HK);
-    const size_t nt = (size_t)(C / BT);  // + the direct kernel's tile table
+    const size_t nt = (size_t)(C / BT);  // + the ring kernel's tile table
     return (size_t)C * (size_t)Tp * 2 + 256 + (nt * (nt + 1) / 2 + 320) * 4;
 }
 
@@ -1137,30 +619,25 @@ int h_accumulate_grouped(int n, float* const* H, const void* const* X, const int
     if (!ws || ws_bytes < need) GQ_FAIL(GQ_E_WORKSPACE, "gq_h_accumulate: workspace %zu < %zu bytes", ws_bytes, need);
     SyrkGroup grp;
     grp.n = n;
+    // 256x256 ring kernel when every C is a multiple of 256 (GQ_SYRK_128 forces the 128x128 kernel: comparison)
     bool big = getenv("GQ_SYRK_128") == nullptr;
     for (int i = 0; i < n; ++i) big = big && (C[i] % BT == 0);
-    const bool direct = big && getenv("GQ_SYRK_REGSTAGE") == nullptr;  // register-staged 256 kernel: comparison only
-    const bool use_e = direct && !getenv("GQ_SYRK_Q") && !getenv("GQ_SYRK_D");  // 16x16x32 MFMA kernel (default)
     int tiles = 0;
     unsigned char* wp = reinterpret_cast<unsigned char*>(((uintptr_t)ws + 255) & ~(uintptr_t)255);
     for (int i = 0; i < n; ++i) {
-        const int64_t Tp = (T[i] + 2 * HK - 1) / (2 * HK) * (2 * HK);  // whole ring turns for the direct kernel
+        const int64_t Tp = (T[i] + 2 * HK - 1) / (2 * HK) * (2 * HK);  // whole turns of the 4-slot ring
         uint16_t* Xt = reinterpret_cast<uint16_t*>(wp);
         wp += ((size_t)C[i] * Tp * 2 + 255) & ~(size_t)255;
         {
             ProfScope ps(PT_TRANSPOSE, st);
             dim3 tg((unsigned)(Tp / HK), (unsigned)(C[i] / HT));
             hipLaunchKernelGGL(transpose16_kernel, tg, block, 0, st, (const uint16_t*)X[i], T[i], C[i], Xt, Tp / HK,
-                               direct ? (use_e ? 2 : 1) : 0);
+                               big ? 1 : 0);
             GQ_LAUNCH_CHECK();
         }
-        if (big) {
-            const int nt = (int)(C[i] / BT), nsc = (nt + 7) / 8, nsr = (nt + 3) / 4;
-            grp.p[i] = SyrkProblem{H[i], Xt, C[i], Tp, beta[i], alpha[i], tiles, nt};
-            for (int sI = 0; sI < nsr; ++sI) tiles += nsc - ((sI * 4) >> 3);  // 4x8 super-tiles on/above the diagonal
-        } else {
-            const int nt = (int)(C[i] / HT);
-            grp.p[i] = SyrkProblem{H[i], Xt, C[i], Tp, beta[i], alpha[i], tiles, nt};
+        const int nt = (int)(C[i] / (big ? BT : HT));
+        grp.p[i] = SyrkProblem{H[i], Xt, C[i], Tp, beta[i], alpha[i], tiles, nt};
+        if (!big) {
             const int ns = (nt + 7) / 8;  // 8x8 super-tiles per dimension
             tiles += ns * (ns + 1) / 2;
         }
@@ -1172,23 +649,18 @@ int h_accumulate_grouped(int n, float* const* H, const void* const* X, const int
     if (!attr_set) {
         GQ_HIP(hipFuncSetAttribute((const void*)syrk16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * H_STAGE_BYTES));
         GQ_HIP(hipFuncSetAttribute((const void*)syrk16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * H_STAGE_BYTES));
-        GQ_HIP(hipFuncSetAttribute((const void*)syrk16_256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * B_STAGE_BYTES));
-        GQ_HIP(hipFuncSetAttribute((const void*)syrk16_256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * B_STAGE_BYTES));
-        GQ_HIP(hipFuncSetAttribute((const void*)syrk16_256d_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES));
-        GQ_HIP(hipFuncSetAttribute((const void*)syrk16_256d_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES));
         GQ_HIP(hipFuncSetAttribute((const void*)syrk16_256e_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES));
         GQ_HIP(hipFuncSetAttribute((const void*)syrk16_256e_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES));
-        GQ_HIP(hipFuncSetAttribute((const void*)syrk16_256q_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES));
-        GQ_HIP(hipFuncSetAttribute((const void*)syrk16_256q_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES));
         attr_set = true;
     }
     std::vector<uint32_t> table;
-    if (direct) {
+    if (big) {
         // Balanced schedule: the valid (ti <= tj) tiles of all problems, enumerated super-tile by super-tile
         // (4 x 8 tiles share 12 operand panels), are cut into groups of 32 CONSECUTIVE tiles -- one group =
         // what the 32 CUs of an XCD run at the same time out of one L2 -- and the groups are dealt
         // round-robin to the 8 XCDs, so every XCD gets the same number of tiles (+-32) and no workgroup
-        // exits early.  (The id -> super-tile map of the other kernels leaves XCDs up to 30 % apart.)
+        // exits early.  (An arithmetic id -> super-tile map leaves XCDs up to 30 % apart: diagonal
+        // super-tiles are half empty.)
         std::vector<uint32_t> all;
         for (int i = 0; i < n; ++i) {
             const int nt = grp.p[i].nt, nsc = (nt + 7) / 8, nsr = (nt + 3) / 4;
@@ -1214,22 +686,10 @@ int h_accumulate_grouped(int n, float* const* H, const void* const* X, const int
         grp.per_xcd = per_xcd;
     }
     ProfScope ps(PT_SYRK, st);
-    if (use_e) {
+    if (big) {
         const dim3 grid((unsigned)(8 * grp.per_xcd)), blk(512);
         if (x_dtype == GQ_BF16) hipLaunchKernelGGL(syrk16_256e_kernel<true>, grid, blk, S_LDS_BYTES, st, grp);
         else hipLaunchKernelGGL(syrk16_256e_kernel<false>, grid, blk, S_LDS_BYTES, st, grp);
-    } else if (direct && getenv("GQ_SYRK_Q")) {
-        const dim3 grid((unsigned)(8 * grp.per_xcd)), blk(256);
-        if (x_dtype == GQ_BF16) hipLaunchKernelGGL(syrk16_256q_kernel<true>, grid, blk, S_LDS_BYTES, st, grp);
-        else hipLaunchKernelGGL(syrk16_256q_kernel<false>, grid, blk, S_LDS_BYTES, st, grp);
-    } else if (direct) {
-        const dim3 grid((unsigned)(8 * grp.per_xcd)), blk(512);
-        if (x_dtype == GQ_BF16) hipLaunchKernelGGL(syrk16_256d_kernel<true>, grid, blk, S_LDS_BYTES, st, grp);
-        else hipLaunchKernelGGL(syrk16_256d_kernel<false>, grid, blk, S_LDS_BYTES, st, grp);
-    } else if (big) {
-        const dim3 grid((unsigned)((tiles + 7) / 8 * 8 * 32)), blk(512);
-        if (x_dtype == GQ_BF16) hipLaunchKernelGGL(syrk16_256_kernel<true>, grid, blk, 2 * B_STAGE_BYTES, st, grp);
-        else hipLaunchKernelGGL(syrk16_256_kernel<false>, grid, blk, 2 * B_STAGE_BYTES, st, grp);
     } else {
         const dim3 grid((unsigned)((tiles + 7) / 8 * 8 * 64));
         if (x_dtype == GQ_BF16) hipLaunchKernelGGL(syrk16_kernel<true>, grid, block, 2 * H_STAGE_BYTES, st, grp);
