@@ -185,21 +185,27 @@ def quantize_block(shapes, W16, X, owners, rank, world, q_type=Q4_K, block_size=
 
 
 def cpu_baseline(shapes, W16, keep):
-    """Oracle (C restatement of the reference, OpenMP) on the host cores: GPTQ.step of the
-    k_proj-shaped Linear given the same U the GPU used.  ~10-30 s of CPU work."""
+    """Oracle (C restatement of the reference, OpenMP) on the host cores: GPTQ.step of the three Linears fed by
+    the attention input (q/k/v: 25.2 M params, one shared U -- the U the GPU used).  ~10-30 s of CPU work."""
     try:
         from oracle import oracle as O
-        R, C, _ = shapes["k_proj"]
         U = keep["k_proj"][7].cpu().numpy()
-        W = W16["k_proj"].float().cpu().numpy()
         threads = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
-        t0 = time.perf_counter()
-        _, oq, *_ = O.gptq_step(W, U, Q4_K, block_size=128)
-        dt = time.perf_counter() - t0
-        same = float((oq == keep["k_proj"][0].cpu().numpy()).mean())
-        return {"value": round(R * C / dt / 1e6, 3), "unit": "Mparams/s", "cores": threads, "kind": "port",
-                "sample": f"GPTQ.step (scale search + column loop + trailing update, given U) of one {R}x{C} "
-                          f"Q4_K Linear (k_proj), {dt:.1f} s; ints equal to the GPU's: {same:.6f}"}
+        names = [n for n in ("q_proj", "k_proj", "v_proj") if n in shapes]
+        tot, same, cnt, dt = 0, 0.0, 0, 0.0
+        for n in names:
+            R, C, _ = shapes[n]
+            W = W16[n].float().cpu().numpy()
+            t0 = time.perf_counter()
+            _, oq, *_ = O.gptq_step(W, U, Q4_K, block_size=128)
+            dt += time.perf_counter() - t0
+            tot += R * C
+            same += float((oq == keep[n][0].cpu().numpy()).sum())
+            cnt += oq.size
+        return {"value": round(tot / dt / 1e6, 3), "unit": "Mparams/s", "cores": threads, "kind": "port",
+                "sample": f"GPTQ.step (scale search + column loop + trailing update, given U) of the {len(names)} "
+                          f"Q4_K Linears fed by the attention input ({'/'.join(names)}, {tot / 1e6:.1f} M params), "
+                          f"{dt:.1f} s; ints equal to the GPU's: {same / cnt:.6f}"}
     except Exception as e:  # the bench line must still print
         return {"value": None, "unit": "Mparams/s", "cores": 0, "kind": "port", "sample": f"failed: {e!r}"}
 
