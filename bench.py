@@ -117,19 +117,18 @@ def quantize_block(shapes, W16, X, owners, rank, world, q_type=Q4_K, block_size=
         ev.record(st)
         for i in grp:
             ev_ready[i] = ev
-    if world > 1:
-        for inp in sorted(H):
+    if world > 1:  # widest first: its chain is the critical one and starts as soon as ITS Hessian is reduced
+        for inp in names:
             dist.all_reduce(H[inp], op=dist.ReduceOp.AVG)  # RCCL over xGMI
+            ev = torch.cuda.Event()
+            ev.record(main)
+            ev_ready[inp] = ev
     # ---- per Linear on its owner.  Linears fed by the same input share H, hence U when their
     # dead/zero-column sets agree (gq_w_prepare checks; the leader's U is then bit-identical).
     # The input groups are independent chains (prepare -> column loop), so each runs on its own HIP
     # stream: the single-workgroup diagonal factorisations and the 64-wave column-loop kernels of one
     # chain overlap with the GEMMs of the others.
     out, pending = {}, []
-    if world > 1:  # the all-reduces above are on the main stream: one common event
-        ev = torch.cuda.Event()
-        ev.record(main)
-        ev_ready = {i: ev for i in H}
     groups = {}
     for name, (R, C, inp) in shapes.items():
         if owners[name] == rank:
