@@ -2,12 +2,12 @@
 // GEMMs of the blocked Cholesky / triangular inverse (K3) only.
 //
 // v_mfma_f32_32x32x2_f32 peaks at 157 TFLOP/s, v_mfma_f32_32x32x16_bf16 at 2.5 PFLOP/s.  Every fp32
-// operand is split EXACTLY into three bf16 terms, x = x1 + x2 + x3 + O(2^-24 x) (x1 = bf16(x),
-// x2 = bf16(x - x1), x3 = bf16(x - x1 - x2); the subtractions are exact), and a*b is accumulated in
-// fp32 from the six products whose weight is >= 2^-16: a1b3, a3b1, a2b2, a1b2, a2b1, a1b1 (smallest
-// first; each bf16 x bf16 product is exact in fp32).  The dropped terms are <= 2^-23 |a b|, the size of
-// one fp32 rounding, so the result has fp32-GEMM accuracy at 6/16 of the MFMA cost of the fp32
-// instruction.  NOT bit-identical to gq_gemm32.hpp: the GPTQ trailing update (parity gate: bit-exact
+// operand is split EXACTLY into three bf16 terms by TRUNCATION, x = x1 + x2 + x3 (x1 = the top 8
+// significand bits of x, x2 = the top 8 of x - x1, x3 = x - x1 - x2: 24 = 8 + 8 + 8, every subtraction is
+// exact and x3 fits in bf16), and a*b is accumulated in fp32 from the six products whose weight is >= 2^-16:
+// a1b3, a3b1, a2b2, a1b2, a2b1, a1b1 (smallest first; each bf16 x bf16 product is exact in fp32).  The
+// dropped terms are <= 2^-22 |a b|, the size of an fp32 rounding, so the result has fp32-GEMM accuracy at
+// 6/16 of the MFMA cost of the fp32 instruction.  NOT bit-identical to gq_gemm32.hpp: the GPTQ trailing update (parity gate: bit-exact
 // against the reference's sgemm chain) never uses this file; U = chol(H^-1) is checked in fp64
 // with an fp32 tolerance (tests/test_gpu_parity.py).
 //
@@ -26,16 +26,19 @@ typedef __bf16 g3_bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int G3_PLANE_BYTES = TM * TK * 2;           // 8 KiB
 constexpr int G3_LDS_BYTES = 6 * G3_PLANE_BYTES;      // A1 A2 A3 B1 B2 B3
 
-// x -> three bf16 (round-to-nearest-even), returned as raw 16-bit patterns
-__device__ __forceinline__ void g3_split(float x, unsigned& h1, unsigned& h2, unsigned& h3) {
-    const __bf16 b1 = (__bf16)x;
-    const float r1 = x - (float)b1;
-    const __bf16 b2 = (__bf16)r1;
-    const float r2 = r1 - (float)b2;
-    const __bf16 b3 = (__bf16)r2;
-    h1 = __builtin_bit_cast(unsigned short, b1);
-    h2 = __builtin_bit_cast(unsigned short, b2);
-    h3 = __builtin_bit_cast(unsigned short, b3);
+// two fp32 -> three dwords, each holding the bf16 pair (x, y) of one plane (x in the low half).
+// Truncation split: 2 ANDs + 2 SUBs per element, 3 v_perm_b32 per pair.
+__device__ __forceinline__ void g3_split2(float x, float y, unsigned& p1, unsigned& p2, unsigned& p3) {
+    const unsigned xb = __builtin_bit_cast(unsigned, x), yb = __builtin_bit_cast(unsigned, y);
+    const unsigned x1 = xb & 0xffff0000u, y1 = yb & 0xffff0000u;
+    const float xr = x - __builtin_bit_cast(float, x1), yr = y - __builtin_bit_cast(float, y1);
+    const unsigned xrb = __builtin_bit_cast(unsigned, xr), yrb = __builtin_bit_cast(unsigned, yr);
+    const unsigned x2 = xrb & 0xffff0000u, y2 = yrb & 0xffff0000u;
+    const float xs = xr - __builtin_bit_cast(float, x2), ys = yr - __builtin_bit_cast(float, y2);  // <= 8 significant bits
+    // v_perm_b32(hi_src, lo_src, sel): bytes 0-3 index lo_src, 4-7 hi_src; take the upper halves
+    p1 = __builtin_amdgcn_perm(y1, x1, 0x07060302u);
+    p2 = __builtin_amdgcn_perm(y2, x2, 0x07060302u);
+    p3 = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, ys), __builtin_bit_cast(unsigned, xs), 0x07060302u);
 }
 
 // [rows][32 k] fp32 chunk held as 4 float4 per thread (g32_load_rows mapping) -> three bf16 planes
@@ -43,16 +46,25 @@ __device__ __forceinline__ void g3_store_rows(const float4 (&v)[4], unsigned cha
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int idx = tid + t * 256, rr = idx >> 3, c4 = (idx & 7) * 4;
-        unsigned a[4], b[4], c[4];
-        g3_split(v[t].x, a[0], b[0], c[0]);
-        g3_split(v[t].y, a[1], b[1], c[1]);
-        g3_split(v[t].z, a[2], b[2], c[2]);
-        g3_split(v[t].w, a[3], b[3], c[3]);
+        unsigned a0, b0, c0, a1, b1, c1;
+        g3_split2(v[t].x, v[t].y, a0, b0, c0);
+        g3_split2(v[t].z, v[t].w, a1, b1, c1);
         const int off = rr * 64 + ((((c4 >> 3) ^ ((rr >> 2) & 3))) << 4) + ((c4 & 4) << 1);
-        *reinterpret_cast<uint2*>(planes + off) = make_uint2(a[0] | (a[1] << 16), a[2] | (a[3] << 16));
-        *reinterpret_cast<uint2*>(planes + G3_PLANE_BYTES + off) = make_uint2(b[0] | (b[1] << 16), b[2] | (b[3] << 16));
-        *reinterpret_cast<uint2*>(planes + 2 * G3_PLANE_BYTES + off) = make_uint2(c[0] | (c[1] << 16), c[2] | (c[3] << 16));
+        *reinterpret_cast<uint2*>(planes + off) = make_uint2(a0, a1);
+        *reinterpret_cast<uint2*>(planes + G3_PLANE_BYTES + off) = make_uint2(b0, b1);
+        *reinterpret_cast<uint2*>(planes + 2 * G3_PLANE_BYTES + off) = make_uint2(c0, c1);
     }
+}
+// g32_load_rows without edge predication: callers guarantee whole 128 x 32 chunks (M, N % 128 == 0, K % 32 == 0)
+__device__ __forceinline__ void g3_load_rows_full(float4 (&v)[4], const float* P, int64_t ld, int64_t r0, int64_t k0, int tid) {
+    const float* p = P + (r0 + (tid >> 3)) * ld + k0 + (tid & 7) * 4;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) v[t] = *reinterpret_cast<const float4*>(p + (int64_t)t * 32 * ld);
+}
+__device__ __forceinline__ void g3_load_kn_full(float (&v)[16], const float* B, int64_t ldb, int64_t n0, int64_t k0, int tid) {
+    const float* p = B + (k0 + (tid >> 7) * 16) * ldb + n0 + (tid & 127);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] = p[(int64_t)e * ldb];
 }
 // [32 k][128 n] chunk of a [K,N] matrix: thread = (n = tid & 127, 16 consecutive k from (tid >> 7) * 16)
 __device__ __forceinline__ void g3_load_kn(float (&v)[16], const float* B, int64_t ldb, int64_t n0, int64_t N, int64_t k0,
@@ -66,20 +78,17 @@ __device__ __forceinline__ void g3_store_kn(const float (&v)[16], unsigned char*
     const int rr = tid & 127, kh = tid >> 7;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {  // two 16-byte chunks of 8 k
-        unsigned a[8], b[8], d[8];
+        unsigned a[4], b[4], d[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) g3_split(v[c * 8 + e], a[e], b[e], d[e]);
+        for (int e = 0; e < 4; ++e) g3_split2(v[c * 8 + 2 * e], v[c * 8 + 2 * e + 1], a[e], b[e], d[e]);
         const int off = rr * 64 + (((kh * 2 + c) ^ ((rr >> 2) & 3)) << 4);
-        *reinterpret_cast<uint4*>(planes + off) =
-            make_uint4(a[0] | (a[1] << 16), a[2] | (a[3] << 16), a[4] | (a[5] << 16), a[6] | (a[7] << 16));
-        *reinterpret_cast<uint4*>(planes + G3_PLANE_BYTES + off) =
-            make_uint4(b[0] | (b[1] << 16), b[2] | (b[3] << 16), b[4] | (b[5] << 16), b[6] | (b[7] << 16));
-        *reinterpret_cast<uint4*>(planes + 2 * G3_PLANE_BYTES + off) =
-            make_uint4(d[0] | (d[1] << 16), d[2] | (d[3] << 16), d[4] | (d[5] << 16), d[6] | (d[7] << 16));
+        *reinterpret_cast<uint4*>(planes + off) = make_uint4(a[0], a[1], a[2], a[3]);
+        *reinterpret_cast<uint4*>(planes + G3_PLANE_BYTES + off) = make_uint4(b[0], b[1], b[2], b[3]);
+        *reinterpret_cast<uint4*>(planes + 2 * G3_PLANE_BYTES + off) = make_uint4(d[0], d[1], d[2], d[3]);
     }
 }
 
-template <bool TRANS_B, int MODE, bool LOWER, int KR = 0>
+template <bool TRANS_B, int MODE, bool LOWER, int KR = 0, bool FULL = false>
 __global__ __launch_bounds__(256, TRANS_B ? 3 : 2) void gemm3b_kernel(float* Cmat, int64_t ldc, const float* A, int64_t lda,
                                                         const float* B, int64_t ldb, int64_t M, int64_t N, int64_t K) {
     extern __shared__ __attribute__((aligned(16))) unsigned char g3_smem[];
@@ -103,9 +112,15 @@ __global__ __launch_bounds__(256, TRANS_B ? 3 : 2) void gemm3b_kernel(float* Cma
     float4 vbt[TRANS_B ? 4 : 1];
     float vbn[TRANS_B ? 1 : 16];
     auto fetch = [&](int64_t k0) {
-        g32_load_rows(va, A, lda, m0, M, k0, K, tid);
-        if constexpr (TRANS_B) g32_load_rows(vbt, B, ldb, n0, N, k0, K, tid);
-        else g3_load_kn(vbn, B, ldb, n0, N, k0, K, tid);
+        if constexpr (FULL) {
+            g3_load_rows_full(va, A, lda, m0, k0, tid);
+            if constexpr (TRANS_B) g3_load_rows_full(vbt, B, ldb, n0, k0, tid);
+            else g3_load_kn_full(vbn, B, ldb, n0, k0, tid);
+        } else {
+            g32_load_rows(va, A, lda, m0, M, k0, K, tid);
+            if constexpr (TRANS_B) g32_load_rows(vbt, B, ldb, n0, N, k0, K, tid);
+            else g3_load_kn(vbn, B, ldb, n0, N, k0, K, tid);
+        }
     };
     auto commit = [&]() {
         g3_store_rows(va, Ap, tid);
@@ -143,19 +158,16 @@ __global__ __launch_bounds__(256, TRANS_B ? 3 : 2) void gemm3b_kernel(float* Cma
                     a[i][p] = *reinterpret_cast<const g3_bf16x8*>(Ap + p * G3_PLANE_BYTES + offA[i] + (((s2 * 2 + lk) ^ swA[i]) << 4));
                     b[i][p] = *reinterpret_cast<const g3_bf16x8*>(Bp + p * G3_PLANE_BYTES + offB[i] + (((s2 * 2 + lk) ^ swB[i]) << 4));
                 }
+            // six products per accumulator, smallest first; the four accumulators are interleaved so that
+            // consecutive MFMAs never depend on each other
+            constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int t6 = 0; t6 < 6; ++t6)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    f32x16 c = acc[i][j];
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);
-                    acc[i][j] = c;
-                }
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[t6]], b[j][PB[t6]], acc[i][j], 0, 0, 0);
         }
         __syncthreads();  // every wave is done with this stage's planes
     }
@@ -168,7 +180,7 @@ __global__ __launch_bounds__(256, TRANS_B ? 3 : 2) void gemm3b_kernel(float* Cma
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int64_t rowi = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                if (rowi < M && col < N) {
+                if (FULL || (rowi < M && col < N)) {
                     float* p = Cmat + rowi * ldc + col;
                     if constexpr (MODE == 0) *p = *p - acc[i][j][e];
                     else if constexpr (MODE == 1) *p = acc[i][j][e];
@@ -185,8 +197,12 @@ inline int launch_gemm3b(float* Cmat, int64_t ldc, const float* A, int64_t lda, 
     if ((lda % 4) || (ldb % 4) || ((uintptr_t)A % 16) || ((uintptr_t)B % 16))
         GQ_FAIL(GQ_E_BAD_SHAPE, "gemm3b: A/B must be 16-byte aligned with ld %% 4 == 0");
     dim3 grid((unsigned)((N + TN - 1) / TN), (unsigned)((M + TM - 1) / TM)), block(256);
-    hipLaunchKernelGGL((gemm3b_kernel<TRANS_B, MODE, LOWER, KR>), grid, block, G3_LDS_BYTES, st, Cmat, ldc, A, lda, B, ldb,
-                       M, N, K);
+    if (M % TM == 0 && N % TN == 0 && K % TM == 0)  // whole tiles (k-ranges are 128-aligned too): no edge predication
+        hipLaunchKernelGGL((gemm3b_kernel<TRANS_B, MODE, LOWER, KR, true>), grid, block, G3_LDS_BYTES, st, Cmat, ldc, A, lda,
+                           B, ldb, M, N, K);
+    else
+        hipLaunchKernelGGL((gemm3b_kernel<TRANS_B, MODE, LOWER, KR, false>), grid, block, G3_LDS_BYTES, st, Cmat, ldc, A, lda,
+                           B, ldb, M, N, K);
     GQ_LAUNCH_CHECK();
     return GQ_OK;
 }
