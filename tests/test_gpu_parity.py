@@ -246,6 +246,52 @@ def test_h_accumulate_shapes(ops):
         assert (H.double() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item() * max(1, T / 512)
 
 
+def test_h_accumulate_grouped_full_size(ops):
+    """BASELINE shapes (C = 14336 and 4096 in one grouped launch, ragged token counts): several rounds of the
+    balanced tile table, the partial last round, the mirrored epilogue and the beta/alpha telescoping, checked on
+    sampled 256-blocks against fp64 products."""
+    torch.manual_seed(5)
+    Ts, Cs = (4096 + 37, 2048), (14336, 4096)
+    Xs = [torch.randn(T, C, device="cuda").half() for T, C in zip(Ts, Cs)]
+    Hs = [torch.zeros(C, C, device="cuda") for C in Cs]
+    ops.h_accumulate_grouped(Hs, [x[: T // 2] for x, T in zip(Xs, Ts)], [0.0, 0.0], [2.0, 2.0])
+    ops.h_accumulate_grouped(Hs, [x[T // 2:] for x, T in zip(Xs, Ts)], [0.5, 0.5], [1.0, 1.0])  # beta*H + alpha*X^T X
+    for H, X, C in zip(Hs, Xs, Cs):
+        T = X.shape[0]
+        h = T // 2
+        for (r0, c0) in ((0, 0), (C - 256, C - 256), (256, C - 512), (C // 2, C // 2 + 256), (C - 512, 0)):
+            a, b = X[:, r0:r0 + 256].double(), X[:, c0:c0 + 256].double()
+            ref = 0.5 * 2.0 * (a[:h].T @ b[:h]) + 1.0 * (a[h:].T @ b[h:])
+            got = H[r0:r0 + 256, c0:c0 + 256].double()
+            assert (got - ref).abs().max().item() <= 3e-6 * ref.abs().max().item() * max(1, T / 512), (C, r0, c0)
+        i = torch.randint(0, C, (4096,), device="cuda")
+        j = torch.randint(0, C, (4096,), device="cuda")
+        assert torch.equal(H[i, j], H[j, i])  # mirrored bit-for-bit
+
+
+def test_h_prepare_full_size(ops):
+    """C = 14336 (down_proj): split-bf16 GEMMs at every level of the recursion; U^T U H_damped == I on sampled
+    columns in fp64, U upper triangular."""
+    torch.manual_seed(6)
+    C = 14336
+    X = (torch.randn(2 * C, C, device="cuda") * torch.exp(torch.randn(C, device="cuda") * 0.5)).half()
+    H = torch.zeros(C, C, device="cuda")
+    ops.h_accumulate(H, X, 0.0, 2.0 / 8)
+    del X
+    W = torch.randn(64, C, device="cuda")
+    U, flag = ops.h_prepare(H, W, 0.01)  # H now holds the damped matrix
+    assert int(flag.item()) == 0
+    cols = torch.tensor([0, 1, 127, 128, 4095, 7167, 7168, 9000, C - 129, C - 1], device="cuda")
+    Ud = U.double()
+    Y = Ud.T @ (Ud @ H[:, cols].double())  # (U^T U) H e_c
+    E = torch.zeros(C, cols.numel(), device="cuda", dtype=torch.float64)
+    E[cols, torch.arange(cols.numel(), device="cuda")] = 1.0
+    assert (Y - E).abs().max().item() < 2e-2
+    r = torch.randint(1, C, (4096,), device="cuda")
+    c = (torch.rand(4096, device="cuda") * r).long()  # c < r: strictly lower
+    assert bool((U[r, c] == 0).all())
+
+
 # --------------------------------------------------------------- K2/K3 prepare
 def test_h_prepare_golden(ops):
     g = load_golden("g4_g5_hessian")
