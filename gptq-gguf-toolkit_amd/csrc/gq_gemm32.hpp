@@ -150,21 +150,28 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(float* Cmat, int64_t ldc
         if (t + 1 < nk) fetch(kb + (t + 1) * TK);  // in flight during the MFMA block
         const float* As = g32_smem + (t & 1) * G32_STAGE_FLOATS;
         const float* Bs = As + G32_A_FLOATS;
-#pragma unroll 4
-        for (int kk = 0; kk < TK; kk += 2) {
-            float av[2], bv[2];
+        // operands of k-step kk+2 are read while the 4 MFMAs of step kk run (explicit register double buffer:
+        // left to the compiler, every 4 MFMAs waited for their own LDS reads)
+        float av[2][2], bv[2][2];
+        auto frag = [&](int kk, float (&a)[2], float (&b)[2]) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) av[i] = As[(wm * 64 + i * 32 + li) * LDA_S + kk + lk];
+            for (int i = 0; i < 2; ++i) a[i] = As[(wm * 64 + i * 32 + li) * LDA_S + kk + lk];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                if constexpr (TRANS_B) bv[j] = Bs[(wn * 64 + j * 32 + li) * LDBT_S + kk + lk];
-                else bv[j] = Bs[(kk + lk) * LDB_S + wn * 64 + j * 32 + li];
+                if constexpr (TRANS_B) b[j] = Bs[(wn * 64 + j * 32 + li) * LDBT_S + kk + lk];
+                else b[j] = Bs[(kk + lk) * LDB_S + wn * 64 + j * 32 + li];
             }
+        };
+        frag(0, av[0], bv[0]);
+#pragma unroll
+        for (int kk = 0; kk < TK; kk += 2) {
+            const int cur = (kk >> 1) & 1;
+            if (kk + 2 < TK) frag(kk + 2, av[cur ^ 1], bv[cur ^ 1]);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i], bv[cur][j], acc[i][j], 0, 0, 0);
         }
         if constexpr (CHAIN != 0) {
             if (((t + 1) * TK) % CHAIN == 0) {  // end of a slice: one subtraction, new chain
