@@ -292,6 +292,31 @@ def test_h_prepare_full_size(ops):
     assert bool((U[r, c] == 0).all())
 
 
+def test_llama70b_down_proj_shape(ops):
+    """Largest BASELINE shape (Llama-3-70B down_proj: C = 28672): accumulate -> prepare -> column loop on a row slice;
+    exercises 112 x 112 tile tables, 224 diagonal blocks and 32-bit-safe indexing (C*C = 8.2e8 elements)."""
+    torch.manual_seed(8)
+    C, T, R = 28672, 4096, 256
+    X = (torch.randn(T, C, device="cuda") * torch.exp(torch.randn(C, device="cuda") * 0.5)).half()
+    H = torch.zeros(C, C, device="cuda")
+    ops.h_accumulate(H, X, 0.0, 2.0 / 2)
+    i = torch.randint(0, C, (2048,), device="cuda")
+    j = torch.randint(0, C, (2048,), device="cuda")
+    ref = 1.0 * (X[:, i].double() * X[:, j].double()).sum(0)
+    assert ((H[i, j].double() - ref).abs() <= 1e-5 * ref.abs().max()).all()
+    del X
+    W0 = (torch.randn(R, C, device="cuda") * 0.02).half().float()
+    W = W0.clone()
+    U, flag = ops.h_prepare(H, W, 0.01)  # T < C: H is rank-deficient, the damping makes it definite
+    assert int(flag.item()) == 0
+    t = TYPES["Q4_K"]
+    q, d, s, dmin, m = ops.gptq_quantize(W, U, t, block_size=128)
+    deq = ops.dequantize(t, q, d, s, dmin, m)
+    assert bool((W == deq).all()) and int(q.min()) >= 0 and int(q.max()) <= 15
+    rel = ((deq - W0).norm() / W0.norm()).item()
+    assert rel < 0.2, rel
+
+
 # --------------------------------------------------------------- K2/K3 prepare
 def test_h_prepare_golden(ops):
     g = load_golden("g4_g5_hessian")
