@@ -28,10 +28,11 @@ int launch_scale_search(const float* x, int64_t rows, int64_t ld, int q_type, co
 //   qparams d/dmin [R, C/256], s/m [R, C/G] already hold the super-group of `a`
 constexpr int SEG = 128;
 constexpr int SB = 16;  // register sub-block
+constexpr int SEG_WAVES = 8;  // wave 0 walks the dependent chain, all waves share the rank-1 tile updates
 constexpr int SEG_LDS_BYTES = (SEG * 64 + SEG * SEG + SB * 64) * 4;
 
 template <bool PERM>
-__global__ __launch_bounds__(256) void gptq_segment_kernel(
+__global__ __launch_bounds__(SEG_WAVES * 64) void gptq_segment_kernel(
     float* W, int64_t C, const float* src, int64_t ld_src,  // may alias (single-segment blocks)
     const float* __restrict__ U, int64_t a, int len, int64_t R,
     const uint16_t* __restrict__ d, const uint8_t* __restrict__ s, const uint16_t* __restrict__ dmin,
@@ -39,15 +40,15 @@ __global__ __launch_bounds__(256) void gptq_segment_kernel(
     uint8_t* __restrict__ qweight, float* __restrict__ Err, int64_t ld_err, int64_t err_col0,
     const int32_t* __restrict__ perm) {  // PERM (act_order, gptq.py:211-216): column j takes the parameters of
                                          // the group of its ORIGINAL column perm[j]
-    // One workgroup = 64 rows (lane = row) x 4 waves.  Wave 0 walks the columns (the dependent chain);
-    // after every 16-column sub-block all four waves share the rank-1 updates of the later columns.
+    // One workgroup = 64 rows (lane = row) x SEG_WAVES waves.  Wave 0 walks the columns (the dependent chain);
+    // after every 16-column sub-block all waves share the rank-1 updates of the later columns.
     extern __shared__ __attribute__((aligned(16))) float seg_smem[];
     float* wl = seg_smem;                   // wl[j*64 + lane]: working copy, column-major (32 KiB)
     float* Us = seg_smem + SEG * 64;        // Us[i*SEG + j] = U[a+i, a+j]: diagonal block (64 KiB), read back
                                             // with wave-uniform (broadcast) 16-byte LDS loads
     float* ne = Us + SEG * SEG;             // ne[k*64 + lane]: -err of the current sub-block (4 KiB)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    for (int idx = tid; idx < len * (SEG / 4); idx += 256) {
+    for (int idx = tid; idx < len * (SEG / 4); idx += SEG_WAVES * 64) {
         const int i = idx / (SEG / 4), j4 = (idx % (SEG / 4)) * 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (j4 < len) v = *reinterpret_cast<const float4*>(U + (a + i) * C + a + j4);
@@ -60,8 +61,7 @@ __global__ __launch_bounds__(256) void gptq_segment_kernel(
     // gptq.py:225 w_blk = w[:, c1:c2].clone()  (each wave brings in a quarter of the columns)
     {
         const float* sp = src + r * ld_src;
-        const int q4 = len / 4;
-        for (int j = wid * q4; j < (wid + 1) * q4; j += 4) {
+        for (int j = wid * 4; j < len; j += 4 * SEG_WAVES) {
             float4 v = *reinterpret_cast<const float4*>(sp + j);
             wl[(j + 0) * 64 + lane] = v.x;
             wl[(j + 1) * 64 + lane] = v.y;
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void gptq_segment_kernel(
         // (packed v_pk_mul_f32 / v_pk_add_f32 were measured 35 % SLOWER here)
         int t = 0;
         for (int j0 = i0 + SB; j0 < len; j0 += SB, ++t) {
-            if ((t & 3) != wid) continue;
+            if ((t % SEG_WAVES) != wid) continue;
             float wt[SB], nk[SB];
 #pragma unroll
             for (int jj = 0; jj < SB; ++jj) wt[jj] = wl[(j0 + jj) * 64 + lane];
@@ -241,7 +241,7 @@ int gptq_quantize(float* W, const float* U, int64_t R, int64_t C, int q_type, in
                                           dmin + c / 256, nsg, m + (c / 256) * gps, ng, st)))
                 return rc;
     }
-    const dim3 seg_grid((unsigned)((R + 63) / 64)), seg_block(256);
+    const dim3 seg_grid((unsigned)((R + 63) / 64)), seg_block(SEG_WAVES * 64);
     static bool seg_attr = false;
     if (!seg_attr) {
         GQ_HIP(hipFuncSetAttribute((const void*)gptq_segment_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
