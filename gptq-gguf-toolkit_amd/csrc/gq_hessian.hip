@@ -287,8 +287,13 @@ __global__ __launch_bounds__(512, 2) void syrk16_256e_kernel(const SyrkGroup grp
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid >> 2, wn = wid & 3;
-    const uint32_t ent = grp.table[(blockIdx.x & 7) * grp.per_xcd + (blockIdx.x >> 3)];
-    if (ent == 0xffffffffu) return;
+    // Workgroup b serves XCD b % 8 and walks that XCD's tile list with stride gridDim.x / 8 (one tile each with the
+    // default grid).  Measured with a capped grid (64-192 workgroups) for the gap-filling second launch of a
+    // block: no gain over the uncapped launch -- the step is bound by total work, not by the launch order.
+    for (int slot = (int)(blockIdx.x >> 3); slot < grp.per_xcd; slot += (int)(gridDim.x >> 3)) {
+    const uint32_t ent = grp.table[(blockIdx.x & 7) * grp.per_xcd + slot];
+    if (ent == 0xffffffffu) break;  // lists are dense; padding only at the end
+    __syncthreads();                // every wave is done with the ring of the previous tile
     const SyrkProblem& P = grp.p[ent >> 24];
     const int64_t ti = (ent >> 12) & 0xfff, tj = ent & 0xfff;
     const int64_t C = P.C;
@@ -463,7 +468,7 @@ __global__ __launch_bounds__(512, 2) void syrk16_256e_kernel(const SyrkGroup grp
 #undef GQ_ESTEP
 #undef GQ_EINTERVAL
 #ifdef GQ_D_NOEPI
-    if (P.alpha != 12345.f) return;
+    if (P.alpha != 12345.f) continue;
 #endif
     float* __restrict__ H = P.H;
     const float beta = P.beta, alpha = P.alpha;
@@ -511,6 +516,7 @@ __global__ __launch_bounds__(512, 2) void syrk16_256e_kernel(const SyrkGroup grp
     GQ_ESTORE(c72, 7, 2);
     GQ_ESTORE(c73, 7, 3);
 #undef GQ_ESTORE
+    }  // tile loop
 }
 
 // --------------------------------------------------------------- fp32 SYRK
@@ -687,7 +693,7 @@ int h_accumulate_grouped(int n, float* const* H, const void* const* X, const int
     }
     ProfScope ps(PT_SYRK, st);
     if (big) {
-        const dim3 grid((unsigned)(8 * grp.per_xcd)), blk(512);
+        const dim3 grid((unsigned)(8 * grp.per_xcd)), blk(512);  // one tile per workgroup (fewer would walk the lists)
         if (x_dtype == GQ_BF16) hipLaunchKernelGGL(syrk16_256e_kernel<true>, grid, blk, S_LDS_BYTES, st, grp);
         else hipLaunchKernelGGL(syrk16_256e_kernel<false>, grid, blk, S_LDS_BYTES, st, grp);
     } else {
