@@ -291,7 +291,9 @@ __global__ __launch_bounds__(512, 2) void syrk16_256e_kernel(const SyrkGroup grp
     // default grid).  Measured with a capped grid (64-192 workgroups) for the gap-filling second launch of a
     // block: no gain over the uncapped launch -- the step is bound by total work, not by the launch order.
     for (int slot = (int)(blockIdx.x >> 3); slot < grp.per_xcd; slot += (int)(gridDim.x >> 3)) {
-    const uint32_t ent = grp.table[(blockIdx.x & 7) * grp.per_xcd + slot];
+    // readfirstlane: everything derived from the entry (panel base pointers used as SGPR asm operands) must be
+    // provably wave-uniform for the compiler
+    const uint32_t ent = (uint32_t)__builtin_amdgcn_readfirstlane((int)grp.table[(blockIdx.x & 7) * grp.per_xcd + slot]);
     if (ent == 0xffffffffu) break;  // lists are dense; padding only at the end
     __syncthreads();                // every wave is done with the ring of the previous tile
     const SyrkProblem& P = grp.p[ent >> 24];
@@ -473,15 +475,19 @@ __global__ __launch_bounds__(512, 2) void syrk16_256e_kernel(const SyrkGroup grp
     float* __restrict__ H = P.H;
     const float beta = P.beta, alpha = P.alpha;
     const int64_t i0 = ti * BT + wm * 128 + 4 * lk, j0 = tj * BT + wn * 64 + lr;
+    // the four accumulator elements of a lane are four consecutive ROWS of one column: the mirrored copy is one
+    // 16-byte store per lane (four lanes = one 64-byte segment of the mirrored row)
 #define GQ_ESTORE(c, i, j)                                                                            \
     do {                                                                                              \
-        const int64_t col = j0 + (j) * 16;                                                            \
-        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                               \
-            const int64_t row = i0 + (i) * 16 + e;                                                    \
-            const float h = beta * H[row * C + col] + alpha * c[e];                                   \
-            H[row * C + col] = h;                                                                     \
-            if (ti != tj) H[col * C + row] = h;                                                       \
-        }                                                                                             \
+        const int64_t col = j0 + (j) * 16, row = i0 + (i) * 16;                                       \
+        float4 h;                                                                                     \
+        h.x = beta * H[(row + 0) * C + col] + alpha * c[0];                                           \
+        h.y = beta * H[(row + 1) * C + col] + alpha * c[1];                                           \
+        h.z = beta * H[(row + 2) * C + col] + alpha * c[2];                                           \
+        h.w = beta * H[(row + 3) * C + col] + alpha * c[3];                                           \
+        H[(row + 0) * C + col] = h.x; H[(row + 1) * C + col] = h.y;                                   \
+        H[(row + 2) * C + col] = h.z; H[(row + 3) * C + col] = h.w;                                   \
+        if (ti != tj) *reinterpret_cast<float4*>(H + col * C + row) = h;                              \
     } while (0)
     GQ_ESTORE(c00, 0, 0);
     GQ_ESTORE(c01, 0, 1);
