@@ -38,7 +38,7 @@ sys.path.insert(0, ROOT)
 from gptq_gguf_toolkit_amd import _cabi, dist_utils, ops  # noqa: E402
 
 Q4_K = 12
-SYRK_TRAFFIC_GB_PER_LAUNCH = 70.85  # (117.9 + 23.8) / 2, see profiles/r01_syrk_pmc.txt
+SYRK_TRAFFIC_GB_PER_LAUNCH = 73.84  # (125.6 + 22.1) / 2, see profiles/r01_syrk_pmc.txt
 # Llama-3-8B block: name -> (R, C, input group)
 LLAMA3_8B = {
     "q_proj": (4096, 4096, "attn_in"), "k_proj": (1024, 4096, "attn_in"), "v_proj": (1024, 4096, "attn_in"),
@@ -308,7 +308,7 @@ def main():
             nt = C // 128
             flops += x.shape[0] * args.steps * 2.0 * L * 128 * 128 * (nt * (nt + 1) // 2)  # all launches together
         ach = flops / (syrk_ms * 1e-3) / 1e12 if syrk_ms > 0 else None
-        roof = {"bound": "mfma", "kernel": "syrk16_256e_kernel<f16> (gq_h_accumulate_grouped)",
+        roof = {"bound": "mfma", "kernel": "syrk16_256n_kernel<f16> (gq_h_accumulate_grouped)",
                 "achieved": round(ach, 2) if ach else None, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_F16_MFMA_TFLOPS, 4) if ach else None,
                 # PMC cannot be read live: L2-miss reads per SYRK launch (rocprofv3 --pmc FETCH_SIZE on this very

@@ -266,6 +266,7 @@ constexpr int S_BUF_BYTES = 2 * BT * SK * 2;    // one ring slot: A 16 KiB | B 1
 constexpr int S_NBUF = 4;
 constexpr int S_LDS_BYTES = S_NBUF * S_BUF_BYTES;  // 128 KiB
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 // profiles/micro/mfma_power.hip: with random fp16 operands the chip is POWER-limited on MFMA work -- a
 // register-resident loop sustains 1.70 PFLOP/s with v_mfma_f32_32x32x16_f16 and 1.95 PFLOP/s with
@@ -525,6 +526,289 @@ __global__ __launch_bounds__(512, 2) void syrk16_256e_kernel(const SyrkGroup grp
     }  // tile loop
 }
 
+// -------------- 16-bit SYRK, 256x256 tiles, NATURAL activation layout (no re-layout pass), gfx950 transpose reads
+// Same tile / wave shape, ring, hand-ordered stream and tile table as syrk16_256e_kernel, but the ring slots hold
+// X as it lies in memory -- [32 tokens][256 channels] per operand, 512-byte rows -- and the MFMA fragments are
+// assembled by ds_read_b64_tr_b16: per 16-lane group, lane j passes the address of 4 consecutive channels of token
+// row j>>2 and receives channel j of that 4x16 block, i.e. 4 consecutive tokens of one channel; two reads (token
+// rows +0..3 and +4..7) are the 8-deep k-slice of one lane of a 16x16x32 operand (profiles/micro/tr_read_probe.hip).
+// Bank conflicts: the 8 rows one instruction touches are 512 bytes apart; the 32-byte fragment slot F of row r is
+// therefore stored at slot F ^ g(r), g(r) = (r & 3) | ((r >> 3) & 1) << 2 (conflict-free, tr_read_banks.hip) -- the
+// permutation is applied by the DMA source addresses, the fragment address is base ^ (i << 5).
+// Per k32 step: 32 MFMAs; fragments a0,b0..b3,a1,a2 of the NEXT half-stage are read behind MFMAs 12..25 into the
+// other register set, a3..a7 of the CURRENT one behind MFMAs 0..9 (single set) -- never more than 15 LDS reads in
+// flight (lgkmcnt is 4 bits).  Requires T % 128 == 0 (whole ring turns); other T take the re-layout path.
+template <bool BF16>
+__global__ __launch_bounds__(512, 2) void syrk16_256n_kernel(const SyrkGroup grp) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 2, wn = wid & 3;
+    for (int slot = (int)(blockIdx.x >> 3); slot < grp.per_xcd; slot += (int)(gridDim.x >> 3)) {
+    const uint32_t ent = (uint32_t)__builtin_amdgcn_readfirstlane((int)grp.table[(blockIdx.x & 7) * grp.per_xcd + slot]);
+    if (ent == 0xffffffffu) break;
+    __syncthreads();
+    const SyrkProblem& P = grp.p[ent >> 24];
+    const int64_t ti = (ent >> 12) & 0xfff, tj = ent & 0xfff;
+    const int64_t C = P.C;
+    const int nhs = (int)(P.Tp / SK);          // Tp = T here
+    const unsigned lds0 = (unsigned)(uintptr_t)smem;
+    // ---- DMA: waves 0-3 bring the A image (channels 256 ti ..), waves 4-7 the B image; wave w & 3 owns token rows
+    // 8 (w & 3) .. +7 of every half-stage as four 1 KiB pieces of two rows each
+    const int op = wid >> 2, rb = 8 * (wid & 3);
+    const char* gsrc = reinterpret_cast<const char*>(P.Xt) + (op ? tj : ti) * 512;
+    const int64_t hstride = 32 * C * 2;        // bytes per half-stage
+    unsigned voff0, voff1, voff2, voff3;
+    {
+        const int hrow = lane >> 5, s16 = lane & 31;
+#define GQ_NVOFF(u)                                                                                   \
+        ([&] {                                                                                        \
+            const int r_ = rb + 2 * (u) + hrow;                                                       \
+            const int g_ = (r_ & 3) | (((r_ >> 3) & 1) << 2);                                         \
+            return (unsigned)(r_ * C * 2) + (unsigned)((((s16 >> 1) ^ g_) << 5) + ((s16 & 1) << 4));  \
+        }())
+        voff0 = GQ_NVOFF(0); voff1 = GQ_NVOFF(1); voff2 = GQ_NVOFF(2); voff3 = GQ_NVOFF(3);
+#undef GQ_NVOFF
+    }
+    const unsigned ldsw = lds0 + (unsigned)(op * 16384 + rb * 512);
+    int hnext = 0;
+    const char* gbase = gsrc;
+#ifdef GQ_D_NOLOAD
+#define GQ_NDL(vo, slot_, u) (void)0
+#else
+#define GQ_NDL(vo, slot_, u) GQ_NDL_(vo, slot_, u)
+#endif
+#define GQ_NDL_(vo, slot_, u)                                                                         \
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"                      \
+                 :: "v"(vo), "s"(gbase), "s"(ldsw + (unsigned)((slot_) * S_BUF_BYTES + (u) * 1024)) : "memory")
+#define GQ_NADV()                                                                                     \
+    do {                                                                                              \
+        hnext = hnext + 1 < nhs ? hnext + 1 : nhs - 1;                                                \
+        gbase = gsrc + (int64_t)hnext * hstride;                                                      \
+    } while (0)
+    // ---- fragment addresses (see header): lane = (k-group kc, row-in-group q, 8-byte chunk ch)
+    unsigned bAlo, bAhi, bBlo, bBhi;
+    {
+        const int kc = lane >> 4, q = (lane & 15) >> 2, ch = lane & 3;
+        const int r = 8 * kc + q, g = q | ((kc & 1) << 2);
+        bAlo = lds0 + (unsigned)(r * 512 + (((wm * 8) | g) << 5) + ch * 8);
+        bBlo = lds0 + 16384u + (unsigned)(r * 512 + ((((wn << 2)) ^ g) << 5) + ch * 8);
+        bAhi = bAlo + 65536u;
+        bBhi = bBlo + 65536u;
+    }
+    f32x4 c00, c01, c02, c03, c10, c11, c12, c13, c20, c21, c22, c23, c30, c31, c32, c33, c40, c41, c42, c43, c50, c51, c52, c53, c60, c61, c62, c63, c70, c71, c72, c73;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        c00[e] = 0.f;
+        c01[e] = 0.f;
+        c02[e] = 0.f;
+        c03[e] = 0.f;
+        c10[e] = 0.f;
+        c11[e] = 0.f;
+        c12[e] = 0.f;
+        c13[e] = 0.f;
+        c20[e] = 0.f;
+        c21[e] = 0.f;
+        c22[e] = 0.f;
+        c23[e] = 0.f;
+        c30[e] = 0.f;
+        c31[e] = 0.f;
+        c32[e] = 0.f;
+        c33[e] = 0.f;
+        c40[e] = 0.f;
+        c41[e] = 0.f;
+        c42[e] = 0.f;
+        c43[e] = 0.f;
+        c50[e] = 0.f;
+        c51[e] = 0.f;
+        c52[e] = 0.f;
+        c53[e] = 0.f;
+        c60[e] = 0.f;
+        c61[e] = 0.f;
+        c62[e] = 0.f;
+        c63[e] = 0.f;
+        c70[e] = 0.f;
+        c71[e] = 0.f;
+        c72[e] = 0.f;
+        c73[e] = 0.f;
+    }
+    u32x2 pa0l, pa0h, pb0l, pb0h, pb1l, pb1h, pb2l, pb2h, pb3l, pb3h, pa1l, pa1h, pa2l, pa2h;
+    u32x2 qa0l, qa0h, qb0l, qb0h, qb1l, qb1h, qb2l, qb2h, qb3l, qb3h, qa1l, qa1h, qa2l, qa2h;
+    u32x2 la3l, la3h, la4l, la4h, la5l, la5h, la6l, la6h, la7l, la7h;
+#define GQ_NRD(dst, base, idx, off)                                                                   \
+    do {                                                                                              \
+        const unsigned t_ = (base) ^ ((unsigned)(idx) << 5);                                          \
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(t_), "n"(off) : "memory"); \
+    } while (0)
+#define GQ_NWAIT(N, x, y) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(x), "+v"(y)::"memory")
+#define GQ_NMF(c, al, ah, bl, bh)                                                                     \
+    do {                                                                                              \
+        const u32x4 A_ = __builtin_shufflevector(al, ah, 0, 1, 2, 3), B_ = __builtin_shufflevector(bl, bh, 0, 1, 2, 3); \
+        if constexpr (BF16) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(A_), "v"(B_)); \
+        else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(A_), "v"(B_));     \
+    } while (0)
+#define GQ_NBAR() asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory")
+#define GQ_NSTEP(X, Y, AC, OFFC, AN, BN, OFFN, L0, L1, L2, L3)                                        \
+    do {                                                                                              \
+        GQ_NWAIT(12, X##a0l, X##a0h);                                                                 \
+        GQ_NWAIT(10, X##b0l, X##b0h);                                                                 \
+        GQ_NMF(c00, X##a0l, X##a0h, X##b0l, X##b0h);                                                  \
+        GQ_NRD(la3l, AC, 3, (OFFC) + 0);                                                              \
+        GQ_NWAIT(9, X##b1l, X##b1h);                                                                  \
+        GQ_NMF(c01, X##a0l, X##a0h, X##b1l, X##b1h);                                                  \
+        GQ_NRD(la3h, AC, 3, (OFFC) + 2048);                                                           \
+        GQ_NWAIT(8, X##b2l, X##b2h);                                                                  \
+        GQ_NMF(c02, X##a0l, X##a0h, X##b2l, X##b2h);                                                  \
+        GQ_NRD(la4l, AC, 4, (OFFC) + 0);                                                              \
+        GQ_NWAIT(7, X##b3l, X##b3h);                                                                  \
+        GQ_NMF(c03, X##a0l, X##a0h, X##b3l, X##b3h);                                                  \
+        GQ_NRD(la4h, AC, 4, (OFFC) + 2048);                                                           \
+        GQ_NWAIT(6, X##a1l, X##a1h);                                                                  \
+        GQ_NMF(c10, X##a1l, X##a1h, X##b0l, X##b0h);                                                  \
+        GQ_NRD(la5l, AC, 5, (OFFC) + 0);                                                              \
+        GQ_NMF(c11, X##a1l, X##a1h, X##b1l, X##b1h);                                                  \
+        GQ_NRD(la5h, AC, 5, (OFFC) + 2048);                                                           \
+        GQ_NMF(c12, X##a1l, X##a1h, X##b2l, X##b2h);                                                  \
+        GQ_NRD(la6l, AC, 6, (OFFC) + 0);                                                              \
+        GQ_NMF(c13, X##a1l, X##a1h, X##b3l, X##b3h);                                                  \
+        GQ_NRD(la6h, AC, 6, (OFFC) + 2048);                                                           \
+        GQ_NWAIT(8, X##a2l, X##a2h);                                                                  \
+        GQ_NMF(c20, X##a2l, X##a2h, X##b0l, X##b0h);                                                  \
+        GQ_NRD(la7l, AC, 7, (OFFC) + 0);                                                              \
+        GQ_NMF(c21, X##a2l, X##a2h, X##b1l, X##b1h);                                                  \
+        GQ_NRD(la7h, AC, 7, (OFFC) + 2048);                                                           \
+        GQ_NMF(c22, X##a2l, X##a2h, X##b2l, X##b2h);                                                  \
+        GQ_NBAR();                                                                                    \
+        GQ_NMF(c23, X##a2l, X##a2h, X##b3l, X##b3h);                                                  \
+        L0;                                                                                           \
+        GQ_NWAIT(8, la3l, la3h);                                                                      \
+        GQ_NMF(c30, la3l, la3h, X##b0l, X##b0h);                                                      \
+        GQ_NRD(Y##a0l, AN, 0, (OFFN) + 0);                                                            \
+        GQ_NMF(c31, la3l, la3h, X##b1l, X##b1h);                                                      \
+        L1;                                                                                           \
+        GQ_NRD(Y##a0h, AN, 0, (OFFN) + 2048);                                                         \
+        GQ_NMF(c32, la3l, la3h, X##b2l, X##b2h);                                                      \
+        GQ_NRD(Y##b0l, BN, 0, (OFFN) + 0);                                                            \
+        GQ_NMF(c33, la3l, la3h, X##b3l, X##b3h);                                                      \
+        L2;                                                                                           \
+        GQ_NRD(Y##b0h, BN, 0, (OFFN) + 2048);                                                         \
+        GQ_NWAIT(10, la4l, la4h);                                                                     \
+        GQ_NMF(c40, la4l, la4h, X##b0l, X##b0h);                                                      \
+        GQ_NRD(Y##b1l, BN, 1, (OFFN) + 0);                                                            \
+        GQ_NMF(c41, la4l, la4h, X##b1l, X##b1h);                                                      \
+        L3;                                                                                           \
+        GQ_NRD(Y##b1h, BN, 1, (OFFN) + 2048);                                                         \
+        GQ_NMF(c42, la4l, la4h, X##b2l, X##b2h);                                                      \
+        GQ_NRD(Y##b2l, BN, 2, (OFFN) + 0);                                                            \
+        GQ_NMF(c43, la4l, la4h, X##b3l, X##b3h);                                                      \
+        GQ_NRD(Y##b2h, BN, 2, (OFFN) + 2048);                                                         \
+        GQ_NWAIT(12, la5l, la5h);                                                                     \
+        GQ_NMF(c50, la5l, la5h, X##b0l, X##b0h);                                                      \
+        GQ_NRD(Y##b3l, BN, 3, (OFFN) + 0);                                                            \
+        GQ_NMF(c51, la5l, la5h, X##b1l, X##b1h);                                                      \
+        GQ_NRD(Y##b3h, BN, 3, (OFFN) + 2048);                                                         \
+        GQ_NMF(c52, la5l, la5h, X##b2l, X##b2h);                                                      \
+        GQ_NRD(Y##a1l, AN, 1, (OFFN) + 0);                                                            \
+        GQ_NMF(c53, la5l, la5h, X##b3l, X##b3h);                                                      \
+        GQ_NWAIT(13, la6l, la6h);                                                                     \
+        GQ_NRD(Y##a1h, AN, 1, (OFFN) + 2048);                                                         \
+        GQ_NMF(c60, la6l, la6h, X##b0l, X##b0h);                                                      \
+        GQ_NRD(Y##a2l, AN, 2, (OFFN) + 0);                                                            \
+        GQ_NMF(c61, la6l, la6h, X##b1l, X##b1h);                                                      \
+        GQ_NWAIT(13, la7l, la7h);                                                                     \
+        GQ_NRD(Y##a2h, AN, 2, (OFFN) + 2048);                                                         \
+        GQ_NMF(c62, la6l, la6h, X##b2l, X##b2h);                                                      \
+        GQ_NMF(c63, la6l, la6h, X##b3l, X##b3h);                                                      \
+        GQ_NMF(c70, la7l, la7h, X##b0l, X##b0h);                                                      \
+        GQ_NMF(c71, la7l, la7h, X##b1l, X##b1h);                                                      \
+        GQ_NMF(c72, la7l, la7h, X##b2l, X##b2h);                                                      \
+        GQ_NMF(c73, la7l, la7h, X##b3l, X##b3h);                                                      \
+    } while (0)
+#define GQ_NINTERVAL(X, Y, AC, OFFC, AN, BN, OFFN, SLOT3)                                             \
+    GQ_NSTEP(X, Y, AC, OFFC, AN, BN, OFFN, GQ_NDL(voff0, SLOT3, 0), GQ_NDL(voff1, SLOT3, 1),          \
+             GQ_NDL(voff2, SLOT3, 2), GQ_NDL(voff3, SLOT3, 3));                                       \
+    GQ_NADV();
+
+    for (int h = 0; h < 3; ++h) {
+        GQ_NDL_(voff0, h, 0); GQ_NDL_(voff1, h, 1); GQ_NDL_(voff2, h, 2); GQ_NDL_(voff3, h, 3);
+        GQ_NADV();
+    }
+    asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    GQ_NRD(pa0l, bAlo, 0, 0); GQ_NRD(pa0h, bAlo, 0, 2048);
+    GQ_NRD(pb0l, bBlo, 0, 0); GQ_NRD(pb0h, bBlo, 0, 2048);
+    GQ_NRD(pb1l, bBlo, 1, 0); GQ_NRD(pb1h, bBlo, 1, 2048);
+    GQ_NRD(pb2l, bBlo, 2, 0); GQ_NRD(pb2h, bBlo, 2, 2048);
+    GQ_NRD(pb3l, bBlo, 3, 0); GQ_NRD(pb3h, bBlo, 3, 2048);
+    GQ_NRD(pa1l, bAlo, 1, 0); GQ_NRD(pa1h, bAlo, 1, 2048);
+    GQ_NRD(pa2l, bAlo, 2, 0); GQ_NRD(pa2h, bAlo, 2, 2048);
+    for (int n = 0; n < nhs; n += 4) {  // nhs % 4 == 0; interval n multiplies slot n & 3
+        GQ_NINTERVAL(p, q, bAlo, 0, bAlo, bBlo, 32768, 3)
+        GQ_NINTERVAL(q, p, bAlo, 32768, bAhi, bBhi, 0, 0)
+        GQ_NINTERVAL(p, q, bAhi, 0, bAhi, bBhi, 32768, 1)
+        GQ_NINTERVAL(q, p, bAhi, 32768, bAlo, bBlo, 0, 2)
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+#undef GQ_NDL
+#undef GQ_NDL_
+#undef GQ_NADV
+#undef GQ_NRD
+#undef GQ_NWAIT
+#undef GQ_NMF
+#undef GQ_NBAR
+#undef GQ_NSTEP
+#undef GQ_NINTERVAL
+    float* __restrict__ H = P.H;
+    const float beta = P.beta, alpha = P.alpha;
+    const int lr = lane & 15, lk = lane >> 4;
+    const int64_t i0 = ti * BT + wm * 128 + 4 * lk, j0 = tj * BT + wn * 64 + lr;
+#define GQ_NSTORE(c, i, j)                                                                            \
+    do {                                                                                              \
+        const int64_t col = j0 + (j) * 16, row = i0 + (i) * 16;                                       \
+        float4 h;                                                                                     \
+        h.x = beta * H[(row + 0) * C + col] + alpha * c[0];                                           \
+        h.y = beta * H[(row + 1) * C + col] + alpha * c[1];                                           \
+        h.z = beta * H[(row + 2) * C + col] + alpha * c[2];                                           \
+        h.w = beta * H[(row + 3) * C + col] + alpha * c[3];                                           \
+        H[(row + 0) * C + col] = h.x; H[(row + 1) * C + col] = h.y;                                   \
+        H[(row + 2) * C + col] = h.z; H[(row + 3) * C + col] = h.w;                                   \
+        if (ti != tj) *reinterpret_cast<float4*>(H + col * C + row) = h;                              \
+    } while (0)
+    GQ_NSTORE(c00, 0, 0);
+    GQ_NSTORE(c01, 0, 1);
+    GQ_NSTORE(c02, 0, 2);
+    GQ_NSTORE(c03, 0, 3);
+    GQ_NSTORE(c10, 1, 0);
+    GQ_NSTORE(c11, 1, 1);
+    GQ_NSTORE(c12, 1, 2);
+    GQ_NSTORE(c13, 1, 3);
+    GQ_NSTORE(c20, 2, 0);
+    GQ_NSTORE(c21, 2, 1);
+    GQ_NSTORE(c22, 2, 2);
+    GQ_NSTORE(c23, 2, 3);
+    GQ_NSTORE(c30, 3, 0);
+    GQ_NSTORE(c31, 3, 1);
+    GQ_NSTORE(c32, 3, 2);
+    GQ_NSTORE(c33, 3, 3);
+    GQ_NSTORE(c40, 4, 0);
+    GQ_NSTORE(c41, 4, 1);
+    GQ_NSTORE(c42, 4, 2);
+    GQ_NSTORE(c43, 4, 3);
+    GQ_NSTORE(c50, 5, 0);
+    GQ_NSTORE(c51, 5, 1);
+    GQ_NSTORE(c52, 5, 2);
+    GQ_NSTORE(c53, 5, 3);
+    GQ_NSTORE(c60, 6, 0);
+    GQ_NSTORE(c61, 6, 1);
+    GQ_NSTORE(c62, 6, 2);
+    GQ_NSTORE(c63, 6, 3);
+    GQ_NSTORE(c70, 7, 0);
+    GQ_NSTORE(c71, 7, 1);
+    GQ_NSTORE(c72, 7, 2);
+    GQ_NSTORE(c73, 7, 3);
+#undef GQ_NSTORE
+    }  // tile loop
+}
+
 // --------------------------------------------------------------- fp32 SYRK
 // H tile = sum_t X[t, i] X[t, j]: both operands are read straight from X rows
 // (lanes walk channels), no transpose needed for one-float MFMA operands.
@@ -598,10 +882,103 @@ __global__ __launch_bounds__(256) void syrk32_kernel(float* __restrict__ H, int6
         }
 }
 
+// 16-bit inputs with C % 256 == 0 and T % 128 == 0 are read in place (syrk16_256n_kernel): only the tile table
+// needs scratch.  Everything else goes through the re-laid-out operand image.
+static inline bool syrk_in_place(int64_t T, int64_t C) {
+    return (C % BT == 0) && (T % (2 * HK) == 0) && getenv("GQ_SYRK_IMAGE") == nullptr && getenv("GQ_SYRK_128") == nullptr;
+}
+
 size_t h_accumulate_workspace_bytes(int64_t T, int64_t C) {
+    const size_t nt = (size_t)(C / BT);
+    const size_t table = (nt * (nt + 1) / 2 + 320) * 4 + 256;  // tile table of the 256x256 kernels
+    if (syrk_in_place(T, C)) return table;
     const int64_t Tp = (T + 2 * HK - 1) / (2 * HK) * (2 * HK);
-    const size_t nt = (size_t)(C / BT);  // + the ring kernel's tile table
-    return (size_t)C * (size_t)Tp * 2 + 256 + (nt * (nt + 1) / 2 + 320) * 4;
+    return (size_t)C * (size_t)Tp * 2 + 256 + table;
+}
+
+// one launch over the problems idx[0..m): kind 0 = 128x128 kernel, 1 = 256x256 ring kernel on the re-laid-out
+// image, 2 = 256x256 ring kernel reading X in place
+static int syrk16_launch(int kind, const int* idx, int m, float* const* H, const void* const* X, const int64_t* T,
+                         const int64_t* C, const float* beta, const float* alpha, int x_dtype, unsigned char*& wp,
+                         unsigned char* ws_end, hipStream_t st) {
+    const dim3 block(256);
+    SyrkGroup grp;
+    grp.n = m;
+    int tiles = 0;
+    for (int k = 0; k < m; ++k) {
+        const int i = idx[k];
+        const int64_t Tp = (T[i] + 2 * HK - 1) / (2 * HK) * (2 * HK);  // whole turns of the 4-slot ring
+        const uint16_t* Xt = reinterpret_cast<const uint16_t*>(X[i]);
+        if (kind != 2) {
+            uint16_t* img = reinterpret_cast<uint16_t*>(wp);
+            wp += ((size_t)C[i] * Tp * 2 + 255) & ~(size_t)255;
+            if (wp > ws_end) GQ_FAIL(GQ_E_WORKSPACE, "gq_h_accumulate: workspace too small for the operand image");
+            ProfScope ps(PT_TRANSPOSE, st);
+            dim3 tg((unsigned)(Tp / HK), (unsigned)(C[i] / HT));
+            hipLaunchKernelGGL(transpose16_kernel, tg, block, 0, st, (const uint16_t*)X[i], T[i], C[i], img, Tp / HK,
+                               kind == 1 ? 1 : 0);
+            GQ_LAUNCH_CHECK();
+            Xt = img;
+        }
+        const int nt = (int)(C[i] / (kind ? BT : HT));
+        grp.p[k] = SyrkProblem{H[i], Xt, C[i], Tp, beta[i], alpha[i], tiles, nt};
+        if (!kind) {
+            const int ns = (nt + 7) / 8;  // 8x8 super-tiles per dimension
+            tiles += ns * (ns + 1) / 2;
+        }
+    }
+    grp.total_tiles = tiles;
+    grp.table = nullptr;
+    grp.per_xcd = 0;
+    std::vector<uint32_t> table;
+    if (kind) {
+        // Balanced schedule: the valid (ti <= tj) tiles of all problems, enumerated super-tile by super-tile
+        // (4 x 8 tiles share 12 operand panels), are cut into groups of 32 CONSECUTIVE tiles -- one group =
+        // what the 32 CUs of an XCD run at the same time out of one L2 -- and the groups are dealt
+        // round-robin to the 8 XCDs, so every XCD gets the same number of tiles (+-32) and no workgroup
+        // exits early.  (An arithmetic id -> super-tile map leaves XCDs up to 30 % apart: diagonal
+        // super-tiles are half empty.)
+        std::vector<uint32_t> all;
+        for (int k = 0; k < m; ++k) {
+            const int nt = grp.p[k].nt, nsc = (nt + 7) / 8, nsr = (nt + 3) / 4;
+            for (int sI = 0; sI < nsr; ++sI)
+                for (int sJ = (sI * 4) >> 3; sJ < nsc; ++sJ)
+                    for (int slot = 0; slot < 32; ++slot) {
+                        const int ti = sI * 4 + (slot >> 3), tj = sJ * 8 + (slot & 7);
+                        if (ti < nt && tj < nt && ti <= tj) all.push_back((uint32_t)k << 24 | (uint32_t)ti << 12 | (uint32_t)tj);
+                    }
+        }
+        const size_t ngroups = (all.size() + 31) / 32;
+        const int per_xcd = (int)((ngroups + 7) / 8) * 32;
+        table.assign((size_t)8 * per_xcd, 0xffffffffu);
+        for (size_t t = 0; t < all.size(); ++t) {
+            const size_t gi = t >> 5;
+            table[(gi & 7) * per_xcd + (gi >> 3) * 32 + (t & 31)] = all[t];
+        }
+        wp = reinterpret_cast<unsigned char*>(((uintptr_t)wp + 255) & ~(uintptr_t)255);
+        if (wp + table.size() * 4 > ws_end) GQ_FAIL(GQ_E_WORKSPACE, "gq_h_accumulate: workspace too small for the tile table");
+        GQ_HIP(hipMemcpyAsync(wp, table.data(), table.size() * 4, hipMemcpyHostToDevice, st));  // pageable: staged before return
+        grp.table = reinterpret_cast<const uint32_t*>(wp);
+        grp.per_xcd = per_xcd;
+        wp += table.size() * 4;
+    }
+    ProfScope ps(PT_SYRK, st);
+    const bool bf = x_dtype == GQ_BF16;
+    if (kind == 2) {
+        const dim3 grid((unsigned)(8 * grp.per_xcd)), blk(512);  // one tile per workgroup (fewer would walk the lists)
+        if (bf) hipLaunchKernelGGL(syrk16_256n_kernel<true>, grid, blk, S_LDS_BYTES, st, grp);
+        else hipLaunchKernelGGL(syrk16_256n_kernel<false>, grid, blk, S_LDS_BYTES, st, grp);
+    } else if (kind == 1) {
+        const dim3 grid((unsigned)(8 * grp.per_xcd)), blk(512);
+        if (bf) hipLaunchKernelGGL(syrk16_256e_kernel<true>, grid, blk, S_LDS_BYTES, st, grp);
+        else hipLaunchKernelGGL(syrk16_256e_kernel<false>, grid, blk, S_LDS_BYTES, st, grp);
+    } else {
+        const dim3 grid((unsigned)((tiles + 7) / 8 * 8 * 64));
+        if (bf) hipLaunchKernelGGL(syrk16_kernel<true>, grid, block, 2 * H_STAGE_BYTES, st, grp);
+        else hipLaunchKernelGGL(syrk16_kernel<false>, grid, block, 2 * H_STAGE_BYTES, st, grp);
+    }
+    GQ_LAUNCH_CHECK();
+    return GQ_OK;
 }
 
 int h_accumulate_grouped(int n, float* const* H, const void* const* X, const int64_t* T, const int64_t* C,
@@ -629,85 +1006,31 @@ int h_accumulate_grouped(int n, float* const* H, const void* const* X, const int
         need += h_accumulate_workspace_bytes(T[i], C[i]);
     }
     if (!ws || ws_bytes < need) GQ_FAIL(GQ_E_WORKSPACE, "gq_h_accumulate: workspace %zu < %zu bytes", ws_bytes, need);
-    SyrkGroup grp;
-    grp.n = n;
-    // 256x256 ring kernel when every C is a multiple of 256 (GQ_SYRK_128 forces the 128x128 kernel: comparison)
-    bool big = getenv("GQ_SYRK_128") == nullptr;
-    for (int i = 0; i < n; ++i) big = big && (C[i] % BT == 0);
-    int tiles = 0;
-    unsigned char* wp = reinterpret_cast<unsigned char*>(((uintptr_t)ws + 255) & ~(uintptr_t)255);
-    for (int i = 0; i < n; ++i) {
-        const int64_t Tp = (T[i] + 2 * HK - 1) / (2 * HK) * (2 * HK);  // whole turns of the 4-slot ring
-        uint16_t* Xt = reinterpret_cast<uint16_t*>(wp);
-        wp += ((size_t)C[i] * Tp * 2 + 255) & ~(size_t)255;
-        {
-            ProfScope ps(PT_TRANSPOSE, st);
-            dim3 tg((unsigned)(Tp / HK), (unsigned)(C[i] / HT));
-            hipLaunchKernelGGL(transpose16_kernel, tg, block, 0, st, (const uint16_t*)X[i], T[i], C[i], Xt, Tp / HK,
-                               big ? 1 : 0);
-            GQ_LAUNCH_CHECK();
-        }
-        const int nt = (int)(C[i] / (big ? BT : HT));
-        grp.p[i] = SyrkProblem{H[i], Xt, C[i], Tp, beta[i], alpha[i], tiles, nt};
-        if (!big) {
-            const int ns = (nt + 7) / 8;  // 8x8 super-tiles per dimension
-            tiles += ns * (ns + 1) / 2;
-        }
-    }
-    grp.total_tiles = tiles;
-    grp.table = nullptr;
-    grp.per_xcd = 0;
     static bool attr_set = false;
     if (!attr_set) {
         GQ_HIP(hipFuncSetAttribute((const void*)syrk16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * H_STAGE_BYTES));
         GQ_HIP(hipFuncSetAttribute((const void*)syrk16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * H_STAGE_BYTES));
         GQ_HIP(hipFuncSetAttribute((const void*)syrk16_256e_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES));
         GQ_HIP(hipFuncSetAttribute((const void*)syrk16_256e_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES));
+        GQ_HIP(hipFuncSetAttribute((const void*)syrk16_256n_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES));
+        GQ_HIP(hipFuncSetAttribute((const void*)syrk16_256n_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES));
         attr_set = true;
     }
-    std::vector<uint32_t> table;
-    if (big) {
-        // Balanced schedule: the valid (ti <= tj) tiles of all problems, enumerated super-tile by super-tile
-        // (4 x 8 tiles share 12 operand panels), are cut into groups of 32 CONSECUTIVE tiles -- one group =
-        // what the 32 CUs of an XCD run at the same time out of one L2 -- and the groups are dealt
-        // round-robin to the 8 XCDs, so every XCD gets the same number of tiles (+-32) and no workgroup
-        // exits early.  (An arithmetic id -> super-tile map leaves XCDs up to 30 % apart: diagonal
-        // super-tiles are half empty.)
-        std::vector<uint32_t> all;
-        for (int i = 0; i < n; ++i) {
-            const int nt = grp.p[i].nt, nsc = (nt + 7) / 8, nsr = (nt + 3) / 4;
-            for (int sI = 0; sI < nsr; ++sI)
-                for (int sJ = (sI * 4) >> 3; sJ < nsc; ++sJ)
-                    for (int slot = 0; slot < 32; ++slot) {
-                        const int ti = sI * 4 + (slot >> 3), tj = sJ * 8 + (slot & 7);
-                        if (ti < nt && tj < nt && ti <= tj) all.push_back((uint32_t)i << 24 | (uint32_t)ti << 12 | (uint32_t)tj);
-                    }
-        }
-        const size_t ngroups = (all.size() + 31) / 32;
-        const int per_xcd = (int)((ngroups + 7) / 8) * 32;
-        table.assign((size_t)8 * per_xcd, 0xffffffffu);
-        for (size_t t = 0; t < all.size(); ++t) {
-            const size_t gi = t >> 5;
-            table[(gi & 7) * per_xcd + (gi >> 3) * 32 + (t & 31)] = all[t];
-        }
-        wp = reinterpret_cast<unsigned char*>(((uintptr_t)wp + 255) & ~(uintptr_t)255);
-        if (wp + table.size() * 4 > reinterpret_cast<unsigned char*>(ws) + ws_bytes)
-            GQ_FAIL(GQ_E_WORKSPACE, "gq_h_accumulate: workspace too small for the tile table");
-        GQ_HIP(hipMemcpyAsync(wp, table.data(), table.size() * 4, hipMemcpyHostToDevice, st));  // pageable: staged before return
-        grp.table = reinterpret_cast<const uint32_t*>(wp);
-        grp.per_xcd = per_xcd;
+    // Problems are sorted into at most three launches by the kernel they can take (usually all take the first):
+    // in place (kind 2), 256x256 on the image (kind 1: T not a multiple of 128), 128x128 (kind 0: C % 256 != 0).
+    int idx[3][H_MAX_GROUP], cnt[3] = {0, 0, 0};
+    const bool force128 = getenv("GQ_SYRK_128") != nullptr;
+    for (int i = 0; i < n; ++i) {
+        const int kind = (force128 || C[i] % BT) ? 0 : (syrk_in_place(T[i], C[i]) ? 2 : 1);
+        idx[kind][cnt[kind]++] = i;
     }
-    ProfScope ps(PT_SYRK, st);
-    if (big) {
-        const dim3 grid((unsigned)(8 * grp.per_xcd)), blk(512);  // one tile per workgroup (fewer would walk the lists)
-        if (x_dtype == GQ_BF16) hipLaunchKernelGGL(syrk16_256e_kernel<true>, grid, blk, S_LDS_BYTES, st, grp);
-        else hipLaunchKernelGGL(syrk16_256e_kernel<false>, grid, blk, S_LDS_BYTES, st, grp);
-    } else {
-        const dim3 grid((unsigned)((tiles + 7) / 8 * 8 * 64));
-        if (x_dtype == GQ_BF16) hipLaunchKernelGGL(syrk16_kernel<true>, grid, block, 2 * H_STAGE_BYTES, st, grp);
-        else hipLaunchKernelGGL(syrk16_kernel<false>, grid, block, 2 * H_STAGE_BYTES, st, grp);
-    }
-    GQ_LAUNCH_CHECK();
+    unsigned char* wp = reinterpret_cast<unsigned char*>(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+    unsigned char* ws_end = reinterpret_cast<unsigned char*>(ws) + ws_bytes;
+    for (int kind = 2; kind >= 0; --kind)
+        if (cnt[kind]) {
+            const int rc = syrk16_launch(kind, idx[kind], cnt[kind], H, X, T, C, beta, alpha, x_dtype, wp, ws_end, st);
+            if (rc) return rc;
+        }
     return GQ_OK;
 }
 

@@ -33,6 +33,23 @@ __global__ __launch_bounds__(WAVES * 64) void k(const f16x8* __restrict__ in, fl
     out[t] = s;
 }
 
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_agpr(const f16x8* __restrict__ in, float* out, int iters) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    f16x8 a[4], b[4];
+    for (int i = 0; i < 4; ++i) { a[i] = in[(t * 8 + i) & 0xffff]; b[i] = in[(t * 8 + 4 + i) & 0xffff]; }
+    f32x4 c[16];
+    for (int i = 0; i < 16; ++i) for (int e = 0; e < 4; ++e) c[i][e] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c[i]) : "v"(a[i & 3]), "v"(b[i >> 2]));
+    }
+    float s = 0.f;
+    for (int i = 0; i < 16; ++i) for (int e = 0; e < 4; ++e) s += c[i][e];
+    out[t] = s;
+}
+
 template <int SHAPE, int WAVES>
 void run(const f16x8* in, float* out, const char* name) {
     const int iters = 200000, blocks = 256 * (8 / WAVES);
@@ -63,6 +80,18 @@ int main() {
     run<16, 8>(d, o, "16x16x32 f16");
     run<32, 4>(d, o, "32x32x16 f16");
     run<16, 4>(d, o, "16x16x32 f16");
+    {
+        const int iters = 200000, blocks = 256;
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        for (int rep = 0; rep < 3; ++rep) {
+            hipEventRecord(e0);
+            hipLaunchKernelGGL((k_agpr<8>), dim3(blocks), dim3(512), 0, 0, d, o, iters);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            printf("16x16x32 f16, accumulators in AGPRs, waves/WG=8 rep %d: %.2f ms  %.0f TFLOP/s\n", rep, ms,
+                   (double)blocks * 8 * iters * 16 * 16384.0 / ms / 1e9);
+        }
+    }
     hipMemset(d, 0, n * sizeof(f16x8));
     run<32, 8>(d, o, "32x32x16 f16 ZERO data");
     return 0;

@@ -2,6 +2,8 @@
 fixtures.  Bit-exact for every integer/byte/fp16 output; the two fp32 linear-algebra
 stages (H accumulate, Cholesky chain) carry their tolerance in the test.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -244,6 +246,36 @@ def test_h_accumulate_shapes(ops):
         ops.h_accumulate(H, X, 0.0, 2.0)
         ref = 2.0 * (X.double().T @ X.double())
         assert (H.double() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item() * max(1, T / 512)
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_h_accumulate_natural_layout_equals_relayout(ops, dt):
+    """T % 128 == 0 takes the kernel that reads X in place through ds_read_b64_tr_b16; it feeds the MFMAs the
+    same operands in the same order as the re-layout kernel, so the two agree BIT FOR BIT (and with fp64 to
+    accumulation-order tolerance).  Random, non-symmetric data: a transposed or permuted operand cannot pass."""
+    torch.manual_seed(12)
+    T, C = 1536, 1280
+    X = (torch.randn(T, C, device="cuda") * torch.exp(torch.randn(C, device="cuda") * 0.5)).to(dt)
+    H0 = torch.randn(C, C, device="cuda")
+    H0 = H0 + H0.T
+    outs = []
+    for env in (None, "1"):
+        if env is None:
+            os.environ.pop("GQ_SYRK_IMAGE", None)
+        else:
+            os.environ["GQ_SYRK_IMAGE"] = env
+        try:
+            H = H0.clone()
+            ops.h_accumulate(H, X[:1024], 0.25, 2.0 / 3)
+            ops.h_accumulate(H, X[1024:], 0.5, 0.125)   # T = 512: a single turn of the ring
+            outs.append(H)
+        finally:
+            os.environ.pop("GQ_SYRK_IMAGE", None)
+    assert torch.equal(outs[0], outs[1])
+    Xd = X.double()
+    ref = 0.5 * (0.25 * H0.double() + (2.0 / 3) * (Xd[:1024].T @ Xd[:1024])) + 0.125 * (Xd[1024:].T @ Xd[1024:])
+    assert (outs[0].double() - ref).abs().max().item() <= 5e-6 * ref.abs().max().item()
+    assert torch.equal(outs[0], outs[0].T)
 
 
 def test_h_accumulate_grouped_full_size(ops):
