@@ -27,6 +27,9 @@ import sys
 import time
 
 os.environ.setdefault("OMP_NUM_THREADS", "8")  # cpu_baseline threads (the reference's run_quant.sh:9 pins 8 too)
+# One hardware queue per HIP stream: with the runtime's default of 4 two of the block's independent chains share a
+# queue and run one after the other (kernel trace: same Queue_Id).  Must be set before the HIP runtime starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 import numpy as np
 import torch

@@ -10,6 +10,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # one hardware queue per HIP stream (the driver runs 4 chains), see bench.py
+
 import torch
 import torch.distributed as dist
 

@@ -5,6 +5,7 @@ set -euo pipefail
 
 BITS=${1:-Q4_K}
 export OMP_NUM_THREADS=8
+export GPU_MAX_HW_QUEUES="${GPU_MAX_HW_QUEUES:-16}"  # one hardware queue per HIP stream
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 
 DEVICES="${HIP_VISIBLE_DEVICES:-${CUDA_VISIBLE_DEVICES:-0}}"
