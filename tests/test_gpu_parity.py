@@ -221,6 +221,27 @@ def test_rtn_model_dtype_golden(ops, oracle, tag, dt):
         assert np.array_equal(oq, npy(q)) and np.array_equal(od, u16(d)) and np.array_equal(os_, npy(s))
 
 
+@pytest.mark.parametrize("dt,rmode", [(torch.bfloat16, 2), (torch.float16, 1)])
+def test_rtn_embedding_size(ops, oracle, dt, rmode):
+    """Llama-3 embed_tokens / lm_head shape (128256 x 4096) in the model dtype, Q6_K (README mixed map) and Q4_K:
+    row blocks sampled across the matrix (first, last, odd offsets) equal the per-op-rounding oracle bit for bit;
+    the dequantized matrix is within the type's relative error of the weights."""
+    torch.manual_seed(21)
+    R, C = 128256, 4096
+    W = (torch.randn(R, C, device="cuda") * 0.02).to(dt)
+    rows = [0, 1, 63, 64, 4097, 65535, 100001, R - 65, R - 1]
+    for name in ("Q6_K", "Q4_K"):
+        t = TYPES[name]
+        q, d, s, dmin, m = ops.rtn_quantize(W, t)
+        Wn = W[rows].float().cpu().numpy()
+        oq, od, os_, odm, om = oracle.rtn_quantize_lp(Wn, rmode, t)
+        assert np.array_equal(oq, npy(q[rows])) and np.array_equal(od, u16(d[rows])) and np.array_equal(os_, npy(s[rows]))
+        assert np.array_equal(odm, u16(dmin[rows])) and np.array_equal(om, npy(m[rows]))
+        deq = ops.dequantize(t, q[:4096], d[:4096], s[:4096], dmin[:4096], m[:4096])
+        rel = ((deq - W[:4096].float()).norm() / W[:4096].float().norm()).item()
+        assert rel < (0.10 if name == "Q4_K" else 0.04), (name, rel)
+
+
 # ------------------------------------------------------------------ K1 Hessian
 def test_h_accumulate_golden(ops):
     g = load_golden("g4_g5_hessian")
