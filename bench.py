@@ -273,6 +273,18 @@ def main():
         quantize_block(shapes, W16, X, owners, rank, world, hbatch=hb, hws=hws, streams=streams, row_chunks=args.row_chunks)
     sync()
     # dominant kernel (the fp16 MFMA SYRK of the Hessian accumulation) timed live with HIP
+    if world > 1 and os.environ.get("GQ_BENCH_VERIFY") == "1":  # every rank must hold the same results
+        outv = quantize_block(shapes, W16, X, owners, rank, world, hbatch=hb, hws=hws, streams=streams,
+                              row_chunks=args.row_chunks)
+        sync()
+        for name in sorted(outv):
+            cs_ = outv[name].double().sum().reshape(1)
+            lo_, hi_ = cs_.clone(), cs_.clone()
+            dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
+            assert float(lo_) == float(hi_) and float(outv[name].float().abs().sum()) > 0, f"{name}: ranks disagree"
+        if rank == 0:
+            print("verify: all ranks hold identical results", file=sys.stderr)
     # events on its launch stream, inside the timed region
     _cabi.prof_enable(["syrk"])
     keep = {}
