@@ -45,20 +45,20 @@ std::mutex g_mu;
 hipEvent_t get_event() {
     if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
     hipEvent_t e;
-    hipEventCreate(&e);
+    (void)hipEventCreate(&e);
     return e;
 }
 }  // namespace
 void prof_begin(int tag, hipStream_t st) {
     std::lock_guard<std::mutex> lk(g_mu);
     Rec r{get_event(), get_event(), tag};
-    hipEventRecord(r.a, st);
+    (void)hipEventRecord(r.a, st);
     g_recs.push_back(r);
 }
 void prof_end(int tag, hipStream_t st) {
     std::lock_guard<std::mutex> lk(g_mu);
     for (size_t i = g_recs.size(); i-- > 0;)
-        if (g_recs[i].tag == tag) { hipEventRecord(g_recs[i].b, st); break; }
+        if (g_recs[i].tag == tag) { (void)hipEventRecord(g_recs[i].b, st); break; }
 }
 }  // namespace gq
 

@@ -22,7 +22,6 @@
 namespace gq {
 
 constexpr int NB = 128;
-constexpr int NBP = NB + 1;
 
 // ------------------------------------------------------------------ prelude
 // dead[j] = (H[j,j] == 0)                               gptq.py:134
