@@ -14,30 +14,39 @@
 //            with A_i B_i the i-th CHAIN-wide slice of the product -- bit-identical to K/CHAIN separate
 //            MODE-0 launches, with ONE read and write of C (the GPTQ look-ahead trailing update)
 //
-// Workgroup = 256 threads = 4 waves (2x2); tile 128x128; each wave owns 64x64 = 2x2
-// MFMA tiles (64 accumulator VGPRs).  K streams in chunks of 32 through a double-buffered
+// Workgroup = 256 threads = 4 waves (2x2); tile TS x TS, TS = 128 (each wave owns 64x64 = 2x2 MFMA tiles,
+// 64 accumulator VGPRs) or TS = 64 (one MFMA tile per wave) for problems too small to fill the chip with
+// 128-tiles: a 128x128x128 tile is 8.6 us of matrix-pipe time on ONE CU, four 64-tiles are 2.1 us on four.  K streams in chunks of 32 through a double-buffered
 // LDS image: the global loads of chunk t+1 are issued into registers before the 64 MFMAs
 // of chunk t and written to the other LDS buffer after them (one barrier per chunk).
 #pragma once
+#include <stdlib.h>
+
 #include "gq_common.hpp"
 
 namespace gq {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int TM = 128, TN = 128, TK = 32;
-constexpr int LDA_S = TK + 1;   // A tile [TM][TK]: lanes walk rows -> odd stride
-constexpr int LDB_S = TN + 4;   // B tile [TK][TN] (NN): lanes walk columns
-constexpr int LDBT_S = TK + 1;  // B tile [TN][TK] (NT)
-constexpr int G32_A_FLOATS = TM * LDA_S;
-constexpr int G32_B_FLOATS = (TK * LDB_S > TN * LDBT_S) ? TK * LDB_S : TN * LDBT_S;
-constexpr int G32_STAGE_FLOATS = G32_A_FLOATS + G32_B_FLOATS;
-constexpr int G32_LDS_BYTES = 2 * G32_STAGE_FLOATS * 4;
+constexpr int TM = 128, TN = 128, TK = 32;  // the default tile (gq_gemm3b.hpp uses these too)
+constexpr int LDA_S = TK + 1;   // A tile [TS][TK]: lanes walk rows -> odd stride
+constexpr int LDBT_S = TK + 1;  // B tile [TS][TK] (NT)
+template <int TS> struct G32 {
+    static constexpr int NV = TS / 32;       // float4 per thread and operand chunk
+    static constexpr int LDB = TS + 4;       // B tile [TK][TS] (NN): lanes walk columns
+    static constexpr int A_FLOATS = TS * LDA_S;
+    static constexpr int B_FLOATS = (TK * LDB > TS * LDBT_S) ? TK * LDB : TS * LDBT_S;
+    static constexpr int STAGE_FLOATS = A_FLOATS + B_FLOATS;
+    static constexpr int LDS_BYTES = 2 * STAGE_FLOATS * 4;
+};
+constexpr int LDB_S = G32<128>::LDB;
+constexpr int G32_LDS_BYTES = G32<128>::LDS_BYTES;
 
-// rows x 32-float panel chunk -> 4 float4 per thread (128 rows x 8 float4)
-__device__ __forceinline__ void g32_load_rows(float4 (&v)[4], const float* P, int64_t ld, int64_t r0, int64_t rmax,
+// rows x 32-float panel chunk -> NV float4 per thread (32 NV rows x 8 float4)
+template <int NV>
+__device__ __forceinline__ void g32_load_rows(float4 (&v)[NV], const float* P, int64_t ld, int64_t r0, int64_t rmax,
                                               int64_t k0, int64_t K, int tid) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < NV; ++t) {
         const int idx = tid + t * 256, rr = idx >> 3, c4 = (idx & 7) * 4;
         float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
         if (r0 + rr < rmax) {
@@ -52,20 +61,22 @@ __device__ __forceinline__ void g32_load_rows(float4 (&v)[4], const float* P, in
         v[t] = x;
     }
 }
-__device__ __forceinline__ void g32_store_rows(const float4 (&v)[4], float* S, int lds, int tid) {
+template <int NV>
+__device__ __forceinline__ void g32_store_rows(const float4 (&v)[NV], float* S, int lds, int tid) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < NV; ++t) {
         const int idx = tid + t * 256, rr = idx >> 3, c4 = (idx & 7) * 4;
         float* o = S + rr * lds + c4;
         o[0] = v[t].x; o[1] = v[t].y; o[2] = v[t].z; o[3] = v[t].w;
     }
 }
-// 32 k-rows x 128 columns chunk of a [K,N] matrix -> 4 float4 per thread (32 rows x 32 float4)
-__device__ __forceinline__ void g32_load_kn(float4 (&v)[4], const float* B, int64_t ldb, int64_t n0, int64_t N,
+// 32 k-rows x TS columns chunk of a [K,N] matrix -> NV float4 per thread (32 rows x TS/4 float4)
+template <int NV>
+__device__ __forceinline__ void g32_load_kn(float4 (&v)[NV], const float* B, int64_t ldb, int64_t n0, int64_t N,
                                             int64_t k0, int64_t K, int tid) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int idx = tid + t * 256, kk = idx >> 5, c4 = (idx & 31) * 4;
+    for (int t = 0; t < NV; ++t) {
+        const int idx = tid + t * 256, kk = idx / (8 * NV), c4 = (idx % (8 * NV)) * 4;
         float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
         if (k0 + kk < K) {
             const float* p = B + (k0 + kk) * ldb + n0 + c4;
@@ -79,15 +90,16 @@ __device__ __forceinline__ void g32_load_kn(float4 (&v)[4], const float* B, int6
         v[t] = x;
     }
 }
-__device__ __forceinline__ void g32_store_kn(const float4 (&v)[4], float* S, int tid) {
+template <int NV>
+__device__ __forceinline__ void g32_store_kn(const float4 (&v)[NV], float* S, int tid) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int idx = tid + t * 256, kk = idx >> 5, c4 = (idx & 31) * 4;
-        *reinterpret_cast<float4*>(S + kk * LDB_S + c4) = v[t];
+    for (int t = 0; t < NV; ++t) {
+        const int idx = tid + t * 256, kk = idx / (8 * NV), c4 = (idx % (8 * NV)) * 4;
+        *reinterpret_cast<float4*>(S + kk * (32 * NV + 4) + c4) = v[t];
     }
 }
 
-template <bool TRANS_B, int MODE, bool LOWER, int KR = 0, int CHAIN = 0>
+template <bool TRANS_B, int MODE, bool LOWER, int KR = 0, int CHAIN = 0, int TS = 128>
 __global__ __launch_bounds__(256, 2) void gemm32_kernel(float* Cmat, int64_t ldc, const float* A, int64_t lda,
                                                         const float* B, int64_t ldb, int64_t M, int64_t N, int64_t K) {
     extern __shared__ __attribute__((aligned(16))) float g32_smem[];
@@ -97,49 +109,50 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(float* Cmat, int64_t ldc
     if (LOWER && bx > by) return;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
-    const int64_t m0 = (int64_t)by * TM, n0 = (int64_t)bx * TN;
-    f32x16 acc[2][2];
+    constexpr int WT = TS / 2, NI = TS / 64, NV = G32<TS>::NV;  // wave tile, MFMA tiles per wave and dimension
+    const int64_t m0 = (int64_t)by * TS, n0 = (int64_t)bx * TS;
+    f32x16 acc[NI][NI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NI; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
     static_assert(CHAIN == 0 || (MODE == 0 && CHAIN % TK == 0 && KR == 0), "CHAIN: MODE 0, whole stages");
     const int lc = lane & 31, lh = lane >> 5;
-    f32x16 cv[CHAIN ? 2 : 1][CHAIN ? 2 : 1];
+    f32x16 cv[CHAIN ? NI : 1][CHAIN ? NI : 1];
     if constexpr (CHAIN != 0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int64_t col = n0 + wn * 64 + j * 32 + lc;
+            for (int j = 0; j < NI; ++j) {
+                const int64_t col = n0 + wn * WT + j * 32 + lc;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const int64_t rowi = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    const int64_t rowi = m0 + wm * WT + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
                     cv[i][j][e] = (rowi < M && col < N) ? Cmat[rowi * ldc + col] : 0.f;
                 }
             }
     }
-    float4 va[4], vb[4];
+    float4 va[NV], vb[NV];
     auto fetch = [&](int64_t k0) {
         g32_load_rows(va, A, lda, m0, M, k0, K, tid);
         if constexpr (TRANS_B) g32_load_rows(vb, B, ldb, n0, N, k0, K, tid);
         else g32_load_kn(vb, B, ldb, n0, N, k0, K, tid);
     };
     auto commit = [&](int buf) {
-        float* As = g32_smem + buf * G32_STAGE_FLOATS;
-        float* Bs = As + G32_A_FLOATS;
+        float* As = g32_smem + buf * G32<TS>::STAGE_FLOATS;
+        float* Bs = As + G32<TS>::A_FLOATS;
         g32_store_rows(va, As, LDA_S, tid);
         if constexpr (TRANS_B) g32_store_rows(vb, Bs, LDBT_S, tid);
         else g32_store_kn(vb, Bs, tid);
     };
     const int li = lane & 31, lk = lane >> 5;
     int64_t kb = 0, ke = K;
-    if constexpr (KR == 1) ke = (n0 + TN < K) ? n0 + TN : K;
+    if constexpr (KR == 1) ke = (n0 + TS < K) ? n0 + TS : K;
     if constexpr (KR == 2) kb = (n0 < K) ? n0 : K;
-    if constexpr (KR == 3) ke = (m0 + TM < K) ? m0 + TM : K;
+    if constexpr (KR == 3) ke = (m0 + TS < K) ? m0 + TS : K;
     const int64_t nk = (ke - kb + TK - 1) / TK;
     if (nk > 0) {
         fetch(kb);
@@ -148,18 +161,18 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(float* Cmat, int64_t ldc
     __syncthreads();
     for (int64_t t = 0; t < nk; ++t) {
         if (t + 1 < nk) fetch(kb + (t + 1) * TK);  // in flight during the MFMA block
-        const float* As = g32_smem + (t & 1) * G32_STAGE_FLOATS;
-        const float* Bs = As + G32_A_FLOATS;
+        const float* As = g32_smem + (t & 1) * G32<TS>::STAGE_FLOATS;
+        const float* Bs = As + G32<TS>::A_FLOATS;
         // operands of k-step kk+2 are read while the 4 MFMAs of step kk run (explicit register double buffer:
         // left to the compiler, every 4 MFMAs waited for their own LDS reads)
-        float av[2][2], bv[2][2];
-        auto frag = [&](int kk, float (&a)[2], float (&b)[2]) {
+        float av[2][NI], bv[2][NI];
+        auto frag = [&](int kk, float (&a)[NI], float (&b)[NI]) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = As[(wm * 64 + i * 32 + li) * LDA_S + kk + lk];
+            for (int i = 0; i < NI; ++i) a[i] = As[(wm * WT + i * 32 + li) * LDA_S + kk + lk];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                if constexpr (TRANS_B) b[j] = Bs[(wn * 64 + j * 32 + li) * LDBT_S + kk + lk];
-                else b[j] = Bs[(kk + lk) * LDB_S + wn * 64 + j * 32 + li];
+            for (int j = 0; j < NI; ++j) {
+                if constexpr (TRANS_B) b[j] = Bs[(wn * WT + j * 32 + li) * LDBT_S + kk + lk];
+                else b[j] = Bs[(kk + lk) * G32<TS>::LDB + wn * WT + j * 32 + li];
             }
         };
         frag(0, av[0], bv[0]);
@@ -168,17 +181,17 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(float* Cmat, int64_t ldc
             const int cur = (kk >> 1) & 1;
             if (kk + 2 < TK) frag(kk + 2, av[cur ^ 1], bv[cur ^ 1]);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < NI; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i], bv[cur][j], acc[i][j], 0, 0, 0);
         }
         if constexpr (CHAIN != 0) {
             if (((t + 1) * TK) % CHAIN == 0) {  // end of a slice: one subtraction, new chain
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < NI; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                    for (int j = 0; j < NI; ++j)
 #pragma unroll
                         for (int e = 0; e < 16; ++e) {
                             cv[i][j][e] = cv[i][j][e] - acc[i][j][e];
@@ -191,13 +204,13 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(float* Cmat, int64_t ldc
     }
     // D layout: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int64_t col = n0 + wn * 64 + j * 32 + lc;
+        for (int j = 0; j < NI; ++j) {
+            const int64_t col = n0 + wn * WT + j * 32 + lc;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int64_t rowi = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                const int64_t rowi = m0 + wm * WT + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
                 if (rowi < M && col < N) {
                     float* p = Cmat + rowi * ldc + col;
                     if constexpr (CHAIN != 0) *p = cv[i][j][e];
@@ -209,6 +222,22 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(float* Cmat, int64_t ldc
         }
 }
 
+template <bool TRANS_B, int MODE, bool LOWER, int KR, int CHAIN, int TS>
+inline int launch_gemm32_ts(float* Cmat, int64_t ldc, const float* A, int64_t lda, const float* B, int64_t ldb, int64_t M,
+                            int64_t N, int64_t K, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        GQ_HIP(hipFuncSetAttribute((const void*)gemm32_kernel<TRANS_B, MODE, LOWER, KR, CHAIN, TS>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, G32<TS>::LDS_BYTES));
+        attr_set = true;
+    }
+    dim3 grid((unsigned)((N + TS - 1) / TS), (unsigned)((M + TS - 1) / TS)), block(256);
+    hipLaunchKernelGGL((gemm32_kernel<TRANS_B, MODE, LOWER, KR, CHAIN, TS>), grid, block, G32<TS>::LDS_BYTES, st, Cmat, ldc,
+                       A, lda, B, ldb, M, N, K);
+    GQ_LAUNCH_CHECK();
+    return GQ_OK;
+}
+
 template <bool TRANS_B, int MODE, bool LOWER, int KR = 0, int CHAIN = 0>
 inline int launch_gemm32(float* Cmat, int64_t ldc, const float* A, int64_t lda, const float* B, int64_t ldb, int64_t M,
                          int64_t N, int64_t K, hipStream_t st) {
@@ -216,17 +245,13 @@ inline int launch_gemm32(float* Cmat, int64_t ldc, const float* A, int64_t lda, 
     if ((lda % 4) || (ldb % 4) || ((uintptr_t)A % 16) || ((uintptr_t)B % 16))
         GQ_FAIL(GQ_E_BAD_SHAPE, "gemm32: A/B must be 16-byte aligned with ld %% 4 == 0");
     if (CHAIN != 0 && (K % CHAIN)) GQ_FAIL(GQ_E_BAD_SHAPE, "gemm32: K=%ld is not a multiple of the chain length %d", (long)K, CHAIN);
-    static bool attr_set = false;
-    if (!attr_set) {
-        GQ_HIP(hipFuncSetAttribute((const void*)gemm32_kernel<TRANS_B, MODE, LOWER, KR, CHAIN>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, G32_LDS_BYTES));
-        attr_set = true;
-    }
-    dim3 grid((unsigned)((N + TN - 1) / TN), (unsigned)((M + TM - 1) / TM)), block(256);
-    hipLaunchKernelGGL((gemm32_kernel<TRANS_B, MODE, LOWER, KR, CHAIN>), grid, block, G32_LDS_BYTES, st, Cmat, ldc, A, lda, B, ldb,
-                       M, N, K);
-    GQ_LAUNCH_CHECK();
-    return GQ_OK;
+    // fewer 128-tiles than CUs: 64-tiles put four times as many CUs on the (latency-bound) problem.  Every output
+    // element is the same k-ordered chain either way, so the choice never changes a result.
+    const int64_t tiles128 = ((M + 127) / 128) * ((N + 127) / 128) / (LOWER ? 2 : 1);
+    static const int64_t max64 = getenv("GQ_GEMM32_64_MAX") ? atol(getenv("GQ_GEMM32_64_MAX")) : 256;  // 0: never
+    if (CHAIN == 0 && tiles128 < max64)
+        return launch_gemm32_ts<TRANS_B, MODE, LOWER, KR, CHAIN == 0 ? 0 : 0, 64>(Cmat, ldc, A, lda, B, ldb, M, N, K, st);
+    return launch_gemm32_ts<TRANS_B, MODE, LOWER, KR, CHAIN, 128>(Cmat, ldc, A, lda, B, ldb, M, N, K, st);
 }
 
 }  // namespace gq
