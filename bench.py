@@ -305,11 +305,11 @@ def main():
         _cabi.prof_enable(None)
         quantize_block(shapes, W16, X, owners, rank, world, hbatch=hb, hws=hws, streams=streams, row_chunks=args.row_chunks)
         torch.cuda.synchronize()
-        bd = _cabi.prof_collect()
+        bd = _cabi.prof_collect(busy=True)  # GQ_PROF_DUMP=<file> also writes the interval timeline
         _cabi.prof_enable([])
         tot = sum(v[0] for v in bd.values())
-        for k, (ms, n) in sorted(bd.items(), key=lambda kv: -kv[1][0]):
-            print(f"  {k:22s} {ms:10.2f} ms  {n:6d} launches  {100 * ms / tot:5.1f} %", file=sys.stderr)
+        for k, (ms, n, busy) in sorted(bd.items(), key=lambda kv: -kv[1][0]):
+            print(f"  {k:22s} {ms:10.2f} ms  {n:6d} launches  {100 * ms / tot:5.1f} %  busy {busy:8.2f} ms", file=sys.stderr)
 
     if rank == 0:
         # roofline of the dominant kernel: algorithmic MFMA flops of the upper-triangular SYRK at 128x128

@@ -38,7 +38,7 @@ int w_prepare(const uint8_t*, float*, int64_t, int64_t, int*, hipStream_t);
 namespace gq {
 unsigned g_prof_mask = 0;
 namespace {
-struct Rec { hipEvent_t a, b; int tag; };
+struct Rec { hipEvent_t a, b; int tag; hipStream_t st; };
 std::vector<Rec> g_recs;
 std::vector<hipEvent_t> g_pool;
 std::mutex g_mu;
@@ -51,7 +51,7 @@ hipEvent_t get_event() {
 }  // namespace
 void prof_begin(int tag, hipStream_t st) {
     std::lock_guard<std::mutex> lk(g_mu);
-    Rec r{get_event(), get_event(), tag};
+    Rec r{get_event(), get_event(), tag, st};
     (void)hipEventRecord(r.a, st);
     g_recs.push_back(r);
 }
@@ -192,14 +192,23 @@ const char* gq_prof_name(int tag) {
 int gq_prof_collect2(double* ms_host, long* n_host, double* busy_ms_host) {
     std::lock_guard<std::mutex> lk(g_mu);
     std::vector<std::pair<double, double>> iv[PT_COUNT];
+    // GQ_PROF_DUMP=<file>: append every interval as "tag name stream start_ms end_ms" (timeline studies)
+    const char* dump_path = getenv("GQ_PROF_DUMP");
+    FILE* dump = (dump_path && busy_ms_host) ? fopen(dump_path, "a") : nullptr;
     for (auto& r : g_recs) {
         float t = 0.f, t0 = 0.f;
         if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) {
             ms_host[r.tag] += t;
             n_host[r.tag] += 1;
-            if (busy_ms_host && hipEventElapsedTime(&t0, g_recs.front().a, r.a) == hipSuccess)
+            if (busy_ms_host && hipEventElapsedTime(&t0, g_recs.front().a, r.a) == hipSuccess) {
                 iv[r.tag].emplace_back((double)t0, (double)t0 + t);
+                if (dump) fprintf(dump, "%d %s %p %.4f %.4f\n", r.tag, gq_prof_name(r.tag), (void*)r.st, t0, t0 + t);
+            }
         }
+    }
+    if (dump) {
+        fprintf(dump, "# end of collect\n");
+        fclose(dump);
     }
     if (busy_ms_host)
         for (int tag = 0; tag < PT_COUNT; ++tag) {

@@ -42,12 +42,12 @@ constexpr int LDB_S = G32<128>::LDB;
 constexpr int G32_LDS_BYTES = G32<128>::LDS_BYTES;
 
 // rows x 32-float panel chunk -> NV float4 per thread (32 NV rows x 8 float4)
-template <int NV>
+template <int NV, int NT = 256>
 __device__ __forceinline__ void g32_load_rows(float4 (&v)[NV], const float* P, int64_t ld, int64_t r0, int64_t rmax,
                                               int64_t k0, int64_t K, int tid) {
 #pragma unroll
     for (int t = 0; t < NV; ++t) {
-        const int idx = tid + t * 256, rr = idx >> 3, c4 = (idx & 7) * 4;
+        const int idx = tid + t * NT, rr = idx >> 3, c4 = (idx & 7) * 4;
         float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
         if (r0 + rr < rmax) {
             const float* p = P + (r0 + rr) * ld + k0 + c4;
@@ -61,22 +61,22 @@ __device__ __forceinline__ void g32_load_rows(float4 (&v)[NV], const float* P, i
         v[t] = x;
     }
 }
-template <int NV>
+template <int NV, int NT = 256>
 __device__ __forceinline__ void g32_store_rows(const float4 (&v)[NV], float* S, int lds, int tid) {
 #pragma unroll
     for (int t = 0; t < NV; ++t) {
-        const int idx = tid + t * 256, rr = idx >> 3, c4 = (idx & 7) * 4;
+        const int idx = tid + t * NT, rr = idx >> 3, c4 = (idx & 7) * 4;
         float* o = S + rr * lds + c4;
         o[0] = v[t].x; o[1] = v[t].y; o[2] = v[t].z; o[3] = v[t].w;
     }
 }
 // 32 k-rows x TS columns chunk of a [K,N] matrix -> NV float4 per thread (32 rows x TS/4 float4)
-template <int NV>
+template <int NV, int NT = 256>
 __device__ __forceinline__ void g32_load_kn(float4 (&v)[NV], const float* B, int64_t ldb, int64_t n0, int64_t N,
                                             int64_t k0, int64_t K, int tid) {
 #pragma unroll
     for (int t = 0; t < NV; ++t) {
-        const int idx = tid + t * 256, kk = idx / (8 * NV), c4 = (idx % (8 * NV)) * 4;
+        const int idx = tid + t * NT, kk = idx / (NV * NT / 32), c4 = (idx % (NV * NT / 32)) * 4;
         float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
         if (k0 + kk < K) {
             const float* p = B + (k0 + kk) * ldb + n0 + c4;
@@ -90,17 +90,44 @@ __device__ __forceinline__ void g32_load_kn(float4 (&v)[NV], const float* B, int
         v[t] = x;
     }
 }
-template <int NV>
+template <int NV, int NT = 256>
 __device__ __forceinline__ void g32_store_kn(const float4 (&v)[NV], float* S, int tid) {
 #pragma unroll
     for (int t = 0; t < NV; ++t) {
-        const int idx = tid + t * 256, kk = idx / (8 * NV), c4 = (idx % (8 * NV)) * 4;
-        *reinterpret_cast<float4*>(S + kk * (32 * NV + 4) + c4) = v[t];
+        const int idx = tid + t * NT, kk = idx / (NV * NT / 32), c4 = (idx % (NV * NT / 32)) * 4;
+        *reinterpret_cast<float4*>(S + kk * (NV * NT / 8 + 4) + c4) = v[t];
     }
 }
 
-template <bool TRANS_B, int MODE, bool LOWER, int KR = 0, int CHAIN = 0, int TS = 128>
-__global__ __launch_bounds__(256, 2) void gemm32_kernel(float* Cmat, int64_t ldc, const float* A, int64_t lda,
+// whole-tile variants (FULL kernels: M, N multiples of TS and K of TK): plain 16-byte loads, no predicates
+template <int NV, int NT = 256>
+__device__ __forceinline__ void g32_load_rows_full(float4 (&v)[NV], const float* P, int64_t ld, int64_t r0, int64_t k0,
+                                                   int tid) {
+#pragma unroll
+    for (int t = 0; t < NV; ++t) {
+        const int idx = tid + t * NT, rr = idx >> 3, c4 = (idx & 7) * 4;
+        v[t] = *reinterpret_cast<const float4*>(P + (r0 + rr) * ld + k0 + c4);
+    }
+}
+template <int NV, int NT = 256>
+__device__ __forceinline__ void g32_load_kn_full(float4 (&v)[NV], const float* B, int64_t ldb, int64_t n0, int64_t k0,
+                                                 int tid) {
+#pragma unroll
+    for (int t = 0; t < NV; ++t) {
+        const int idx = tid + t * NT, kk = idx / (NV * NT / 32), c4 = (idx % (NV * NT / 32)) * 4;
+        const float4 x = *reinterpret_cast<const float4*>(B + (k0 + kk) * ldb + n0 + c4);
+        v[t].x = x.x; v[t].y = x.y; v[t].z = x.z; v[t].w = x.w;  // member-wise: a whole-vector copy keeps v[] in scratch
+    }
+}
+
+#ifndef GQ_G32_CHAIN_NW
+#define GQ_G32_CHAIN_NW 8
+#endif
+#ifndef GQ_G32_COMMIT_AT
+#define GQ_G32_COMMIT_AT 24
+#endif
+template <bool TRANS_B, int MODE, bool LOWER, int KR = 0, int CHAIN = 0, int TS = 128, bool FULL = false, int NW = 4>
+__global__ __launch_bounds__(NW * 64, 2) void gemm32_kernel(float* Cmat, int64_t ldc, const float* A, int64_t lda,
                                                         const float* B, int64_t ldb, int64_t M, int64_t N, int64_t K) {
     extern __shared__ __attribute__((aligned(16))) float g32_smem[];
     // triangular k-ranges make tile cost grow with n0 (KR 1) or m0 (KR 3): dispatch the long tiles first
@@ -108,45 +135,55 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(float* Cmat, int64_t ldc
     const unsigned by = (KR == 3) ? gridDim.y - 1 - blockIdx.y : blockIdx.y;
     if (LOWER && bx > by) return;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 1, wn = wid & 1;
-    constexpr int WT = TS / 2, NI = TS / 64, NV = G32<TS>::NV;  // wave tile, MFMA tiles per wave and dimension
+    // waves 2 x NW/2: wave tile WTM x WTN = NIM x NIN MFMA tiles (NW = 8 halves the accumulator registers
+    // of the CHAIN kernel, which also holds the C tile, so that two workgroups = 16 waves share a CU)
+    constexpr int NT = NW * 64, WNW = NW / 2;
+    const int wm = wid / WNW, wn = wid % WNW;
+    constexpr int WTM = TS / 2, WTN = TS / WNW, NIM = WTM / 32, NIN = WTN / 32, NV = TS * 8 / NT;
+    static_assert(NIN >= 1 && NV >= 1, "tile too small for this many waves");
     const int64_t m0 = (int64_t)by * TS, n0 = (int64_t)bx * TS;
-    f32x16 acc[NI][NI];
+    f32x16 acc[NIM][NIN];
 #pragma unroll
-    for (int i = 0; i < NI; ++i)
+    for (int i = 0; i < NIM; ++i)
 #pragma unroll
-        for (int j = 0; j < NI; ++j)
+        for (int j = 0; j < NIN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
     static_assert(CHAIN == 0 || (MODE == 0 && CHAIN % TK == 0 && KR == 0), "CHAIN: MODE 0, whole stages");
     const int lc = lane & 31, lh = lane >> 5;
-    f32x16 cv[CHAIN ? NI : 1][CHAIN ? NI : 1];
+    f32x16 cv[CHAIN ? NIM : 1][CHAIN ? NIN : 1];
     if constexpr (CHAIN != 0) {
 #pragma unroll
-        for (int i = 0; i < NI; ++i)
+        for (int i = 0; i < NIM; ++i)
 #pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                const int64_t col = n0 + wn * WT + j * 32 + lc;
+            for (int j = 0; j < NIN; ++j) {
+                const int64_t col = n0 + wn * WTN + j * 32 + lc;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const int64_t rowi = m0 + wm * WT + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                    cv[i][j][e] = (rowi < M && col < N) ? Cmat[rowi * ldc + col] : 0.f;
+                    const int64_t rowi = m0 + wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    cv[i][j][e] = (FULL || (rowi < M && col < N)) ? Cmat[rowi * ldc + col] : 0.f;
                 }
             }
     }
     float4 va[NV], vb[NV];
     auto fetch = [&](int64_t k0) {
-        g32_load_rows(va, A, lda, m0, M, k0, K, tid);
-        if constexpr (TRANS_B) g32_load_rows(vb, B, ldb, n0, N, k0, K, tid);
-        else g32_load_kn(vb, B, ldb, n0, N, k0, K, tid);
+        if constexpr (FULL) {
+            g32_load_rows_full<NV, NT>(va, A, lda, m0, k0, tid);
+            if constexpr (TRANS_B) g32_load_rows_full<NV, NT>(vb, B, ldb, n0, k0, tid);
+            else g32_load_kn_full<NV, NT>(vb, B, ldb, n0, k0, tid);
+        } else {
+            g32_load_rows<NV, NT>(va, A, lda, m0, M, k0, K, tid);
+            if constexpr (TRANS_B) g32_load_rows<NV, NT>(vb, B, ldb, n0, N, k0, K, tid);
+            else g32_load_kn<NV, NT>(vb, B, ldb, n0, N, k0, K, tid);
+        }
     };
     auto commit = [&](int buf) {
         float* As = g32_smem + buf * G32<TS>::STAGE_FLOATS;
         float* Bs = As + G32<TS>::A_FLOATS;
-        g32_store_rows(va, As, LDA_S, tid);
-        if constexpr (TRANS_B) g32_store_rows(vb, Bs, LDBT_S, tid);
-        else g32_store_kn(vb, Bs, tid);
+        g32_store_rows<NV, NT>(va, As, LDA_S, tid);
+        if constexpr (TRANS_B) g32_store_rows<NV, NT>(vb, Bs, LDBT_S, tid);
+        else g32_store_kn<NV, NT>(vb, Bs, tid);
     };
     const int li = lane & 31, lk = lane >> 5;
     int64_t kb = 0, ke = K;
@@ -154,25 +191,28 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(float* Cmat, int64_t ldc
     if constexpr (KR == 2) kb = (n0 < K) ? n0 : K;
     if constexpr (KR == 3) ke = (m0 + TS < K) ? m0 + TS : K;
     const int64_t nk = (ke - kb + TK - 1) / TK;
+    // Software pipeline: chunk t+1 is written to the other LDS buffer in the MIDDLE of the MFMA block of
+    // chunk t (its loads were issued half a chunk + one barrier earlier) and the loads of chunk t+2 follow
+    // it, so the LDS writes, the address arithmetic and the global loads all issue in the shadow of MFMAs.
     if (nk > 0) {
         fetch(kb);
         commit(0);
+        fetch(kb + ((nk > 1) ? TK : 0));
     }
     __syncthreads();
     for (int64_t t = 0; t < nk; ++t) {
-        if (t + 1 < nk) fetch(kb + (t + 1) * TK);  // in flight during the MFMA block
         const float* As = g32_smem + (t & 1) * G32<TS>::STAGE_FLOATS;
         const float* Bs = As + G32<TS>::A_FLOATS;
         // operands of k-step kk+2 are read while the 4 MFMAs of step kk run (explicit register double buffer:
         // left to the compiler, every 4 MFMAs waited for their own LDS reads)
-        float av[2][NI], bv[2][NI];
-        auto frag = [&](int kk, float (&a)[NI], float (&b)[NI]) {
+        float av[2][NIM], bv[2][NIN];
+        auto frag = [&](int kk, float (&a)[NIM], float (&b)[NIN]) {
 #pragma unroll
-            for (int i = 0; i < NI; ++i) a[i] = As[(wm * WT + i * 32 + li) * LDA_S + kk + lk];
+            for (int i = 0; i < NIM; ++i) a[i] = As[(wm * WTM + i * 32 + li) * LDA_S + kk + lk];
 #pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                if constexpr (TRANS_B) b[j] = Bs[(wn * WT + j * 32 + li) * LDBT_S + kk + lk];
-                else b[j] = Bs[(kk + lk) * G32<TS>::LDB + wn * WT + j * 32 + li];
+            for (int j = 0; j < NIN; ++j) {
+                if constexpr (TRANS_B) b[j] = Bs[(wn * WTN + j * 32 + li) * LDBT_S + kk + lk];
+                else b[j] = Bs[(kk + lk) * G32<TS>::LDB + wn * WTN + j * 32 + li];
             }
         };
         frag(0, av[0], bv[0]);
@@ -180,18 +220,24 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(float* Cmat, int64_t ldc
         for (int kk = 0; kk < TK; kk += 2) {
             const int cur = (kk >> 1) & 1;
             if (kk + 2 < TK) frag(kk + 2, av[cur ^ 1], bv[cur ^ 1]);
+            if (kk == GQ_G32_COMMIT_AT) {
+                // unconditional, so that the chunk body stays ONE basic block the scheduler can interleave:
+                // past the end the last chunk is fetched again and committed to the buffer nobody reads
+                commit((int)((t + 1) & 1));  // the other buffer: its readers passed the last barrier
+                fetch(kb + ((t + 2 < nk) ? t + 2 : nk - 1) * TK);
+            }
 #pragma unroll
-            for (int i = 0; i < NI; ++i)
+            for (int i = 0; i < NIM; ++i)
 #pragma unroll
-                for (int j = 0; j < NI; ++j)
+                for (int j = 0; j < NIN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i], bv[cur][j], acc[i][j], 0, 0, 0);
         }
         if constexpr (CHAIN != 0) {
             if (((t + 1) * TK) % CHAIN == 0) {  // end of a slice: one subtraction, new chain
 #pragma unroll
-                for (int i = 0; i < NI; ++i)
+                for (int i = 0; i < NIM; ++i)
 #pragma unroll
-                    for (int j = 0; j < NI; ++j)
+                    for (int j = 0; j < NIN; ++j)
 #pragma unroll
                         for (int e = 0; e < 16; ++e) {
                             cv[i][j][e] = cv[i][j][e] - acc[i][j][e];
@@ -199,19 +245,18 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(float* Cmat, int64_t ldc
                         }
             }
         }
-        if (t + 1 < nk) commit((int)((t + 1) & 1));  // the other buffer: its readers passed the last barrier
         __syncthreads();
     }
     // D layout: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
 #pragma unroll
-    for (int i = 0; i < NI; ++i)
+    for (int i = 0; i < NIM; ++i)
 #pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            const int64_t col = n0 + wn * WT + j * 32 + lc;
+        for (int j = 0; j < NIN; ++j) {
+            const int64_t col = n0 + wn * WTN + j * 32 + lc;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int64_t rowi = m0 + wm * WT + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                if (rowi < M && col < N) {
+                const int64_t rowi = m0 + wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (FULL || (rowi < M && col < N)) {
                     float* p = Cmat + rowi * ldc + col;
                     if constexpr (CHAIN != 0) *p = cv[i][j][e];
                     else if constexpr (MODE == 0) *p = *p - acc[i][j][e];
@@ -222,20 +267,30 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(float* Cmat, int64_t ldc
         }
 }
 
-template <bool TRANS_B, int MODE, bool LOWER, int KR, int CHAIN, int TS>
-inline int launch_gemm32_ts(float* Cmat, int64_t ldc, const float* A, int64_t lda, const float* B, int64_t ldb, int64_t M,
+template <bool TRANS_B, int MODE, bool LOWER, int KR, int CHAIN, int TS, bool FULL>
+inline int launch_gemm32_full(float* Cmat, int64_t ldc, const float* A, int64_t lda, const float* B, int64_t ldb, int64_t M,
                             int64_t N, int64_t K, hipStream_t st) {
+    constexpr int NW = (CHAIN != 0 && TS == 128) ? GQ_G32_CHAIN_NW : 4;  // the chained kernel also holds the C tile: 8 waves
     static bool attr_set = false;
     if (!attr_set) {
-        GQ_HIP(hipFuncSetAttribute((const void*)gemm32_kernel<TRANS_B, MODE, LOWER, KR, CHAIN, TS>,
+        GQ_HIP(hipFuncSetAttribute((const void*)gemm32_kernel<TRANS_B, MODE, LOWER, KR, CHAIN, TS, FULL, NW>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, G32<TS>::LDS_BYTES));
         attr_set = true;
     }
-    dim3 grid((unsigned)((N + TS - 1) / TS), (unsigned)((M + TS - 1) / TS)), block(256);
-    hipLaunchKernelGGL((gemm32_kernel<TRANS_B, MODE, LOWER, KR, CHAIN, TS>), grid, block, G32<TS>::LDS_BYTES, st, Cmat, ldc,
+    dim3 grid((unsigned)((N + TS - 1) / TS), (unsigned)((M + TS - 1) / TS)), block(NW * 64);
+    hipLaunchKernelGGL((gemm32_kernel<TRANS_B, MODE, LOWER, KR, CHAIN, TS, FULL, NW>), grid, block, G32<TS>::LDS_BYTES, st, Cmat, ldc,
                        A, lda, B, ldb, M, N, K);
     GQ_LAUNCH_CHECK();
     return GQ_OK;
+}
+
+template <bool TRANS_B, int MODE, bool LOWER, int KR, int CHAIN, int TS>
+inline int launch_gemm32_ts(float* Cmat, int64_t ldc, const float* A, int64_t lda, const float* B, int64_t ldb, int64_t M,
+                            int64_t N, int64_t K, hipStream_t st) {
+    // whole tiles only (every GPTQ / Cholesky shape of a 128-multiple Linear): the unpredicated kernel
+    if (M % TS == 0 && N % TS == 0 && K % TK == 0 && ldc % 4 == 0)
+        return launch_gemm32_full<TRANS_B, MODE, LOWER, KR, CHAIN, TS, true>(Cmat, ldc, A, lda, B, ldb, M, N, K, st);
+    return launch_gemm32_full<TRANS_B, MODE, LOWER, KR, CHAIN, TS, false>(Cmat, ldc, A, lda, B, ldb, M, N, K, st);
 }
 
 template <bool TRANS_B, int MODE, bool LOWER, int KR = 0, int CHAIN = 0>

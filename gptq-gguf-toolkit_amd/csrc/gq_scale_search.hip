@@ -63,6 +63,37 @@ __device__ __forceinline__ float group_max8(float v) {
     return v;
 }
 
+// Group reductions for LPG lanes per group (8: the DPP forms above; 1: the whole group in one lane).
+// Element e of a group lives on lane e % LPG as local element e / LPG, and feeds ATen accumulator
+// e % 8 == local accumulator (e / LPG) % NA with NA = 8 / LPG, so both mappings add in the same order.
+template <int LPG, int NA>
+__device__ __forceinline__ float group_sum(const float (&acc)[NA]) {
+    if constexpr (LPG == 8) {
+        return group_sum8(acc[0]);
+    } else {
+        float s = acc[0];
+#pragma unroll
+        for (int j = 1; j < NA; ++j) s = s + acc[j];
+        return s;
+    }
+}
+template <int LPG>
+__device__ __forceinline__ float group_min(float v) {
+    if constexpr (LPG == 8) return group_min8(v);
+    else return v;
+}
+template <int LPG>
+__device__ __forceinline__ float group_max(float v) {
+    if constexpr (LPG == 8) return group_max8(v);
+    else return v;
+}
+// acc[k % NA] (+)= term, first touch assigns
+#define GQ_ACC(acc, k, term)                       \
+    do {                                           \
+        if ((k) < NA) acc[(k) % NA] = (term);      \
+        else acc[(k) % NA] = acc[(k) % NA] + (term); \
+    } while (0)
+
 template <int RM>
 __device__ __forceinline__ float R(float v) {
     if constexpr (RM == 1) {
@@ -84,19 +115,20 @@ struct SearchParams {
     int nstep;
 };
 
-// quant_utils.py:199-274 for one group spread over 8 lanes; NS = G/8 values per lane.
-template <int NS, int BITS, int RM>
+// quant_utils.py:199-274 for one group spread over LPG lanes; NS = G/LPG values per lane.
+template <int NS, int BITS, int RM, int LPG>
 __device__ __forceinline__ void k_search(const float (&x)[NS], const SearchParams& sp, float& scale_out,
                                          float& zero_out) {
     constexpr float maxq = (float)((1 << BITS) - 1);
-    constexpr float G = (float)(NS * 8);
+    constexpr float G = (float)(NS * LPG);
+    constexpr int NA = 8 / LPG;
     const float eps = R<RM>(1e-9f);  // quant_utils.py:69; rounds to 0 in fp16
     float w[NS];
+    float a0[NA], a1[NA], a2[NA];
     // :203-205
-    float p = R<RM>(x[0] * x[0]);
 #pragma unroll
-    for (int k = 1; k < NS; ++k) p = p + R<RM>(x[k] * x[k]);
-    float sum_x2 = R<RM>(group_sum8(p));
+    for (int k = 0; k < NS; ++k) GQ_ACC(a0, k, R<RM>(x[k] * x[k]));
+    float sum_x2 = R<RM>(group_sum<LPG, NA>(a0));
     float av_x = R<RM>(sqrtf(R<RM>(sum_x2 / G)));  // IEEE sqrt (MKL vsSqrt note)
 #pragma unroll
     for (int k = 0; k < NS; ++k) w[k] = R<RM>(av_x + fabsf(x[k]));
@@ -107,35 +139,32 @@ __device__ __forceinline__ void k_search(const float (&x)[NS], const SearchParam
         mn = x[k] < mn ? x[k] : mn;
         mx = x[k] > mx ? x[k] : mx;
     }
-    mn = group_min8(mn);
-    mx = group_max8(mx);
+    mn = group_min<LPG>(mn);
+    mx = group_max<LPG>(mx);
     mn = mn < 0.0f ? mn : 0.0f;
     float x_min = mn;
     const float x_max = mx;
     const bool is_const = (x_max == x_min);
     // :214-215
-    float pw = w[0], px = R<RM>(w[0] * x[0]);
 #pragma unroll
-    for (int k = 1; k < NS; ++k) {
-        pw = pw + w[k];
-        px = px + R<RM>(w[k] * x[k]);
+    for (int k = 0; k < NS; ++k) {
+        GQ_ACC(a0, k, w[k]);
+        GQ_ACC(a1, k, R<RM>(w[k] * x[k]));
     }
-    const float sum_w = R<RM>(group_sum8(pw));
-    const float sum_x = R<RM>(group_sum8(px));
+    const float sum_w = R<RM>(group_sum<LPG, NA>(a0));
+    const float sum_x = R<RM>(group_sum<LPG, NA>(a1));
     // :218-232
     float sc = R<RM>(R<RM>(x_max - x_min) / maxq);
     if (is_const) sc = 0.0f;
     const float isc = R<RM>(1.0f / (sc < eps ? eps : sc));
-    float pe = 0.0f;
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
         float q = 0.0f;
         if (!is_const) q = clampf(rintf(R<RM>(R<RM>(x[k] - x_min) * isc)), 0.0f, maxq);
         float diff = R<RM>(R<RM>(R<RM>(sc * q) + x_min) - x[k]);
-        float e = R<RM>(w[k] * R<RM>(diff * diff));
-        pe = (k == 0) ? e : pe + e;
+        GQ_ACC(a0, k, R<RM>(w[k] * R<RM>(diff * diff)));
     }
-    float best_err = R<RM>(group_sum8(pe));
+    float best_err = R<RM>(group_sum<LPG, NA>(a0));
     float best_scale = sc;
 
     if (sp.nstep >= 1) {  // :235-237
@@ -145,24 +174,25 @@ __device__ __forceinline__ void k_search(const float (&x)[NS], const SearchParam
             den = den < eps ? eps : den;
             const float cand_iscale = R<RM>(R<RM>(1.0f / den) * sp.num[i]);
             float L[NS];
-            float pl = 0.0f, pl2 = 0.0f, pxl = 0.0f;
 #pragma unroll
             for (int k = 0; k < NS; ++k) {
                 float q = 0.0f;  // :243 const groups
                 if (!is_const) q = clampf(rintf(R<RM>(R<RM>(x[k] - x_min) * cand_iscale)), 0.0f, maxq);  // :242
-                int qi = (int)q;
-                float q2 = (float)((qi * qi) & 255);  // :246 new_q**2 stays uint8 (wraps for Q5_K)
-                L[k] = q;
-                float tl = R<RM>(w[k] * q), tl2 = R<RM>(w[k] * q2), txl = R<RM>(R<RM>(w[k] * x[k]) * q);
-                if (k == 0) {
-                    pl = tl; pl2 = tl2; pxl = txl;
+                float q2;  // :246 new_q**2 stays uint8: wraps for Q5_K, exact in fp32 below 16
+                if constexpr (BITS <= 4) {
+                    q2 = q * q;
                 } else {
-                    pl = pl + tl; pl2 = pl2 + tl2; pxl = pxl + txl;
+                    int qi = (int)q;
+                    q2 = (float)((qi * qi) & 255);
                 }
+                L[k] = q;
+                GQ_ACC(a0, k, R<RM>(w[k] * q));
+                GQ_ACC(a1, k, R<RM>(w[k] * q2));
+                GQ_ACC(a2, k, R<RM>(R<RM>(w[k] * x[k]) * q));
             }
-            const float sum_l = R<RM>(group_sum8(pl));
-            const float sum_l2 = R<RM>(group_sum8(pl2));
-            const float sum_xl = R<RM>(group_sum8(pxl));
+            const float sum_l = R<RM>(group_sum<LPG, NA>(a0));
+            const float sum_l2 = R<RM>(group_sum<LPG, NA>(a1));
+            const float sum_xl = R<RM>(group_sum<LPG, NA>(a2));
             const float D = R<RM>(R<RM>(sum_w * sum_l2) - R<RM>(sum_l * sum_l));                           // :249
             float this_scale = R<RM>(R<RM>(R<RM>(sum_w * sum_xl) - R<RM>(sum_x * sum_l)) / D);             // :254
             float this_min = R<RM>(R<RM>(R<RM>(sum_l2 * sum_x) - R<RM>(sum_l * sum_xl)) / D);              // :255
@@ -170,14 +200,12 @@ __device__ __forceinline__ void k_search(const float (&x)[NS], const SearchParam
                 this_scale = R<RM>(sum_xl / (sum_l2 < eps ? eps : sum_l2));
                 this_min = 0.0f;
             }
-            float pc = 0.0f;
 #pragma unroll
             for (int k = 0; k < NS; ++k) {  // :262-264
                 float diff = R<RM>(R<RM>(R<RM>(this_scale * L[k]) + this_min) - x[k]);
-                float e = R<RM>(w[k] * R<RM>(diff * diff));
-                pc = (k == 0) ? e : pc + e;
+                GQ_ACC(a0, k, R<RM>(w[k] * R<RM>(diff * diff)));
             }
-            const float cand_err = R<RM>(group_sum8(pc));
+            const float cand_err = R<RM>(group_sum<LPG, NA>(a0));
 #ifdef GQ_DBG_ITER  // kernel A/B probe: report (cand_err, best_err) of one iteration instead of the result
             if (i == GQ_DBG_ITER) {
                 scale_out = cand_err;
@@ -200,7 +228,7 @@ __device__ __forceinline__ void k_search(const float (&x)[NS], const SearchParam
 }
 
 // quant_utils.py:147-197 (absmax branch)
-template <int NS, int BITS, int RM>
+template <int NS, int BITS, int RM, int LPG>
 __device__ __forceinline__ void absmax_search(const float (&x)[NS], float& scale_out, float& zero_out) {
     constexpr float maxq = (float)((1 << BITS) - 1);
     float mn = x[0], mx = x[0];
@@ -209,8 +237,8 @@ __device__ __forceinline__ void absmax_search(const float (&x)[NS], float& scale
         mn = x[k] < mn ? x[k] : mn;
         mx = x[k] > mx ? x[k] : mx;
     }
-    mn = group_min8(mn);
-    mx = group_max8(mx);
+    mn = group_min<LPG>(mn);
+    mx = group_max<LPG>(mx);
     float a = fabsf(mn);
     mx = a > mx ? a : mx;     // :153
     if (mn < 0.0f) mn = -mx;  // :154-156
@@ -255,8 +283,8 @@ __global__ __launch_bounds__(256) void scale_search_kernel(
     for (int k = 0; k < NS; ++k) xv[k] = load_x<RM>(x, base + k * 8);
 
     float gscale, gzero;
-    if constexpr (KSEARCH) k_search<NS, BITS, RM>(xv, sp, gscale, gzero);
-    else absmax_search<NS, BITS, RM>(xv, gscale, gzero);
+    if constexpr (KSEARCH) k_search<NS, BITS, RM, 8>(xv, sp, gscale, gzero);
+    else absmax_search<NS, BITS, RM, 8>(xv, gscale, gzero);
     if (l8 == 0) {
         sh_scale[row_l][g] = gscale;
         sh_zero[row_l][g] = gzero;
@@ -289,6 +317,77 @@ __global__ __launch_bounds__(256) void scale_search_kernel(
     }
 }
 
+// Lane-per-group variant: one lane owns a whole group (its GSZ values in registers), one wave64 =
+// 64/NG row-panels.  Same arithmetic in the same order as the kernel above (see group_sum), but no
+// cross-lane reductions and the per-group scalar algebra is done once instead of on 8 lanes: about
+// half the VALU work per group.  Rows are read with 16-B loads (the launcher checks alignment).
+template <int GSZ, int BITS, bool KSEARCH, bool SIGNED, int SMQ, int RM>
+__global__ __launch_bounds__(64) void scale_search_lane_kernel(
+    const void* __restrict__ x, int64_t rows, int64_t ld, SearchParams sp,
+    uint16_t* __restrict__ d, int64_t d_stride, uint8_t* __restrict__ s, int64_t s_ld,
+    uint16_t* __restrict__ dmin, int64_t dmin_stride, uint8_t* __restrict__ m, int64_t m_ld,
+    float* __restrict__ gs_out, float* __restrict__ gz_out) {
+    constexpr int NG = 256 / GSZ;  // lanes per row
+    constexpr int RPW = 64 / NG;   // rows per wave
+    const int lane = threadIdx.x;
+    const int row_l = lane / NG;
+    const int g = lane % NG;
+    const int64_t row = (int64_t)blockIdx.x * RPW + row_l;
+    const bool live = row < rows;
+    const int64_t base = (live ? row : 0) * ld + g * GSZ;
+    float xv[GSZ];
+    if constexpr (RM == 0) {
+        const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(x) + base);
+#pragma unroll
+        for (int k = 0; k < GSZ / 4; ++k) {
+            float4 v = p[k];
+            xv[4 * k] = v.x; xv[4 * k + 1] = v.y; xv[4 * k + 2] = v.z; xv[4 * k + 3] = v.w;
+        }
+    } else {
+        const uint4* p = reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(x) + base);
+#pragma unroll
+        for (int k = 0; k < GSZ / 8; ++k) {
+            uint4 v = p[k];
+            const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                uint16_t lo = (uint16_t)(u[t] & 0xffffu), hi = (uint16_t)(u[t] >> 16);
+                xv[8 * k + 2 * t] = RM == 1 ? h2f(lo) : bf2f(lo);
+                xv[8 * k + 2 * t + 1] = RM == 1 ? h2f(hi) : bf2f(hi);
+            }
+        }
+    }
+
+    float gscale, gzero;
+    if constexpr (KSEARCH) k_search<GSZ, BITS, RM, 1>(xv, sp, gscale, gzero);
+    else absmax_search<GSZ, BITS, RM, 1>(xv, gscale, gzero);
+    if (gs_out && live) {  // make_k_quants / make_quants outputs (gq_group_search)
+        gs_out[row * NG + g] = gscale;
+        gz_out[row * NG + g] = gzero;
+    }
+    // quant_utils.py:121-143: row maxima over the NG lanes of the row
+    float max_scale = gscale, max_zero = gzero;
+#pragma unroll
+    for (int o = 1; o < NG; o <<= 1) {
+        float a = __shfl_xor(max_scale, o), b = __shfl_xor(max_zero, o);
+        max_scale = a > max_scale ? a : max_scale;
+        max_zero = b > max_zero ? b : max_zero;
+    }
+    if (live) {
+        constexpr float smq = (float)SMQ;
+        float inv_scale = max_scale > 0.0f ? R<RM>(R<RM>(1.0f / max_scale) * smq) : 0.0f;  // :128
+        float inv_zero = max_zero > 0.0f ? R<RM>(R<RM>(1.0f / max_zero) * smq) : 0.0f;     // :129
+        float a = clampf(rintf(R<RM>(inv_scale * gscale)), 0.0f, smq);                     // :132-143
+        float b = clampf(rintf(R<RM>(inv_zero * gzero)), 0.0f, smq);
+        s[row * s_ld + g] = SIGNED ? (uint8_t)(int8_t)a : (uint8_t)a;
+        m[row * m_ld + g] = SIGNED ? (uint8_t)(int8_t)b : (uint8_t)b;
+        if (g == 0) {
+            d[row * d_stride] = f2h(R<RM>(max_scale / smq));       // :124 (+ .to(float16))
+            dmin[row * dmin_stride] = f2h(R<RM>(max_zero / smq));  // :125
+        }
+    }
+}
+
 template <int RM>
 static int launch_ss(const void* x, int64_t rows, int64_t ld, int q_type, const gq_search_t* p, uint16_t* d,
                      int64_t d_stride, uint8_t* s, int64_t s_ld, uint16_t* dmin, int64_t dmin_stride, uint8_t* m,
@@ -302,12 +401,28 @@ static int launch_ss(const void* x, int64_t rows, int64_t ld, int q_type, const 
     const double rmin = p ? p->rmin : -1.0, rdelta = p ? p->rdelta : 0.1;
     const double maxq = (double)((1 << ti.bits) - 1);
     for (int i = 0; i < 24; ++i) sp.num[i] = (float)(rmin + rdelta * (double)i + maxq);
-    const int rpw = ti.group == 32 ? 4 : 2;
-    dim3 grid((unsigned)((rows + rpw - 1) / rpw)), block(256);
+    // lane-per-group kernel when the rows can be read with 16-B loads and there are enough groups to put a
+    // wave on half the SIMDs (>= 512 waves): it does half the VALU work per group, but one wave takes ~35 us
+    // whatever the size, against ~17 us for a small launch of the 8-lanes-per-group kernel (measured,
+    // profiles/ss_probe.py).  GQ_SS_WIDE=1 / 0 forces the wide / lane kernel (A/B measurements, parity test).
+    const size_t esz = RM == 0 ? 4 : 2;
+    const bool aligned = (reinterpret_cast<uintptr_t>(x) % 16 == 0) && ((size_t)ld * esz) % 16 == 0;
+    const char* wide_env = getenv("GQ_SS_WIDE");
+    bool lane_kernel = aligned && rows * (256 / ti.group) >= 32768;
+    if (wide_env && wide_env[0] == '1') lane_kernel = false;
+    if (wide_env && wide_env[0] == '0') lane_kernel = aligned;
+    const int rpw = lane_kernel ? (64 / (256 / ti.group)) : (ti.group == 32 ? 4 : 2);
+    dim3 grid((unsigned)((rows + rpw - 1) / rpw)), block(lane_kernel ? 64 : 256);
     ProfScope ps(PT_SCALE_SEARCH, st);
-#define GQ_SS(G, B, K, S, Q)                                                                                     \
-    hipLaunchKernelGGL((scale_search_kernel<G, B, K, S, Q, RM>), grid, block, 0, st, x, rows, ld, sp, d, d_stride, \
-                       s, s_ld, dmin, dmin_stride, m, m_ld, gs_out, gz_out)
+#define GQ_SS(G, B, K, S, Q)                                                                                       \
+    do {                                                                                                           \
+        if (lane_kernel)                                                                                           \
+            hipLaunchKernelGGL((scale_search_lane_kernel<G, B, K, S, Q, RM>), grid, block, 0, st, x, rows, ld, sp, \
+                               d, d_stride, s, s_ld, dmin, dmin_stride, m, m_ld, gs_out, gz_out);                  \
+        else                                                                                                       \
+            hipLaunchKernelGGL((scale_search_kernel<G, B, K, S, Q, RM>), grid, block, 0, st, x, rows, ld, sp, d,   \
+                               d_stride, s, s_ld, dmin, dmin_stride, m, m_ld, gs_out, gz_out);                     \
+    } while (0)
     switch (q_type) {
     case GQ_Q2_K: GQ_SS(16, 2, true, false, 15); break;
     case GQ_Q3_K: GQ_SS(16, 3, false, true, 31); break;
