@@ -13,9 +13,8 @@
 //
 // Same interface and modes as gemm32_kernel (MODE 0/1/2, TRANS_B, LOWER, KR; no CHAIN).
 // Workgroup = 256 threads = 4 waves (2x2), tile 128x128, wave tile 64x64 = 2x2 MFMA tiles.  K streams in
-// stages of 32: fp32 global loads into registers one stage ahead, split on the VALU, stored as three
-// bf16 planes per operand ([128 rows][32 k], 64-byte rows, 16-byte chunk kc of row r at kc ^ ((r>>2)&3):
-// conflict-free ds_read_b128 fragments, as in the SYRK image) -- 48 KiB per workgroup, 3 workgroups/CU.
+// stages of 16: fp32 global loads into registers two stages ahead, split on the VALU, stored as three
+// bf16 planes per operand into a double-buffered LDS image (2 x 24 KiB per workgroup, up to 3 workgroups/CU).
 #pragma once
 #include "gq_common.hpp"
 #include "gq_gemm32.hpp"
@@ -23,9 +22,6 @@
 namespace gq {
 
 typedef __bf16 g3_bf16x8 __attribute__((ext_vector_type(8)));
-constexpr int G3_PLANE_BYTES = TM * TK * 2;           // 8 KiB
-constexpr int G3_LDS_BYTES = 6 * G3_PLANE_BYTES;      // A1 A2 A3 B1 B2 B3
-
 // two fp32 -> three dwords, each holding the bf16 pair (x, y) of one plane (x in the low half).
 // Truncation split: 2 ANDs + 2 SUBs per element, 3 v_perm_b32 per pair.
 __device__ __forceinline__ void g3_split2(float x, float y, unsigned& p1, unsigned& p2, unsigned& p3) {
@@ -41,55 +37,74 @@ __device__ __forceinline__ void g3_split2(float x, float y, unsigned& p1, unsign
     p3 = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, ys), __builtin_bit_cast(unsigned, xs), 0x07060302u);
 }
 
-// [rows][32 k] fp32 chunk held as 4 float4 per thread (g32_load_rows mapping) -> three bf16 planes
-__device__ __forceinline__ void g3_store_rows(const float4 (&v)[4], unsigned char* planes, int tid) {
+// ---- stages of 16 k, double-buffered LDS image, double-buffered fragments ----
+// One barrier per stage.  Stage t: 12 MFMAs | split + LDS write of chunk t+1 into the other image, global
+// loads of chunk t+2 | barrier | fragment reads of chunk t+1 | 12 MFMAs -- the VALU split, the LDS traffic and
+// the loads all issue in the shadow of this wave's MFMAs.  Planes are [128 rows][16 k] bf16 (32-byte rows: a
+// wave's 64 fragment reads cover 1 KiB contiguously, no swizzle needed).  Same six products in the same order
+// per accumulator and k16 step whatever the staging.
+constexpr int G3_TK = 16;
+constexpr int G3_PLANE_BYTES = TM * G3_TK * 2;        // 4 KiB
+constexpr int G3_STAGE_BYTES = 6 * G3_PLANE_BYTES;    // 24 KiB
+constexpr int G3_LDS_BYTES = 2 * G3_STAGE_BYTES;      // 48 KiB: two workgroups per CU
+
+// [128 rows][16 k] fp32 chunk: 2 float4 per thread (row = idx >> 2, k = (idx & 3) * 4)
+template <bool FULL>
+__device__ __forceinline__ void g3_load_rows(float4 (&v)[2], const float* P, int64_t ld, int64_t r0, int64_t rmax,
+                                              int64_t k0, int64_t K, int tid) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int idx = tid + t * 256, rr = idx >> 3, c4 = (idx & 7) * 4;
+    for (int t = 0; t < 2; ++t) {
+        const int idx = tid + t * 256, rr = idx >> 2, c4 = (idx & 3) * 4;
+        const float* p = P + (r0 + rr) * ld + k0 + c4;
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (FULL) {
+            x = *reinterpret_cast<const float4*>(p);
+        } else if (r0 + rr < rmax) {
+            if (k0 + c4 + 3 < K) x = *reinterpret_cast<const float4*>(p);
+            else {
+                if (k0 + c4 + 0 < K) x.x = p[0];
+                if (k0 + c4 + 1 < K) x.y = p[1];
+                if (k0 + c4 + 2 < K) x.z = p[2];
+            }
+        }
+        v[t].x = x.x; v[t].y = x.y; v[t].z = x.z; v[t].w = x.w;
+    }
+}
+__device__ __forceinline__ void g3_store_rows(const float4 (&v)[2], unsigned char* planes, int tid) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int idx = tid + t * 256, rr = idx >> 2, c4 = (idx & 3) * 4;
         unsigned a0, b0, c0, a1, b1, c1;
         g3_split2(v[t].x, v[t].y, a0, b0, c0);
         g3_split2(v[t].z, v[t].w, a1, b1, c1);
-        const int off = rr * 64 + ((((c4 >> 3) ^ ((rr >> 2) & 3))) << 4) + ((c4 & 4) << 1);
+        const int off = (c4 >> 3) * (TM * 16) + rr * 16 + (c4 & 4) * 2;
         *reinterpret_cast<uint2*>(planes + off) = make_uint2(a0, a1);
         *reinterpret_cast<uint2*>(planes + G3_PLANE_BYTES + off) = make_uint2(b0, b1);
         *reinterpret_cast<uint2*>(planes + 2 * G3_PLANE_BYTES + off) = make_uint2(c0, c1);
     }
 }
-// g32_load_rows without edge predication: callers guarantee whole 128 x 32 chunks (M, N % 128 == 0, K % 32 == 0)
-__device__ __forceinline__ void g3_load_rows_full(float4 (&v)[4], const float* P, int64_t ld, int64_t r0, int64_t k0, int tid) {
-    const float* p = P + (r0 + (tid >> 3)) * ld + k0 + (tid & 7) * 4;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) v[t] = *reinterpret_cast<const float4*>(p + (int64_t)t * 32 * ld);
-}
-__device__ __forceinline__ void g3_load_kn_full(float (&v)[16], const float* B, int64_t ldb, int64_t n0, int64_t k0, int tid) {
-    const float* p = B + (k0 + (tid >> 7) * 16) * ldb + n0 + (tid & 127);
-#pragma unroll
-    for (int e = 0; e < 16; ++e) v[e] = p[(int64_t)e * ldb];
-}
-// [32 k][128 n] chunk of a [K,N] matrix: thread = (n = tid & 127, 16 consecutive k from (tid >> 7) * 16)
-__device__ __forceinline__ void g3_load_kn(float (&v)[16], const float* B, int64_t ldb, int64_t n0, int64_t N, int64_t k0,
-                                           int64_t K, int tid) {
+// [16 k][128 n] chunk of a [K,N] matrix: thread = (n = tid & 127, 8 consecutive k from (tid >> 7) * 8)
+template <bool FULL>
+__device__ __forceinline__ void g3_load_kn(float (&v)[8], const float* B, int64_t ldb, int64_t n0, int64_t N, int64_t k0,
+                                            int64_t K, int tid) {
     const int64_t n = n0 + (tid & 127);
-    const int64_t kb = k0 + (tid >> 7) * 16;
+    const int64_t kb = k0 + (tid >> 7) * 8;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) v[e] = (n < N && kb + e < K) ? B[(kb + e) * ldb + n] : 0.f;
+    for (int e = 0; e < 8; ++e) v[e] = (FULL || (n < N && kb + e < K)) ? B[(kb + e) * ldb + n] : 0.f;
 }
-__device__ __forceinline__ void g3_store_kn(const float (&v)[16], unsigned char* planes, int tid) {
+__device__ __forceinline__ void g3_store_kn(const float (&v)[8], unsigned char* planes, int tid) {
     const int rr = tid & 127, kh = tid >> 7;
+    unsigned a[4], b[4], d[4];
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {  // two 16-byte chunks of 8 k
-        unsigned a[4], b[4], d[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) g3_split2(v[c * 8 + 2 * e], v[c * 8 + 2 * e + 1], a[e], b[e], d[e]);
-        const int off = rr * 64 + (((kh * 2 + c) ^ ((rr >> 2) & 3)) << 4);
-        *reinterpret_cast<uint4*>(planes + off) = make_uint4(a[0], a[1], a[2], a[3]);
-        *reinterpret_cast<uint4*>(planes + G3_PLANE_BYTES + off) = make_uint4(b[0], b[1], b[2], b[3]);
-        *reinterpret_cast<uint4*>(planes + 2 * G3_PLANE_BYTES + off) = make_uint4(d[0], d[1], d[2], d[3]);
-    }
+    for (int e = 0; e < 4; ++e) g3_split2(v[2 * e], v[2 * e + 1], a[e], b[e], d[e]);
+    const int off = kh * (TM * 16) + rr * 16;
+    *reinterpret_cast<uint4*>(planes + off) = make_uint4(a[0], a[1], a[2], a[3]);
+    *reinterpret_cast<uint4*>(planes + G3_PLANE_BYTES + off) = make_uint4(b[0], b[1], b[2], b[3]);
+    *reinterpret_cast<uint4*>(planes + 2 * G3_PLANE_BYTES + off) = make_uint4(d[0], d[1], d[2], d[3]);
 }
 
 template <bool TRANS_B, int MODE, bool LOWER, int KR = 0, bool FULL = false>
-__global__ __launch_bounds__(256, TRANS_B ? 3 : 2) void gemm3b_kernel(float* Cmat, int64_t ldc, const float* A, int64_t lda,
+__global__ __launch_bounds__(256, 2) void gemm3b_kernel(float* Cmat, int64_t ldc, const float* A, int64_t lda,
                                                         const float* B, int64_t ldb, int64_t M, int64_t N, int64_t K) {
     extern __shared__ __attribute__((aligned(16))) unsigned char g3_smem[];
     const unsigned bx = (KR == 1) ? gridDim.x - 1 - blockIdx.x : blockIdx.x;  // long tiles first
@@ -106,23 +121,17 @@ __global__ __launch_bounds__(256, TRANS_B ? 3 : 2) void gemm3b_kernel(float* Cma
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-    unsigned char* Ap = g3_smem;
-    unsigned char* Bp = g3_smem + 3 * G3_PLANE_BYTES;
-    float4 va[4];
-    float4 vbt[TRANS_B ? 4 : 1];
-    float vbn[TRANS_B ? 1 : 16];
+    float4 va[2];
+    float4 vbt[TRANS_B ? 2 : 1];
+    float vbn[TRANS_B ? 1 : 8];
     auto fetch = [&](int64_t k0) {
-        if constexpr (FULL) {
-            g3_load_rows_full(va, A, lda, m0, k0, tid);
-            if constexpr (TRANS_B) g3_load_rows_full(vbt, B, ldb, n0, k0, tid);
-            else g3_load_kn_full(vbn, B, ldb, n0, k0, tid);
-        } else {
-            g32_load_rows(va, A, lda, m0, M, k0, K, tid);
-            if constexpr (TRANS_B) g32_load_rows(vbt, B, ldb, n0, N, k0, K, tid);
-            else g3_load_kn(vbn, B, ldb, n0, N, k0, K, tid);
-        }
+        g3_load_rows<FULL>(va, A, lda, m0, M, k0, K, tid);
+        if constexpr (TRANS_B) g3_load_rows<FULL>(vbt, B, ldb, n0, N, k0, K, tid);
+        else g3_load_kn<FULL>(vbn, B, ldb, n0, N, k0, K, tid);
     };
-    auto commit = [&]() {
+    auto commit = [&](int buf) {
+        unsigned char* Ap = g3_smem + buf * G3_STAGE_BYTES;
+        unsigned char* Bp = Ap + 3 * G3_PLANE_BYTES;
         g3_store_rows(va, Ap, tid);
         if constexpr (TRANS_B) g3_store_rows(vbt, Bp, tid);
         else g3_store_kn(vbn, Bp, tid);
@@ -132,45 +141,59 @@ __global__ __launch_bounds__(256, TRANS_B ? 3 : 2) void gemm3b_kernel(float* Cma
     if constexpr (KR == 1) ke = (n0 + TN < K) ? n0 + TN : K;
     if constexpr (KR == 2) kb = (n0 < K) ? n0 : K;
     if constexpr (KR == 3) ke = (m0 + TM < K) ? m0 + TM : K;
-    const int64_t nk = (ke - kb + TK - 1) / TK;
-    // fragment byte offsets inside a plane (k16 step s adds the chunk pair 2s, 2s+1)
-    int offA[2], offB[2], swA[2], swB[2];
+    const int64_t nk = (ke - kb + G3_TK - 1) / G3_TK;
+    int offA[2], offB[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int ra = wm * 64 + i * 32 + li, rb = wn * 64 + i * 32 + li;
-        offA[i] = ra * 64;
-        swA[i] = (ra >> 2) & 3;
-        offB[i] = rb * 64;
-        swB[i] = (rb >> 2) & 3;
+        offA[i] = lk * (TM * 16) + (wm * 64 + i * 32 + li) * 16;
+        offB[i] = 3 * G3_PLANE_BYTES + lk * (TM * 16) + (wn * 64 + i * 32 + li) * 16;
     }
-    if (nk > 0) fetch(kb);
-    for (int64_t t = 0; t < nk; ++t) {
-        commit();
-        __syncthreads();
-        if (t + 1 < nk) fetch(kb + (t + 1) * TK);  // in flight during the MFMA block
+    g3_bf16x8 fa[2][2][3], fb[2][2][3];  // [set][tile][plane]
+    auto load_frags = [&](int buf, g3_bf16x8 (&a)[2][3], g3_bf16x8 (&b)[2][3]) {
+        const unsigned char* S = g3_smem + buf * G3_STAGE_BYTES;
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            g3_bf16x8 a[2][3], b[2][3];
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                a[i][p] = *reinterpret_cast<const g3_bf16x8*>(S + p * G3_PLANE_BYTES + offA[i]);
+                b[i][p] = *reinterpret_cast<const g3_bf16x8*>(S + p * G3_PLANE_BYTES + offB[i]);
+            }
+    };
+    // six products per accumulator, smallest first; the four accumulators are interleaved so that
+    // consecutive MFMAs never depend on each other
+    constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+    auto mfmas = [&](int t_lo, int t_hi, const g3_bf16x8 (&a)[2][3], const g3_bf16x8 (&b)[2][3]) {
+#pragma unroll
+        for (int t6 = t_lo; t6 < t_hi; ++t6)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) {
-                    a[i][p] = *reinterpret_cast<const g3_bf16x8*>(Ap + p * G3_PLANE_BYTES + offA[i] + (((s2 * 2 + lk) ^ swA[i]) << 4));
-                    b[i][p] = *reinterpret_cast<const g3_bf16x8*>(Bp + p * G3_PLANE_BYTES + offB[i] + (((s2 * 2 + lk) ^ swB[i]) << 4));
-                }
-            // six products per accumulator, smallest first; the four accumulators are interleaved so that
-            // consecutive MFMAs never depend on each other
-            constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
-#pragma unroll
-            for (int t6 = 0; t6 < 6; ++t6)
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[t6]], b[j][PB[t6]], acc[i][j], 0, 0, 0);
-        }
-        __syncthreads();  // every wave is done with this stage's planes
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[t6]], b[j][PB[t6]], acc[i][j], 0, 0, 0);
+    };
+    auto clampk = [&](int64_t t) { return kb + ((t < nk) ? t : nk - 1) * G3_TK; };
+    if (nk > 0) {
+        fetch(kb);
+        commit(0);
+        fetch(clampk(1));
+        __syncthreads();
+        load_frags(0, fa[0], fb[0]);
     }
+    // stage body for a compile-time parity (fragment sets and LDS images alternate)
+#define GQ_G3_STAGE(PAR, T)                                                          \
+    do {                                                                              \
+        mfmas(0, 3, fa[PAR], fb[PAR]);                                                \
+        commit((PAR) ^ 1); /* past the end: the last chunk again, into the idle image */ \
+        fetch(clampk((T) + 2));                                                       \
+        __syncthreads();                                                              \
+        load_frags((PAR) ^ 1, fa[(PAR) ^ 1], fb[(PAR) ^ 1]);                          \
+        mfmas(3, 6, fa[PAR], fb[PAR]);                                                \
+    } while (0)
+    for (int64_t t = 0; t < nk; t += 2) {
+        GQ_G3_STAGE(0, t);
+        if (t + 1 < nk) GQ_G3_STAGE(1, t + 1);
+    }
+#undef GQ_G3_STAGE
     const int lc = lane & 31, lh = lane >> 5;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -197,12 +220,13 @@ inline int launch_gemm3b(float* Cmat, int64_t ldc, const float* A, int64_t lda, 
     if ((lda % 4) || (ldb % 4) || ((uintptr_t)A % 16) || ((uintptr_t)B % 16))
         GQ_FAIL(GQ_E_BAD_SHAPE, "gemm3b: A/B must be 16-byte aligned with ld %% 4 == 0");
     dim3 grid((unsigned)((N + TN - 1) / TN), (unsigned)((M + TM - 1) / TM)), block(256);
-    if (M % TM == 0 && N % TN == 0 && K % TM == 0)  // whole tiles (k-ranges are 128-aligned too): no edge predication
-        hipLaunchKernelGGL((gemm3b_kernel<TRANS_B, MODE, LOWER, KR, true>), grid, block, G3_LDS_BYTES, st, Cmat, ldc, A, lda,
-                           B, ldb, M, N, K);
+    const bool full = (M % TM == 0 && N % TN == 0 && K % TM == 0);  // whole tiles (k-ranges are 128-aligned too)
+    if (full)
+        hipLaunchKernelGGL((gemm3b_kernel<TRANS_B, MODE, LOWER, KR, true>), grid, block, G3_LDS_BYTES, st, Cmat, ldc, A,
+                           lda, B, ldb, M, N, K);
     else
-        hipLaunchKernelGGL((gemm3b_kernel<TRANS_B, MODE, LOWER, KR, false>), grid, block, G3_LDS_BYTES, st, Cmat, ldc, A, lda,
-                           B, ldb, M, N, K);
+        hipLaunchKernelGGL((gemm3b_kernel<TRANS_B, MODE, LOWER, KR, false>), grid, block, G3_LDS_BYTES, st, Cmat, ldc, A,
+                           lda, B, ldb, M, N, K);
     GQ_LAUNCH_CHECK();
     return GQ_OK;
 }

@@ -9,7 +9,7 @@ import csv, glob, collections
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
 for f in glob.glob("$R/gpurun_out/pmc_chol_$TAG/p/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "gemm3b" in r["Kernel_Name"] and r["Grid_Size"] == str(14336 * 56):
+        if "gemm3" in r["Kernel_Name"] and r["Grid_Size"] == str(14336 * 56):
             k = r["Kernel_Name"].split("(")[0][-36:]
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
 for k, v in agg.items():
