@@ -22,6 +22,8 @@
 #pragma once
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "gq_common.hpp"
 
 namespace gq {
@@ -122,6 +124,12 @@ __device__ __forceinline__ void g32_load_kn_full(float4 (&v)[NV], const float* B
 
 #ifndef GQ_G32_CHAIN_NW
 #define GQ_G32_CHAIN_NW 8
+#endif
+#ifndef GQ_G32C_COMMIT_AT
+#define GQ_G32C_COMMIT_AT 16
+#endif
+#ifndef GQ_G32C_BARRIER_AT
+#define GQ_G32C_BARRIER_AT 26
 #endif
 #ifndef GQ_G32_COMMIT_AT
 #define GQ_G32_COMMIT_AT 24
@@ -267,6 +275,166 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm32_kernel(float* Cmat, int64_t
         }
 }
 
+// ---- the GPTQ far trailing update on whole tiles: C = (..((C - A_0 B_0) - A_1 B_1)..), NN, 128x128 tiles ----
+// Same arithmetic as gemm32_kernel<false, 0, false, 0, CHAIN, 128, true, 8> (every output element is the same
+// sequence of k-ordered 128-long chains and subtractions), scheduled for the matrix pipe:
+//   * fragment reads are inline asm with counted s_waitcnt: the compiler otherwise sinks every ds_read next
+//     to its MFMA (measured: 74 % MFMA busy, each pair of MFMAs waiting ~100 cycles for its operands, and for
+//     the LDS writes of the next chunk queued in front of them).  A group = 2 k-steps = 2 ds_read2_b32 (A) +
+//     2 ds_read_b32 (B) + 4 MFMAs; reads run two groups (8 MFMAs) ahead in four rotating register sets;
+//   * ring of THREE LDS images and the barrier in the MIDDLE of a chunk (before group 6, whose prefetch is the
+//     first read of the next image): chunk boundaries have no barrier.  A writer of image (t+1)%3 has passed
+//     barrier t-1, which every wave reaches only after its last read of that image in chunk t-2;
+//   * the loop body is [second half of chain c | subtraction | first half of chain c+1]: the 32 subtractions
+//     of a chain end interleave with the first MFMAs of the next chain, which start from the inline constant 0.
+// 8 waves (2x4), wave tile 64x32, one workgroup per CU (99 KiB of LDS, <= 256 VGPRs).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define GQ_C_RD2(dst, addr, o0, o1) \
+    asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(dst) : "v"(addr), "n"(o0), "n"(o1))
+#define GQ_C_RD1(dst, addr, off) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+// every LDS operation older than the N most recent has completed; the "+v" operands make the consumers of
+// the group's registers depend on the wait
+#define GQ_C_WAIT(N, s) \
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(fa0[s]), "+v"(fa1[s]), "+v"(fb0[s]), "+v"(fb1[s]) : "n"(N))
+
+template <int CHAIN>
+__global__ __launch_bounds__(512, 2) void gemm32_chain_full_kernel(float* Cmat, int64_t ldc, const float* A, int64_t lda,
+                                                                   const float* B, int64_t ldb, int64_t K) {
+    extern __shared__ __attribute__((aligned(16))) float g32_smem[];
+    constexpr int TS = 128, NT = 512, NV = 2, STAGE = G32<TS>::STAGE_FLOATS, AF = G32<TS>::A_FLOATS, LDB = G32<TS>::LDB;
+    constexpr int SPC = CHAIN / TK;  // chunks per chain
+    static_assert(SPC == 4 && TK == 32, "the loop body is written for 4 chunks of 32 k per chain");
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 2, wn = wid & 3;
+    const int li = lane & 31, lk = lane >> 5;
+    const int64_t m0 = (int64_t)blockIdx.y * TS, n0 = (int64_t)blockIdx.x * TS;
+    const int64_t nk = K / TK;
+    f32x16 acc[2], cv[2];
+    float* cp[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        cp[i] = Cmat + (m0 + wm * 64 + i * 32 + 4 * lk) * ldc + n0 + wn * 32 + li;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) cv[i][e] = cp[i][((e & 3) + 8 * (e >> 2)) * ldc];
+    }
+    // global loads run TWO chunks ahead of the LDS write (measured: one chunk, ~2 us, does not cover the
+    // latency tail under load): two register sets, chunk c lives in set c & 1
+    float4 va[2][NV], vb[2][NV];
+    auto fetch = [&](int64_t t, float4 (&a)[NV], float4 (&b)[NV]) {
+        const int64_t k0 = ((t < nk) ? t : nk - 1) * TK;  // past the end: the last chunk again (never consumed)
+        g32_load_rows_full<NV, NT>(a, A, lda, m0, k0, tid);
+        g32_load_kn_full<NV, NT>(b, B, ldb, n0, k0, tid);
+    };
+    auto commit = [&](int buf, const float4 (&a)[NV], const float4 (&b)[NV]) {
+        float* As = g32_smem + buf * STAGE;
+        g32_store_rows<NV, NT>(a, As, LDA_S, tid);
+        g32_store_kn<NV, NT>(b, As + AF, tid);
+    };
+    // LDS byte addresses of this lane's fragments in image 0 (the dynamic LDS segment starts at address 0
+    // of the workgroup's allocation: no static __shared__ in this kernel)
+    const unsigned lds0 = (unsigned)(uintptr_t)g32_smem;
+    const unsigned aoff0 = lds0 + ((wm * 64 + li) * LDA_S + lk) * 4, aoff1 = aoff0 + 32 * LDA_S * 4;
+    const unsigned boff = lds0 + (AF + lk * LDB + wn * 32 + li) * 4;
+    f32x2 fa0[4], fa1[4];  // [set]: A tile 0 / 1, k-steps (4g, 4g+2)
+    float fb0[4], fb1[4];  // [set]: B at k-step 4g / 4g+2
+    // reads of group g (0..7) of the image whose fragment bases are (pa0, pa1, pb) into set s
+#define GQ_C_READS(g, s, pa0, pa1, pb)                  \
+    do {                                                \
+        GQ_C_RD2(fa0[s], pa0, 4 * (g), 4 * (g) + 2);    \
+        GQ_C_RD2(fa1[s], pa1, 4 * (g), 4 * (g) + 2);    \
+        GQ_C_RD1(fb0[s], pb, (4 * (g)) * LDB * 4);      \
+        GQ_C_RD1(fb1[s], pb, (4 * (g) + 2) * LDB * 4);  \
+    } while (0)
+    fetch(0, va[0], vb[0]);
+    commit(0, va[0], vb[0]);
+    fetch(1, va[1], vb[1]);
+    fetch(2, va[0], vb[0]);
+    __syncthreads();
+    unsigned ca0 = aoff0, ca1 = aoff1, cb = boff;  // fragment bases of the current image
+    int buf = 0;
+    int64_t t = 0;
+    GQ_C_READS(0, 0, ca0, ca1, cb);
+    GQ_C_READS(1, 1, ca0, ca1, cb);
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // one chunk = groups 0..7; FIRST: its first k-step starts a new chain.  On entry the reads of groups 0 and 1
+    // are in flight (sets 0, 1); on exit those of the next chunk are.
+    // PAR: parity of the NEXT chunk (t + 1), whose register set is written to LDS and refilled with chunk t + 3
+    auto chunk = [&](auto first_c, auto par_c) {
+        constexpr bool FIRST = decltype(first_c)::value;
+        constexpr int PAR = decltype(par_c)::value;
+        const int nbuf = (buf == 2) ? 0 : buf + 1;
+        const unsigned na0 = aoff0 + nbuf * STAGE * 4, na1 = aoff1 + nbuf * STAGE * 4, nb = boff + nbuf * STAGE * 4;
+#define GQ_C_GROUP(g)                                                                                        \
+    do {                                                                                                     \
+        if ((g) == 6) __builtin_amdgcn_s_barrier(); /* image nbuf is complete: its writes were waited at g = 4 */ \
+        if ((g) == 3) {                                                                                      \
+            GQ_C_WAIT(4, (g) & 3); /* before 6 more LDS operations: lgkmcnt counts to 15 */                  \
+            asm volatile("" ::: "memory");                                                                   \
+            commit(nbuf, va[PAR], vb[PAR]);                                                                  \
+            fetch(t + 3, va[PAR], vb[PAR]);                                                                  \
+            asm volatile("" ::: "memory");                                                                   \
+        }                                                                                                    \
+        if ((g) < 6) GQ_C_READS((g) + 2, ((g) + 2) & 3, ca0, ca1, cb);                                       \
+        else GQ_C_READS((g) - 6, ((g) + 2) & 3, na0, na1, nb);                                               \
+        GQ_C_WAIT(8, (g) & 3);                                                                               \
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[(g) & 3][0], fb0[(g) & 3], (FIRST && (g) == 0) ? zero : acc[0], 0, 0, 0); \
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[(g) & 3][0], fb0[(g) & 3], (FIRST && (g) == 0) ? zero : acc[1], 0, 0, 0); \
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[(g) & 3][1], fb1[(g) & 3], acc[0], 0, 0, 0);       \
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[(g) & 3][1], fb1[(g) & 3], acc[1], 0, 0, 0);       \
+    } while (0)
+        GQ_C_GROUP(0); GQ_C_GROUP(1); GQ_C_GROUP(2); GQ_C_GROUP(3);
+        GQ_C_GROUP(4); GQ_C_GROUP(5); GQ_C_GROUP(6); GQ_C_GROUP(7);
+#undef GQ_C_GROUP
+        buf = nbuf;
+        ca0 = na0; ca1 = na1; cb = nb;
+        ++t;
+    };
+    auto chain_end = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) cv[i][e] = cv[i][e] - acc[i][e];
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    const int64_t nchain = nk / SPC;
+    chunk(T_{}, P1{});  // chunk 0 (even): the next one is odd
+    chunk(F_{}, P0{});
+    for (int64_t c = 1; c < nchain; ++c) {
+        chunk(F_{}, P1{});
+        chunk(F_{}, P0{});
+        chain_end();
+        chunk(T_{}, P1{});
+        chunk(F_{}, P0{});
+    }
+    chunk(F_{}, P1{});
+    chunk(F_{}, P0{});
+    chain_end();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the prefetched (unused) fragments of the image after the last
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) cp[i][((e & 3) + 8 * (e >> 2)) * ldc] = cv[i][e];
+}
+#undef GQ_C_READS
+
+template <int CHAIN>
+inline int launch_gemm32_chain_full(float* Cmat, int64_t ldc, const float* A, int64_t lda, const float* B, int64_t ldb,
+                                    int64_t M, int64_t N, int64_t K, hipStream_t st) {
+    constexpr int LDS = 3 * G32<128>::STAGE_FLOATS * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        GQ_HIP(hipFuncSetAttribute((const void*)gemm32_chain_full_kernel<CHAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_set = true;
+    }
+    dim3 grid((unsigned)(N / 128), (unsigned)(M / 128)), block(512);
+    hipLaunchKernelGGL((gemm32_chain_full_kernel<CHAIN>), grid, block, LDS, st, Cmat, ldc, A, lda, B, ldb, K);
+    GQ_LAUNCH_CHECK();
+    return GQ_OK;
+}
+
 template <bool TRANS_B, int MODE, bool LOWER, int KR, int CHAIN, int TS, bool FULL>
 inline int launch_gemm32_full(float* Cmat, int64_t ldc, const float* A, int64_t lda, const float* B, int64_t ldb, int64_t M,
                             int64_t N, int64_t K, hipStream_t st) {
@@ -288,6 +456,10 @@ template <bool TRANS_B, int MODE, bool LOWER, int KR, int CHAIN, int TS>
 inline int launch_gemm32_ts(float* Cmat, int64_t ldc, const float* A, int64_t lda, const float* B, int64_t ldb, int64_t M,
                             int64_t N, int64_t K, hipStream_t st) {
     // whole tiles only (every GPTQ / Cholesky shape of a 128-multiple Linear): the unpredicated kernel
+    if constexpr (CHAIN == 128 && TS == 128 && !TRANS_B && MODE == 0 && !LOWER && KR == 0) {
+        static const bool generic = getenv("GQ_CHAIN_GENERIC") != nullptr;  // A/B: the generic chained kernel
+        if (!generic && M % TS == 0 && N % TS == 0) return launch_gemm32_chain_full<CHAIN>(Cmat, ldc, A, lda, B, ldb, M, N, K, st);
+    }
     if (M % TS == 0 && N % TS == 0 && K % TK == 0 && ldc % 4 == 0)
         return launch_gemm32_full<TRANS_B, MODE, LOWER, KR, CHAIN, TS, true>(Cmat, ldc, A, lda, B, ldb, M, N, K, st);
     return launch_gemm32_full<TRANS_B, MODE, LOWER, KR, CHAIN, TS, false>(Cmat, ldc, A, lda, B, ldb, M, N, K, st);

@@ -313,7 +313,7 @@ int gptq_quantize(float* W, const float* U, int64_t R, int64_t C, int q_type, in
         }
         // end of the super-block: all its blocks at once, every later column
         {
-            ProfScope ps(PT_TRAILING, st);
+            ProfScope ps(PT_TRAILING_FAR, st);
             if ((rc = launch_gemm32<false, 0, false, 0, LA_B>(W + S1, C, Err, ldE, U + S0 * C + S1, C, R, C - S1, S1 - S0, st)))
                 return rc;
         }

@@ -10,7 +10,7 @@ import csv, glob
 rows = []
 for f in glob.glob("$R/gpurun_out/trace_far/p/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "gemm32_kernel<false, 0, false, 0, 128" in r["Kernel_Name"]:
+        if "gemm32_kernel<false, 0, false, 0, 128" in r["Kernel_Name"] or "gemm32_chain_full_kernel" in r["Kernel_Name"]:
             rows.append(r)
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 print(len(rows), "far-update launches;", list(rows[0].keys()) if rows else "")

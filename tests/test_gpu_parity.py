@@ -123,7 +123,10 @@ def test_gptq_step_act_order_golden(ops, tag):
 
 
 @pytest.mark.parametrize("name,R,C,block", [("Q4_K", 96, 1024, 128), ("Q2_K", 200, 512, 128), ("Q3_K", 64, 768, 64),
-                                            ("Q5_K", 130, 512, 256), ("Q6_K", 64, 512, 96), ("Q4_K", 64, 768, 32)])
+                                            ("Q5_K", 130, 512, 256), ("Q6_K", 64, 512, 96), ("Q4_K", 64, 768, 32),
+                                            # C > 1024: the chained far update (whole-tile kernel at R = 128,
+                                            # predicated kernel at R = 72)
+                                            ("Q4_K", 128, 2304, 128), ("Q6_K", 72, 2048, 128)])
 def test_gptq_step_vs_oracle(ops, oracle, name, R, C, block):
     rng = np.random.default_rng(R + C)
     W0 = (rng.standard_normal((R, C)) * 0.02).astype(np.float16).astype(np.float32)
@@ -138,6 +141,34 @@ def test_gptq_step_vs_oracle(ops, oracle, name, R, C, block):
     assert np.array_equal(u16(d), od) and np.array_equal(u16(dmin), odm)
     assert np.array_equal(npy(s), os_) and np.array_equal(npy(m), om)
     assert np.array_equal(npy(W), Wd)
+
+
+@pytest.mark.parametrize("R", [256, 200])
+def test_gptq_lookahead_equals_per_block_updates(ops, R):
+    """The look-ahead schedule (near updates inside a 1024-column super-block, ONE chained GEMM for all later
+    columns) performs, per element, the same subtractions of the same k-ordered products in the same order as
+    gptq.py:270 applied block by block (GQ_NO_LOOKAHEAD=1): every output and the final W are bit-identical.
+    R = 256 takes the whole-tile chained kernel, R = 200 the predicated one; C = 3328 = 3.25 super-blocks."""
+    torch.manual_seed(R)
+    C = 3328
+    W0 = (torch.randn(R, C, device="cuda") * 0.02).half().float()
+    X = (torch.randn(2 * C, C, device="cuda") * torch.exp(torch.randn(C, device="cuda") * 0.5)).half()
+    H = torch.zeros(C, C, device="cuda")
+    ops.h_accumulate(H, X, 0.0, 2.0 / 4)
+    Wp = W0.clone()
+    U, flag = ops.h_prepare(H, Wp, 0.01)
+    assert int(flag.item()) == 0
+    outs = []
+    for env in (None, "1"):
+        if env:
+            os.environ["GQ_NO_LOOKAHEAD"] = env
+        try:
+            W = Wp.clone()
+            outs.append((W,) + tuple(ops.gptq_quantize(W, U, 12, 128)))
+        finally:
+            os.environ.pop("GQ_NO_LOOKAHEAD", None)
+    for a, b in zip(*outs):
+        assert torch.equal(a.view(torch.uint8), b.view(torch.uint8))
 
 
 def test_gptq_bad_args(ops):
