@@ -54,6 +54,7 @@ TINY = {  # TinyLlama-1.1B block (configs[0] shapes) for quick runs
     "down_proj": (2048, 5632, "down_in"),
 }
 PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X dense fp16/bf16 MFMA (MI355X_MICROARCH.md)
+ROW_SPLIT = -1  # owner id of a matrix every rank quantizes on its own rows (dist_utils.row_split_names)
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X fp32 matrix (v_mfma_f32_32x32x2_f32: 256 flop/clk/CU x 256 CUs x 2.4 GHz)
 
 
@@ -134,10 +135,13 @@ def quantize_block(shapes, W16, X, owners, rank, world, q_type=Q4_K, block_size=
     # chain overlap with the GEMMs of the others.
     out, pending = {}, []
     groups = {}
+    split = {n for n, o in owners.items() if o == ROW_SPLIT}  # every rank: factorise, quantize its own rows
     for name, (R, C, inp) in shapes.items():
-        if owners[name] == rank:
+        if owners[name] == rank or name in split:
             groups.setdefault(inp, []).append(name)
-    order = sorted(groups, key=lambda g: -sum(shapes[n][0] * shapes[n][1] * shapes[n][1] for n in groups[g]))
+    # the critical chain first: row-split matrices (their factorisation is replicated on every rank), then by cost
+    order = sorted(groups, key=lambda g: (not any(n in split for n in groups[g]),
+                                          -sum(shapes[n][0] * shapes[n][1] * shapes[n][1] for n in groups[g])))
     host_trace = os.environ.get("GQ_BENCH_TRACE_HOST")
     t_host0 = time.perf_counter()
     for gi, inp in enumerate(order):
@@ -159,9 +163,17 @@ def quantize_block(shapes, W16, X, owners, rank, world, q_type=Q4_K, block_size=
                     mm = ops.w_prepare(cf, Wf)  # speculative reuse of the leader's U, verified below
                 # the widest Linear is the critical chain: its rows are split over side streams
                 chunks = row_chunks if (gi == 0 and len(groups[inp]) == 1) else 1
-                q, d, s, dmin, m = ops.gptq_quantize(Wf, U, q_type, block_size, row_chunks=chunks)
-                deq = ops.dequantize(q_type, q, d, s, dmin, m, torch.float16)
-                packed = ops.pack(q_type, q, d, s, dmin, m)
+                Wq = Wf
+                if name in split:
+                    r0, r1, rchunk = dist_utils.row_slice(R, rank, world)
+                    Wq = Wf[r0:r1]
+                if Wq.shape[0] > 0:
+                    q, d, s, dmin, m = ops.gptq_quantize(Wq, U, q_type, block_size, row_chunks=chunks)
+                    deq = ops.dequantize(q_type, q, d, s, dmin, m, torch.float16)
+                    packed = ops.pack(q_type, q, d, s, dmin, m)
+                else:
+                    deq = torch.empty(0, C, device=dev, dtype=torch.float16)
+                    q = d = s = dmin = m = packed = None
                 out[name] = deq
                 pending.append((name, inp, mm))
                 if keep is not None:
@@ -181,6 +193,10 @@ def quantize_block(shapes, W16, X, owners, rank, world, q_type=Q4_K, block_size=
             ops.pack(q_type, q, d, s, dmin, m)
     if world > 1:
         for name, (R, C, inp) in shapes.items():
+            if name in split:  # all-gather of the ranks' row slices (padded to the common chunk height)
+                r0, r1, rchunk = dist_utils.row_slice(R, rank, world)
+                out[name] = dist_utils.all_gather_rows(out[name], R, rchunk)
+                continue
             if name not in out:
                 out[name] = torch.empty(R, C, device=dev, dtype=torch.float16)
             dist.broadcast(out[name], src=owners[name])
@@ -288,7 +304,9 @@ def main():
     nseq_local = nseq // world  # contiguous shard, remainder dropped (quant.py:177-179)
     params = sum(R * C for R, C, _ in shapes.values())
     costs = {n: float(R) * C * (C + 128) for n, (R, C, _) in shapes.items()}
-    owners = dist_utils.assign_owners(costs, world)
+    split_names = dist_utils.row_split_names(costs, world)
+    owners = dist_utils.assign_owners({n: c for n, c in costs.items() if n not in split_names}, world)
+    owners.update({n: ROW_SPLIT for n in split_names})
 
     W16 = make_weights(shapes, dev)
     X = make_inputs(shapes, nseq_local, L, dev, seed=1 + rank)
@@ -377,7 +395,7 @@ def main():
                                    f"{nseq}x{L}-token calibration ({hb} sequences per Hessian launch), block_size 128, "
                                    f"rel_damp 0.01, nstep 20",
                        "calib_seqs_per_rank": nseq_local, "parallelism": f"calib-dp{world}+matrix-fanout",
-                       "owners": owners if world > 1 else "rank0"},
+                       "owners": {n: (f"rows/{world}" if o == ROW_SPLIT else o) for n, o in owners.items()} if world > 1 else "rank0"},
             "wall_s_llama3_8b_32_blocks_extrapolated": round(dt / args.steps * 32, 2)
             if args.workload.startswith("llama3") else None,
             "roofline": roof,

@@ -1,7 +1,8 @@
 """Rank helpers + the two multi-GPU decisions of the path (reference dist_utils.py:19-59,
 quant.py:177-179, gptq.py:131-132): calibration sharding and, new here, the per-matrix
 owner assignment that lets the independent Linears of a block quantize on different GPUs."""
-from typing import Dict, List, Sequence
+import os
+from typing import Dict, List, Sequence, Set, Tuple
 
 import torch.distributed as dist
 
@@ -57,3 +58,40 @@ def assign_owners(costs: Dict[str, float], world_size: int) -> Dict[str, int]:
         owners[name] = r
         loads[r] += costs[name]
     return owners
+
+
+def row_split_names(costs: Dict[str, float], world_size: int) -> Set[str]:
+    """Linears of a block that EVERY rank quantizes on its own slice of rows (rows are independent in
+    the column loop given U, so a matrix that alone outweighs a fair share is split R/k rows per GPU with the
+    factorisation replicated).  Replicating the Cholesky chain costs every rank its full time, so the split
+    only pays from 4 ranks up (2 ranks: one takes the widest matrix, the other everything else -- already
+    balanced); GQ_ROW_SPLIT=0 / 1 forces never / always, "all" splits every matrix (tests).  Deterministic: the
+    same set on every rank."""
+    env = os.environ.get("GQ_ROW_SPLIT")
+    if world_size <= 1 or env == "0":
+        return set()
+    if env == "all":
+        return set(costs)
+    if env != "1" and world_size < 4:
+        return set()
+    total = sum(costs.values())
+    return {n for n, c in costs.items() if c > 0.4 * total}
+
+
+def row_slice(rows: int, rank: int, world_size: int, align: int = 128) -> Tuple[int, int, int]:
+    """-> (r0, r1, chunk): rank's rows [r0, r1) of a row-split matrix; chunk (a multiple of `align`, so the
+    whole-tile kernels apply) is the padded per-rank height used by the all-gather.  Late ranks may be empty."""
+    chunk = -(-rows // world_size)
+    chunk = -(-chunk // align) * align
+    r0 = min(rank * chunk, rows)
+    return r0, min(r0 + chunk, rows), chunk
+
+
+def all_gather_rows(part, rows: int, chunk: int):
+    """Concatenate the ranks' row slices (each padded to `chunk` rows) -> [rows, ...] on every rank."""
+    import torch
+    pad = torch.zeros((chunk,) + tuple(part.shape[1:]), dtype=part.dtype, device=part.device)
+    pad[:part.shape[0]] = part
+    pieces = [torch.empty_like(pad) for _ in range(get_world_size())]
+    dist.all_gather(pieces, pad)
+    return torch.cat(pieces, dim=0)[:rows].contiguous()

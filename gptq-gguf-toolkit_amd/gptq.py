@@ -42,6 +42,7 @@ class GPTQ:
         self.verbose = verbose
         # --- beyond the reference ---
         self.owner_rank = 0            # rank that runs step(); the reference hard-codes rank 0 (gptq.py:158)
+        self.row_split = False         # every rank runs step() on its own rows (dist_utils.row_split_names)
         self.shared_H_with = None      # another handle fed by the SAME input tensor (q/k/v, gate/up)
         self._flag = None
         self._ws = None
@@ -168,8 +169,18 @@ class GPTQ:
         if self.act_order:
             return self._compute_act_order(q_type)
         U = self._prepare()
-        return _ops.gptq_quantize(self.W, U, int(q_type), self.block_size, self.static_groups, self.rmin,
+        W = self.W
+        if self._row_split_active():
+            # every rank factorises (same reduced H => the same U, bit for bit) and walks its own rows
+            r0, r1, _ = dist_utils.row_slice(self.d_row, dist_utils.get_rank(), dist_utils.get_world_size())
+            if r1 <= r0:
+                return tuple(t[:0] for t in self._empty_result(q_type))
+            W = self.W[r0:r1]
+        return _ops.gptq_quantize(W, U, int(q_type), self.block_size, self.static_groups, self.rmin,
                                   self.rdelta, self.nstep)
+
+    def _row_split_active(self) -> bool:
+        return bool(getattr(self, "row_split", False)) and not self.act_order and dist_utils.get_world_size() > 1
 
     @torch.no_grad()
     def _compute_act_order(self, q_type: GGMLQuantizationType):
@@ -208,6 +219,9 @@ class GPTQ:
     @torch.no_grad()
     def exchange(self, result, q_type: GGMLQuantizationType):
         """Broadcast of the 5 result tensors from the owner (reference gptq.py:287-293, src=0 there)."""
+        if self._row_split_active():  # all-gather of the ranks' row slices instead of the owner's broadcast
+            _, _, chunk = dist_utils.row_slice(self.d_row, dist_utils.get_rank(), dist_utils.get_world_size())
+            return tuple(dist_utils.all_gather_rows(t, self.d_row, chunk) for t in result)
         if result is None:
             result = self._empty_result(q_type)
         if dist_utils.is_dist_available_and_initialized() and dist_utils.get_world_size() > 1:
@@ -219,7 +233,10 @@ class GPTQ:
     def step(self, q_type: GGMLQuantizationType) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor]:
         """-> (qweight, super_group_scale, group_scale_quant, super_group_zero, group_zero_quant)
         on every rank (reference return order, gptq.py:295)."""
-        res = self.compute(q_type) if dist_utils.get_rank() == self.owner_rank else None
+        if q_type == GGMLQuantizationType.Q3_K:  # before the row-split test: compute() would reset it
+            self.act_order = False
+        mine = dist_utils.get_rank() == self.owner_rank or self._row_split_active()
+        res = self.compute(q_type) if mine else None
         return self.exchange(res, q_type)
 
     def quantize(self, q_type: GGMLQuantizationType):

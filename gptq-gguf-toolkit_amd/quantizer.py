@@ -159,15 +159,24 @@ class Quantizer:
         qtypes = {n: quant_config.get(n.split(".")[-1], GGMLQuantizationType.Q4_K) for n in handles}
         if world > 1:
             costs = {n: float(h.d_row) * h.d_col * (h.d_col + 128) for n, h in handles.items()}
-            for n, r in dist_utils.assign_owners(costs, world).items():
+            # a matrix that outweighs a fair share is quantized by every rank on its own rows (U replicated);
+            # the rest are handed out whole
+            split = {n for n in dist_utils.row_split_names(costs, world) if not handles[n].act_order}
+            for n in split:
+                handles[n].row_split = True
+            for n, r in dist_utils.assign_owners({n: c for n, c in costs.items() if n not in split}, world).items():
                 handles[n].owner_rank = r
         # phase 0: one all-reduce per distinct Hessian, same order on every rank
         for h in handles.values():
             h.sync_hessian()
         # phase 1: owners run prepare + column loop, no communication in between
         results = {}
-        for n, h in handles.items():
-            if h.owner_rank == rank:
+        order = sorted(handles, key=lambda n: not getattr(handles[n], "row_split", False))  # split matrices first
+        for n in order:
+            h = handles[n]
+            if qtypes[n] == GGMLQuantizationType.Q3_K:
+                h.act_order = False  # reference gptq.py:204-206
+            if h.owner_rank == rank or h._row_split_active():
                 if self.verbose:
                     print(f"[rank {rank}] Quantizing {n} with {qtypes[n].name}.")
                 h.make_working_copy()

@@ -186,6 +186,49 @@ def _worker(rank, world, port, tmp, ret):
     dist.destroy_process_group()
 
 
+def test_row_split_plan():
+    from gptq_gguf_toolkit_amd.dist_utils import row_slice, row_split_names
+    shapes = {"q": (4096, 4096), "k": (1024, 4096), "v": (1024, 4096), "o": (4096, 4096), "gate": (14336, 4096),
+              "up": (14336, 4096), "down": (4096, 14336)}
+    costs = {n: float(r) * c * (c + 128) for n, (r, c) in shapes.items()}
+    os.environ.pop("GQ_ROW_SPLIT", None)
+    assert row_split_names(costs, 1) == set() and row_split_names(costs, 2) == set()
+    assert row_split_names(costs, 4) == {"down"} and row_split_names(costs, 8) == {"down"}  # 56 % of a Llama block
+    for R, w in ((4096, 8), (4096, 4), (1000, 8), (130, 4)):
+        sl = [row_slice(R, r, w) for r in range(w)]
+        assert sl[0][0] == 0 and all(a[1] == b[0] for a, b in zip(sl, sl[1:])) and sl[-1][1] == R  # a partition
+        assert all(c[2] % 128 == 0 and c[1] - c[0] <= c[2] for c in sl)
+
+
+def _worker_split(rank, world, port, tmp, ret):
+    os.environ["GQ_ROW_SPLIT"] = "all"
+    _worker(rank, world, port, tmp, ret)
+
+
+def test_two_rank_row_split_matches_owner_mode(tmp_path):
+    """Row-split mode (every rank factorises, quantizes its own rows, all-gather) produces the same model and the
+    same data.pth tree as owner mode (one rank per matrix, broadcast): rows are independent given U."""
+    world = 2
+    mgr = mp.Manager()
+    outs = []
+    for k, fn in enumerate((_worker, _worker_split)):
+        ret = mgr.dict()
+        d = str(tmp_path / f"m{k}")
+        os.makedirs(d)
+        mp.spawn(fn, args=(world, 31000 + k * 7 + os.getpid() % 2000, d, ret), nprocs=world, join=True)
+        outs.append((d, ret[0], ret[1]))
+    (d0, (sd0, c0), _), (d1, (sd1, c1), (sd1b, c1b)) = outs
+    for k in sd0:
+        assert torch.equal(sd0[k], sd1[k]) and torch.equal(sd1[k], sd1b[k]), f"{k} differs"
+    # rank 0 walked (its rows of) every matrix, rank 1 those with more than one 128-row slice
+    assert c1["gptq_quantize"] == 14 and 0 < c1b["gptq_quantize"] <= 14
+    for n in sorted(os.listdir(d0)):
+        a = torch.load(os.path.join(d0, n, "data.pth"), weights_only=True)
+        b = torch.load(os.path.join(d1, n, "data.pth"), weights_only=True)
+        for key in a:
+            assert (a[key] == b[key]).all() if torch.is_tensor(a[key]) else a[key] == b[key], f"{n}/{key}"
+
+
 def test_two_rank_gloo_matches_single_rank(tmp_path):
     """calib-sharded H (all-reduce AVG) + per-matrix owners + broadcast: every rank ends with the same
     quantized model, equal to the 1-rank run on the full calibration set up to H rounding order."""
