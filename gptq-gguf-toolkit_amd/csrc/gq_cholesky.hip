@@ -294,6 +294,7 @@ __global__ __launch_bounds__(256) void diag_blk_kernel(float* __restrict__ A, in
             // ---- factor + invert the 32x32 diagonal sub-block in registers (lanes 32-63 mirror 0-31)
             const int i = lane & 31;
             float a[32], x[32];
+            float myinv = 0.0f;  // lane j: 1 / L[j][j]
 #pragma unroll
             for (int c = 0; c < 32; ++c) a[c] = S[(c0 + i) * LDQ + c0 + c];
             bool bad = false;
@@ -304,18 +305,25 @@ __global__ __launch_bounds__(256) void diag_blk_kernel(float* __restrict__ A, in
                     bad = true;
                     pj = 1.0f;
                 }
-                const float ljj = sqrtf(pj), inv = 1.0f / ljj;
+                // 1/sqrt by v_rsq_f32 + one Newton step (<= 2 ulp) instead of an IEEE sqrt and an IEEE division:
+                // the 128 pivots of a block are a serial chain, ~35 dependent instructions shorter each this way.
+                // U is a tolerance-class output: the pivot itself carries the rounding of a
+                // 14336-term sum.
+                float inv = __builtin_amdgcn_rsqf(pj);
+                inv = fmaf(inv, fmaf(-0.5f * pj * inv, inv, 0.5f), inv);
+                const float ljj = pj * inv;
+                if (i == j) myinv = inv;
                 a[j] = (i == j) ? ljj : a[j] * inv;
 #pragma unroll
                 for (int c = j + 1; c < 32; ++c) a[c] = fmaf(-a[j], rdlane(a[j], c), a[c]);
             }
 #pragma unroll
             for (int r = 0; r < 32; ++r) {  // lane i = column i of the inverse
-                const float lrr = rdlane(a[r], r);
+                const float irr = rdlane(myinv, r);
                 float acc = 0.0f;
 #pragma unroll
                 for (int p = 0; p < r; ++p) acc = fmaf(rdlane(a[p], r), x[p], acc);
-                x[r] = (r < i) ? 0.0f : ((r == i) ? 1.0f / lrr : -acc / lrr);
+                x[r] = (r < i) ? 0.0f : ((r == i) ? irr : -acc * irr);
             }
             if (lane < 32) {
 #pragma unroll
