@@ -16,9 +16,12 @@
 //
 // Workgroup = 256 threads = 4 waves (2x2); tile TS x TS, TS = 128 (each wave owns 64x64 = 2x2 MFMA tiles,
 // 64 accumulator VGPRs) or TS = 64 (one MFMA tile per wave) for problems too small to fill the chip with
-// 128-tiles: a 128x128x128 tile is 8.6 us of matrix-pipe time on ONE CU, four 64-tiles are 2.1 us on four.  K streams in chunks of 32 through a double-buffered
-// LDS image: the global loads of chunk t+1 are issued into registers before the 64 MFMAs
-// of chunk t and written to the other LDS buffer after them (one barrier per chunk).
+// 128-tiles: a 128x128x128 tile is 8.6 us of matrix-pipe time on ONE CU, four 64-tiles are 2.1 us on four.
+// K streams in chunks of 32 through a double-buffered LDS image: chunk t+1 is written to the other image in
+// the middle of the MFMA block of chunk t and the loads of chunk t+2 follow it (one barrier per chunk, one
+// basic block per chunk).  FULL kernels (whole tiles) load without predicates.  The CHAIN kernel also holds
+// the C tile and runs 8 waves (2x4, wave tile 64x32); the GPTQ far update on whole tiles has its own kernel,
+// gemm32_chain_full_kernel below.
 #pragma once
 #include <stdlib.h>
 
