@@ -39,12 +39,31 @@ def shard_calibration(data: Sequence, rank: int, world_size: int) -> list:
     return list(data[rank * n:(rank + 1) * n])
 
 
-def allreduce_hessian(H):
+def allreduce_hessian(H, num_samples=None):
     """One collective per distinct Hessian (reference gptq.py:131-132: all_reduce AVG).
-    Backend 'nccl' is RCCL over xGMI on ROCm; 'gloo' in the CPU tests."""
-    if is_dist_available_and_initialized() and get_world_size() > 1:
+    Backend 'nccl' is RCCL over xGMI on ROCm; 'gloo' in the CPU tests.
+
+    `num_samples` (this rank's sample count behind H) makes the reduction sample-weighted when the ranks saw
+    DIFFERENT counts -- MoE experts receive a data-dependent number of tokens per rank, and
+    H = (2/N) sum x x^T over all ranks' tokens is sum_r n_r H_r / sum_r n_r, not the plain mean.  With equal
+    counts (every dense Linear) the reference's AVG is used unchanged.  Returns the total sample count (None when
+    num_samples is None)."""
+    if not (is_dist_available_and_initialized() and get_world_size() > 1):
+        return num_samples
+    if num_samples is None:
         dist.all_reduce(H, op=dist.ReduceOp.AVG)
-    return H
+        return None
+    import torch
+    counts = torch.zeros(get_world_size(), dtype=torch.float64, device=H.device)
+    counts[get_rank()] = float(num_samples)
+    dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+    total = float(counts.sum().item())
+    if bool((counts == counts[0]).all()):
+        dist.all_reduce(H, op=dist.ReduceOp.AVG)
+    elif total > 0:
+        H.mul_(float(num_samples) / total)
+        dist.all_reduce(H, op=dist.ReduceOp.SUM)
+    return int(total)
 
 
 def assign_owners(costs: Dict[str, float], world_size: int) -> Dict[str, int]:

@@ -23,7 +23,8 @@ from .quant_utils import GGML_QUANT_SIZES, GGMLQuantizationType, _check_scale
 class GPTQ:
     def __init__(self, layer: nn.Module, rel_damp: float = 1e-2, block_size: Optional[int] = None,
                  act_order: bool = False, quant_scale: str = "absmax", rmin: float = -1.0, rdelta: float = 0.1,
-                 nstep: int = 20, grid: int = 100, static_groups: bool = False, verbose: bool = False):
+                 nstep: int = 20, grid: int = 100, static_groups: bool = False, verbose: bool = False,
+                 allow_no_samples: bool = False):
         if act_order:
             assert static_groups  # reference gptq.py:45-46
         assert isinstance(layer, (nn.Linear, _ConvNd)), "OBC supports only linear and convolutional layers."
@@ -43,6 +44,10 @@ class GPTQ:
         # --- beyond the reference ---
         self.owner_rank = 0            # rank that runs step(); the reference hard-codes rank 0 (gptq.py:158)
         self.row_split = False         # every rank runs step() on its own rows (dist_utils.row_split_names)
+        # MoE experts may receive no calibration token at all: with allow_no_samples the handle then uses H = I
+        # (round-to-nearest with the lazily computed scales) instead of the reference's assertion (gptq.py:126)
+        self.allow_no_samples = allow_no_samples
+        self.no_samples = False
         self.shared_H_with = None      # another handle fed by the SAME input tensor (q/k/v, gate/up)
         self._flag = None
         self._ws = None
@@ -122,11 +127,19 @@ class GPTQ:
             self.H = leader.H
             self._reduced = True
             return
-        assert self.H is not None, "One has to process at least one sample of calibration data to run pruning"
+        if not self.allow_no_samples:
+            assert self.H is not None, "One has to process at least one sample of calibration data to run pruning"
+        if self.H is None:  # this rank saw no token of this expert: it still takes part in the collective
+            self.H = torch.zeros((self.d_col, self.d_col), device=self.W_device, dtype=torch.float32)
         self.flush()
         self._buf = None
         if not getattr(self, "_reduced", False):
-            dist_utils.allreduce_hessian(self.H)
+            # sample-weighted when the ranks' counts differ (experts); plain AVG otherwise (every dense Linear)
+            total = dist_utils.allreduce_hessian(self.H, self.num_samples)
+            if total == 0:
+                assert self.allow_no_samples
+                self.H = torch.eye(self.d_col, device=self.W_device, dtype=torch.float32)
+                self.no_samples = True
             self._reduced = True
 
     @torch.no_grad()

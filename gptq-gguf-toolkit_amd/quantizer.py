@@ -116,11 +116,14 @@ class Quantizer:
         dist_utils.barrier()
 
     # --------------------------------------------------------- hooks / handles
-    def _create_handle(self, layer) -> GPTQ:
-        return GPTQ(layer, **self.quantizer_kwargs)
+    def _create_handle(self, layer, name: str = "") -> GPTQ:
+        # MoE expert Linears ("...experts.<e>.w1"): the router may send them no calibration token at all, and a
+        # data-dependent number per rank -- the handle then falls back to H = I and reduces H sample-weighted
+        # (the reference asserts, gptq.py:126, and averages unweighted)
+        return GPTQ(layer, allow_no_samples=".experts." in f".{name}.", **self.quantizer_kwargs)
 
     def _prepare_hooks_and_handles(self, layers: Dict[str, nn.Module]):
-        handles: Dict[str, GPTQ] = {n: self._create_handle(l) for n, l in layers.items()}
+        handles: Dict[str, GPTQ] = {n: self._create_handle(l, n) for n, l in layers.items()}
         hooks = {}
         seen: Dict[Any, Any] = {}  # per block call: input identity -> (leader handle, tensor kept alive)
 

@@ -413,6 +413,40 @@ def test_h_prepare_full_size(ops):
     assert bool((U[r, c] == 0).all())
 
 
+@pytest.mark.parametrize("name", list(TYPES))
+def test_full_width_linear_every_type_vs_oracle_rows(ops, oracle, name):
+    """BASELINE config 3 (every K-quant encoder on Llama-3-8B Linears) at FULL width C = 4096, R = 1024 (k_proj):
+    the whole GPU path (scale search at every 256-column boundary, 32 column-loop blocks, near and chained far
+    trailing updates) against the oracle on a 48-row slice given the same U -- rows are independent, so the
+    slice's integers, scales and final weights must be bit-identical.  Plus the size-independent properties on
+    all rows: W_out == dequantize(outputs), packed bytes decode (independent ggml-spec decoder) to the same fields."""
+    torch.manual_seed(40 + TYPES[name])
+    R, C, T = 1024, 4096, 8192
+    X = (torch.randn(T, C, device="cuda") * torch.exp(torch.randn(C, device="cuda") * 0.5)).half()
+    X[:, torch.randperm(C, device="cuda")[:4]] *= 20.0  # outlier channels (SURVEY 8d)
+    H = torch.zeros(C, C, device="cuda")
+    ops.h_accumulate(H, X, 0.0, 2.0 / 4)
+    del X
+    W0 = (torch.randn(R, C, device="cuda") * 0.02).half().float()
+    Wp = W0.clone()
+    U, flag = ops.h_prepare(H, Wp, 0.01)
+    assert int(flag.item()) == 0
+    t = TYPES[name]
+    W = Wp.clone()
+    q, d, s, dmin, m = ops.gptq_quantize(W, U, t, block_size=128)
+    rows = slice(517, 565)
+    Wd, oq, od, os_, odm, om = oracle.gptq_step(npy(Wp[rows]), npy(U), t, block_size=128)
+    assert np.array_equal(npy(q[rows]), oq), f"{(npy(q[rows]) != oq).mean():.4%} ints differ"
+    assert np.array_equal(u16(d[rows]), od) and np.array_equal(u16(dmin[rows]), odm)
+    assert np.array_equal(npy(s[rows]), os_) and np.array_equal(npy(m[rows]), om)
+    assert np.array_equal(npy(W[rows]), Wd)
+    deq = ops.dequantize(t, q, d, s, dmin, m)
+    assert torch.equal(W, deq)
+    codes, d2, sc2, dm2, mn2 = unpack(t, npy(ops.pack(t, q, d, s, dmin, m)))
+    assert np.array_equal(codes, npy(q).astype(np.int32)) and np.array_equal(sc2, npy(s).astype(np.int32))
+    assert np.array_equal(d2, u16(d)) and np.array_equal(dm2, u16(dmin)) and np.array_equal(mn2, npy(m).astype(np.int32))
+
+
 def test_llama70b_down_proj_shape(ops):
     """Largest BASELINE shape (Llama-3-70B down_proj: C = 28672): accumulate -> prepare -> column loop on a row slice;
     exercises 112 x 112 tile tables, 224 diagonal blocks and 32-bit-safe indexing (C*C = 8.2e8 elements)."""
@@ -436,6 +470,56 @@ def test_llama70b_down_proj_shape(ops):
     assert bool((W == deq).all()) and int(q.min()) >= 0 and int(q.max()) <= 15
     rel = ((deq - W0).norm() / W0.norm()).item()
     assert rel < 0.2, rel
+
+
+def test_mixtral_expert_shapes(ops):
+    """BASELINE config 5 (Mixtral-8x7B: experts Q3_K, attention Q6_K): an expert's w2 is 4096 x 14336 and sees
+    only the tokens routed to it -- ragged [tokens, C] batches with batch = tokens (gptq.py:86), T % 128 != 0
+    (the 128x128 SYRK path, C = 14336), sample-weighted telescoping; then prepare and the Q3_K column loop
+    (signed ints, 16-wide groups, no mins) on a row slice, and Q6_K on an attention-shaped 256 x 4096 slice."""
+    torch.manual_seed(55)
+    C, R = 14336, 256
+    sig = torch.exp(torch.randn(C, device="cuda") * 0.5)
+    batches = [1237, 611, 2053]
+    H = torch.zeros(C, C, device="cuda")
+    n = 0
+    i = torch.randint(0, C, (1024,), device="cuda")
+    j = torch.randint(0, C, (1024,), device="cuda")
+    ref = torch.zeros(1024, device="cuda", dtype=torch.float64)
+    for b in batches:
+        X = (torch.randn(b, C, device="cuda") * sig).half()
+        ops.h_accumulate(H, X, n / (n + b), 2.0 / (n + b))
+        ref += (X[:, i].double() * X[:, j].double()).sum(0)
+        n += b
+    ref *= 2.0 / n
+    assert ((H[i, j].double() - ref).abs() <= 2e-5 * ref.abs().max()).all()
+    assert torch.equal(H, H.T)
+    W0 = (torch.randn(R, C, device="cuda") * 0.02).half().float()
+    W = W0.clone()
+    U, flag = ops.h_prepare(H, W, 0.01)  # 3901 tokens < C: rank-deficient, made definite by the damping
+    assert int(flag.item()) == 0
+    t = TYPES["Q3_K"]
+    q, d, s, dmin, m = ops.gptq_quantize(W, U, t, block_size=128)
+    assert q.dtype == torch.int8 and int(q.min()) >= -4 and int(q.max()) <= 3
+    assert int(s.min()) >= 0 and int(s.max()) <= 31 and not bool(dmin.any()) and not bool(m.any())
+    deq = ops.dequantize(t, q, d, s, dmin, m)
+    assert torch.equal(W, deq)
+    codes, d2, sc2, dm2, mn2 = unpack(t, npy(ops.pack(t, q, d, s, dmin, m)))
+    assert np.array_equal(codes, npy(q).astype(np.int32)) and np.array_equal(sc2, npy(s).astype(np.int32))
+    assert ((deq - W0).norm() / W0.norm()).item() < 0.35
+    # attention side: Q6_K, 4096 wide
+    Ca = 4096
+    Xa = (torch.randn(3000, Ca, device="cuda") * sig[:Ca]).half()
+    Ha = torch.zeros(Ca, Ca, device="cuda")
+    ops.h_accumulate(Ha, Xa, 0.0, 2.0 / 3000)
+    Wa0 = (torch.randn(R, Ca, device="cuda") * 0.02).half().float()
+    Wa = Wa0.clone()
+    Ua, flag = ops.h_prepare(Ha, Wa, 0.01)
+    assert int(flag.item()) == 0
+    t = TYPES["Q6_K"]
+    q, d, s, dmin, m = ops.gptq_quantize(Wa, Ua, t, block_size=128)
+    assert int(q.min()) >= -32 and int(q.max()) <= 31 and torch.equal(Wa, ops.dequantize(t, q, d, s, dmin, m))
+    assert ((Wa - Wa0).norm() / Wa0.norm()).item() < 0.05
 
 
 # --------------------------------------------------------------- K2/K3 prepare

@@ -186,6 +186,51 @@ def _worker(rank, world, port, tmp, ret):
     dist.destroy_process_group()
 
 
+def _worker_moe(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import fake_ops
+    fake_ops.install()
+    from gptq_gguf_toolkit_amd.gptq import GPTQ
+    torch.manual_seed(0)
+    C, R = 256, 32
+    lin = torch.nn.Linear(C, R, bias=False)
+    toks = torch.randn(8, C)                       # the expert's tokens of the whole calibration set
+    mine = toks[:3] if rank == 0 else toks[3:]     # 3 tokens routed on rank 0, 5 on rank 1
+    h = GPTQ(lin, allow_no_samples=True)
+    h.update(mine[:2])                             # 2-D [tokens, C] inputs, as an expert Linear sees them
+    h.update(mine[2:])
+    h.sync_hessian()
+    idle = GPTQ(torch.nn.Linear(C, R, bias=False), allow_no_samples=True)  # an expert no rank routed to
+    idle.sync_hessian()
+    is_eye = torch.equal(idle.H, torch.eye(C))     # before quantize(): the damping is applied to H in place
+    q = idle.quantize(12)[0]
+    ret[rank] = (h.H.clone(), idle.no_samples, is_eye, q.clone())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_moe_sample_weighted_hessian_and_idle_expert():
+    """Expert Linears see [tokens, C] inputs (batch = tokens, reference gptq.py:86) and a different token count
+    on every rank: the reduced H must be (2/N) sum x x^T over ALL tokens, i.e. the sample-weighted mean of the
+    ranks' Hessians; an expert without any token falls back to H = I on every rank and still quantizes."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_moe, args=(world, 33000 + os.getpid() % 2000, ret), nprocs=world, join=True)
+    torch.manual_seed(0)
+    torch.nn.Linear(256, 32, bias=False)
+    toks = torch.randn(8, 256)
+    want = (2.0 / 8) * toks.double().T @ toks.double()
+    for r in range(world):
+        H, flag, is_eye, q = ret[r]
+        assert (H.double() - want).abs().max() < 1e-5 * want.abs().max()
+        assert flag and is_eye
+    assert torch.equal(ret[0][3], ret[1][3])
+
+
 def test_row_split_plan():
     from gptq_gguf_toolkit_amd.dist_utils import row_slice, row_split_names
     shapes = {"q": (4096, 4096), "k": (1024, 4096), "v": (1024, 4096), "o": (4096, 4096), "gate": (14336, 4096),
