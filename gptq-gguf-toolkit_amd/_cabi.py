@@ -54,6 +54,10 @@ def lib():
         raise GQError(
             f"{SO_PATH} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
             f"g.build()'` (or `make -C {CSRC}`). There is no CPU fallback.")
+    # torch first: its wheel bundles its own libamdhip64, and the library must bind to THAT runtime (the one
+    # that owns the device context and the streams of the tensors it is handed).  Loaded before torch, the
+    # library pulls /opt/rocm's copy in and every call fails with "no ROCm-capable device is detected".
+    import torch  # noqa: F401
     L = ctypes.CDLL(SO_PATH)
     vp, i64, ci, cf, sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
     sp = ctypes.POINTER(Search)
