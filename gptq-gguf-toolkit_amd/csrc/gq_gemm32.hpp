@@ -125,18 +125,7 @@ __device__ __forceinline__ void g32_load_kn_full(float4 (&v)[NV], const float* B
     }
 }
 
-#ifndef GQ_G32_CHAIN_NW
-#define GQ_G32_CHAIN_NW 8
-#endif
-#ifndef GQ_G32C_COMMIT_AT
-#define GQ_G32C_COMMIT_AT 16
-#endif
-#ifndef GQ_G32C_BARRIER_AT
-#define GQ_G32C_BARRIER_AT 26
-#endif
-#ifndef GQ_G32_COMMIT_AT
-#define GQ_G32_COMMIT_AT 24
-#endif
+constexpr int G32_COMMIT_AT = 24;  // k position (of 32) where chunk t+1 is written to LDS: 3/4 through the MFMA block
 template <bool TRANS_B, int MODE, bool LOWER, int KR = 0, int CHAIN = 0, int TS = 128, bool FULL = false, int NW = 4>
 __global__ __launch_bounds__(NW * 64, 2) void gemm32_kernel(float* Cmat, int64_t ldc, const float* A, int64_t lda,
                                                         const float* B, int64_t ldb, int64_t M, int64_t N, int64_t K) {
@@ -231,7 +220,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm32_kernel(float* Cmat, int64_t
         for (int kk = 0; kk < TK; kk += 2) {
             const int cur = (kk >> 1) & 1;
             if (kk + 2 < TK) frag(kk + 2, av[cur ^ 1], bv[cur ^ 1]);
-            if (kk == GQ_G32_COMMIT_AT) {
+            if (kk == G32_COMMIT_AT) {
                 // unconditional, so that the chunk body stays ONE basic block the scheduler can interleave:
                 // past the end the last chunk is fetched again and committed to the buffer nobody reads
                 commit((int)((t + 1) & 1));  // the other buffer: its readers passed the last barrier
@@ -441,7 +430,7 @@ inline int launch_gemm32_chain_full(float* Cmat, int64_t ldc, const float* A, in
 template <bool TRANS_B, int MODE, bool LOWER, int KR, int CHAIN, int TS, bool FULL>
 inline int launch_gemm32_full(float* Cmat, int64_t ldc, const float* A, int64_t lda, const float* B, int64_t ldb, int64_t M,
                             int64_t N, int64_t K, hipStream_t st) {
-    constexpr int NW = (CHAIN != 0 && TS == 128) ? GQ_G32_CHAIN_NW : 4;  // the chained kernel also holds the C tile: 8 waves
+    constexpr int NW = (CHAIN != 0 && TS == 128) ? 8 : 4;  // the chained kernel also holds the C tile: 8 waves
     static bool attr_set = false;
     if (!attr_set) {
         GQ_HIP(hipFuncSetAttribute((const void*)gemm32_kernel<TRANS_B, MODE, LOWER, KR, CHAIN, TS, FULL, NW>,
