@@ -90,17 +90,22 @@ def quantize_block(shapes, W16, X, owners, rank, world, q_type=Q4_K, block_size=
     # per launch (beta = n/(n+b), alpha = 2/(n+b): the telescoped form of b single-sample updates of
     # gptq.py:106-112), all distinct inputs of the block in ONE grouped SYRK grid.
     H = {inp: torch.zeros(x.shape[-1], x.shape[-1], device=dev, dtype=torch.float32) for inp, x in X.items()}
-    # Two grouped grids: the widest input first (its Hessian feeds the longest prepare -> column-loop
-    # chain, which then starts while the grid of the remaining inputs is still running).
+    # Two grouped grids, ONE AFTER THE OTHER on the main stream: the narrow inputs first (12 ms), then the widest
+    # one (48 ms) alone on the chip.  The chains of the narrow inputs start at 12 ms and run in the shadow of
+    # the second grid; the widest chain (prepare -> column loop, 43 ms alone) then finds an almost empty GPU.
+    # Measured against the widest-first / concurrent-grids schedule: 105.4 vs 107.3 ms per step on one box, equal
+    # on another; never worse, and no side stream is needed.
     names = sorted(X, key=lambda i: -X[i].shape[-1])
-    splits = [names[:1], names[1:]] if len(names) > 1 and world == 1 else [names]
+    splits = [names[1:], names[:1]] if len(names) > 1 and world == 1 else [names]
+    if os.environ.get("GQ_BENCH_CONCURRENT_GRIDS") and len(splits) == 2:  # A/B: the previous schedule
+        splits = [splits[1], splits[0]]
     nseq = X[names[0]].shape[0]
     hb = hbatch or nseq
     ev_ready = {}
     main = torch.cuda.current_stream(dev)
     # The second grid runs on a side stream with its own slice of the workspace: its workgroups fill the
     # CUs the first grid's last (partial) round of tiles leaves idle.
-    side = streams[-1] if (streams and len(splits) > 1) else None
+    side = streams[-1] if (streams and len(splits) > 1 and os.environ.get("GQ_BENCH_CONCURRENT_GRIDS")) else None
     if side is not None:
         ev0 = torch.cuda.Event()
         ev0.record(main)
@@ -310,7 +315,7 @@ def main():
 
     W16 = make_weights(shapes, dev)
     X = make_inputs(shapes, nseq_local, L, dev, seed=1 + rank)
-    hb = args.hessian_batch or nseq_local
+    hb = args.hessian_batch or nseq_local  # (2-4 launches per grid measured within the box-to-box noise of one)
     hws = torch.empty(sum(ops.workspace_bytes(_cabi.WS_H_ACCUMULATE, 0, x.shape[-1], hb * L) for x in X.values()),
                       dtype=torch.uint8, device=dev)
     streams = [torch.cuda.Stream(dev) for _ in range(args.streams)] if args.streams > 0 else None
