@@ -41,7 +41,9 @@ sys.path.insert(0, ROOT)
 from gptq_gguf_toolkit_amd import _cabi, dist_utils, ops  # noqa: E402
 
 Q4_K = 12
-SYRK_TRAFFIC_GB_PER_LAUNCH = 73.84  # (125.6 + 22.1) / 2, see profiles/r01_syrk_pmc.txt
+# L2-miss read bytes per SYRK launch of THIS command (rocprofv3 --pmc FETCH_SIZE x 2 KB, profiles/pmc_bench_fetch.sh,
+# profiles/r01_syrk_pmc.txt), by sequences per launch: 64 -> (2 x 11.2 + 2 x 58.2) / 4, 128 -> (22.4 + 113.4) / 2
+SYRK_TRAFFIC_GB_PER_LAUNCH = {64: 34.68, 128: 67.89}
 # Llama-3-8B block: name -> (R, C, input group)
 LLAMA3_8B = {
     "q_proj": (4096, 4096, "attn_in"), "k_proj": (1024, 4096, "attn_in"), "v_proj": (1024, 4096, "attn_in"),
@@ -276,7 +278,7 @@ def main():
     ap.add_argument("--calib-seqs", type=int, default=None)
     ap.add_argument("--seq-len", type=int, default=None)
     ap.add_argument("--hessian-batch", type=int, default=None,
-                    help="sequences folded into H per SYRK launch (default: all local sequences; 1 = reference cadence)")
+                    help="sequences folded into H per SYRK launch (default: 64; 1 = reference cadence)")
     ap.add_argument("--streams", type=int, default=4, help="HIP streams for the independent per-input chains (0: one)")
     ap.add_argument("--row-chunks", type=int, default=1,
                     help="row chunks (side streams) for the column loop of the block's widest Linear")
@@ -315,7 +317,9 @@ def main():
 
     W16 = make_weights(shapes, dev)
     X = make_inputs(shapes, nseq_local, L, dev, seed=1 + rank)
-    hb = args.hessian_batch or nseq_local  # (2-4 launches per grid measured within the box-to-box noise of one)
+    # two SYRK launches per grid (64 sequences = 131072 tokens each): the kernel sustains 3 % more than over one
+    # 262144-token launch on every box tried (1196-1215 vs 1159-1178 TFLOP/s; 32-48 sequences are within noise of 64)
+    hb = args.hessian_batch or min(64, nseq_local)
     hws = torch.empty(sum(ops.workspace_bytes(_cabi.WS_H_ACCUMULATE, 0, x.shape[-1], hb * L) for x in X.values()),
                       dtype=torch.uint8, device=dev)
     streams = [torch.cuda.Stream(dev) for _ in range(args.streams)] if args.streams > 0 else None
@@ -384,9 +388,9 @@ def main():
                 "achieved": round(ach, 2) if ach else None, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_F16_MFMA_TFLOPS, 4) if ach else None,
                 # PMC cannot be read live: L2-miss reads per SYRK launch (rocprofv3 --pmc FETCH_SIZE on this very
-                # command, x2 gfx950 correction; profiles/r01_syrk_pmc.txt), average of the step's two launches
-                "traffic": SYRK_TRAFFIC_GB_PER_LAUNCH if (args.workload == "llama3-8b-block-q4k" and world == 1
-                                                          and not args.calib_seqs and not args.seq_len) else None,
+                # command, x2 gfx950 correction; profiles/r01_syrk_pmc.txt), average of the step's launches
+                "traffic": SYRK_TRAFFIC_GB_PER_LAUNCH.get(hb) if (args.workload == "llama3-8b-block-q4k" and world == 1
+                                                               and not args.calib_seqs and not args.seq_len) else None,
                 "traffic_unit": "GB/launch",
                 "launches": syrk_n, "busy_ms_per_step": round(syrk_ms / args.steps, 3),
                 "avg_launch_ms": round(syrk_sum_ms / max(syrk_n, 1), 4),
