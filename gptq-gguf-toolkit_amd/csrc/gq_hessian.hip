@@ -100,6 +100,11 @@ struct SyrkGroup {
     // row x holds the tiles workgroups with blockIdx % 8 == x (= XCD x) process, in order
     const uint32_t* table;
     int per_xcd;
+    // syrk16_256n_kernel only (nullptr: none): K-split of the tiles of the last, partial round.  aux[i] belongs to
+    // table[i]: 0xffffffff = the whole token range, H updated in the epilogue; else slot << 12 | part << 6 | nparts
+    // = tokens [part, part+1) * T / nparts (in units of 128), raw fp32 sums stored to partial[slot] (256 x 256)
+    const uint32_t* aux;
+    float* partial;
 };
 
 template <bool BF16>
@@ -547,17 +552,26 @@ __global__ __launch_bounds__(512, 2) void syrk16_256n_kernel(const SyrkGroup grp
     for (int slot = (int)(blockIdx.x >> 3); slot < grp.per_xcd; slot += (int)(gridDim.x >> 3)) {
     const uint32_t ent = (uint32_t)__builtin_amdgcn_readfirstlane((int)grp.table[(blockIdx.x & 7) * grp.per_xcd + slot]);
     if (ent == 0xffffffffu) break;
+    const uint32_t aux = grp.aux ? (uint32_t)__builtin_amdgcn_readfirstlane((int)grp.aux[(blockIdx.x & 7) * grp.per_xcd + slot])
+                                 : 0xffffffffu;
     __syncthreads();
     const SyrkProblem& P = grp.p[ent >> 24];
     const int64_t ti = (ent >> 12) & 0xfff, tj = ent & 0xfff;
     const int64_t C = P.C;
-    const int nhs = (int)(P.Tp / SK);          // Tp = T here
+    // token range of this unit, in units of 128 tokens (one turn of the ring): all of them, or part k of n
+    int64_t u0 = 0, u1 = P.Tp / (4 * SK);      // Tp = T here
+    if (aux != 0xffffffffu) {
+        const int64_t np = aux & 63, kp = (aux >> 6) & 63;
+        u0 = kp * u1 / np;
+        u1 = (kp + 1) * (P.Tp / (4 * SK)) / np;
+    }
+    const int nhs = (int)((u1 - u0) * 4);
     const unsigned lds0 = (unsigned)(uintptr_t)smem;
     // ---- DMA: waves 0-3 bring the A image (channels 256 ti ..), waves 4-7 the B image; wave w & 3 owns token rows
     // 8 (w & 3) .. +7 of every half-stage as four 1 KiB pieces of two rows each
     const int op = wid >> 2, rb = 8 * (wid & 3);
-    const char* gsrc = reinterpret_cast<const char*>(P.Xt) + (op ? tj : ti) * 512;
     const int64_t hstride = 32 * C * 2;        // bytes per half-stage
+    const char* gsrc = reinterpret_cast<const char*>(P.Xt) + (op ? tj : ti) * 512 + u0 * 4 * hstride;
     unsigned voff0, voff1, voff2, voff3;
     {
         const int hrow = lane >> 5, s16 = lane & 31;
@@ -761,8 +775,15 @@ __global__ __launch_bounds__(512, 2) void syrk16_256n_kernel(const SyrkGroup grp
     const float beta = P.beta, alpha = P.alpha;
     const int lr = lane & 15, lk = lane >> 4;
     const int64_t i0 = ti * BT + wm * 128 + 4 * lk, j0 = tj * BT + wn * 64 + lr;
+    float* __restrict__ Pp = (aux != 0xffffffffu) ? grp.partial + (size_t)(aux >> 12) * (BT * BT) : nullptr;
+    const int rl0 = wm * 128 + 4 * lk, cl0 = wn * 64 + lr;  // position inside the tile
 #define GQ_NSTORE(c, i, j)                                                                            \
     do {                                                                                              \
+        if (Pp) { /* K-split unit: raw sums, combined in fixed order by syrk_reduce_kernel */          \
+            float* q_ = Pp + (rl0 + (i) * 16) * BT + cl0 + (j) * 16;                                  \
+            q_[0] = c[0]; q_[BT] = c[1]; q_[2 * BT] = c[2]; q_[3 * BT] = c[3];                        \
+            break;                                                                                    \
+        }                                                                                             \
         const int64_t col = j0 + (j) * 16, row = i0 + (i) * 16;                                       \
         float4 h;                                                                                     \
         h.x = beta * H[(row + 0) * C + col] + alpha * c[0];                                           \
@@ -807,6 +828,37 @@ __global__ __launch_bounds__(512, 2) void syrk16_256n_kernel(const SyrkGroup grp
     GQ_NSTORE(c73, 7, 3);
 #undef GQ_NSTORE
     }  // tile loop
+}
+
+// K-split tiles: H tile = beta * H tile + alpha * (P_0 + P_1 + ... + P_{n-1}), partial sums added in index
+// order (deterministic), mirrored below the diagonal.  list[2 i] = tile entry (problem << 24 | ti << 12 | tj),
+// list[2 i + 1] = first slot << 8 | nparts.  Grid (tiles, 16): a block owns 16 rows of a tile.
+__global__ __launch_bounds__(256) void syrk_reduce_kernel(const SyrkGroup grp, const uint32_t* __restrict__ list) {
+    const uint32_t ent = list[2 * blockIdx.x], w = list[2 * blockIdx.x + 1];
+    const SyrkProblem& P = grp.p[ent >> 24];
+    const int64_t ti = (ent >> 12) & 0xfff, tj = ent & 0xfff, C = P.C;
+    const int np = (int)(w & 0xff);
+    const float* __restrict__ part = grp.partial + (size_t)(w >> 8) * (BT * BT);
+    float* __restrict__ H = P.H;
+    const float beta = P.beta, alpha = P.alpha;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int idx = (int)threadIdx.x + q * 256, r = (int)blockIdx.y * 16 + idx / 64, c4 = (idx % 64) * 4;
+        float4 a = *reinterpret_cast<const float4*>(part + r * BT + c4);
+        for (int k = 1; k < np; ++k) {
+            const float4 b = *reinterpret_cast<const float4*>(part + (size_t)k * (BT * BT) + r * BT + c4);
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        float* hp = H + (ti * BT + r) * C + tj * BT + c4;
+        float4 h = *reinterpret_cast<const float4*>(hp);
+        h.x = beta * h.x + alpha * a.x; h.y = beta * h.y + alpha * a.y;
+        h.z = beta * h.z + alpha * a.z; h.w = beta * h.w + alpha * a.w;
+        *reinterpret_cast<float4*>(hp) = h;
+        if (ti != tj) {
+            float* mp = H + (tj * BT + c4) * C + ti * BT + r;
+            mp[0] = h.x; mp[C] = h.y; mp[2 * C] = h.z; mp[3 * C] = h.w;
+        }
+    }
 }
 
 // --------------------------------------------------------------- fp32 SYRK
@@ -888,10 +940,19 @@ static inline bool syrk_in_place(int64_t T, int64_t C) {
     return (C % BT == 0) && (T % (2 * HK) == 0) && getenv("GQ_SYRK_IMAGE") == nullptr && getenv("GQ_SYRK_128") == nullptr;
 }
 
+// K-split of the last (partial) round of tiles (syrk16_256n_kernel): partial-sum slots a problem may need.
+// Only long token ranges are split (every part is at least 8 turns of the ring); GQ_SYRK_NOSPLIT disables it.
+static inline size_t syrk_partial_slots(int64_t T, size_t ntile) {
+    if (T < 8192 || getenv("GQ_SYRK_NOSPLIT")) return 0;
+    return 4 * ntile < 512 ? 4 * ntile : 512;
+}
+
 size_t h_accumulate_workspace_bytes(int64_t T, int64_t C) {
     const size_t nt = (size_t)(C / BT);
-    const size_t table = (nt * (nt + 1) / 2 + 320) * 4 + 256;  // tile table of the 256x256 kernels
-    if (syrk_in_place(T, C)) return table;
+    const size_t ntile = nt * (nt + 1) / 2;
+    // tile table + unit attributes + reduce list of the 256x256 kernels (K-split adds up to 512 units)
+    const size_t table = (ntile + 512 + 320) * 4 * 2 + 512 * 8 + 256;
+    if (syrk_in_place(T, C)) return table + syrk_partial_slots(T, ntile) * (size_t)BT * BT * 4 + 256;
     const int64_t Tp = (T + 2 * HK - 1) / (2 * HK) * (2 * HK);
     return (size_t)C * (size_t)Tp * 2 + 256 + table;
 }
@@ -930,6 +991,10 @@ static int syrk16_launch(int kind, const int* idx, int m, float* const* H, const
     grp.total_tiles = tiles;
     grp.table = nullptr;
     grp.per_xcd = 0;
+    grp.aux = nullptr;
+    grp.partial = nullptr;
+    int n_reduce = 0;
+    const uint32_t* reduce_list = nullptr;
     std::vector<uint32_t> table;
     if (kind) {
         // Balanced schedule: the valid (ti <= tj) tiles of all problems, enumerated super-tile by super-tile
@@ -948,19 +1013,68 @@ static int syrk16_launch(int kind, const int* idx, int m, float* const* H, const
                         if (ti < nt && tj < nt && ti <= tj) all.push_back((uint32_t)k << 24 | (uint32_t)ti << 12 | (uint32_t)tj);
                     }
         }
-        const size_t ngroups = (all.size() + 31) / 32;
-        const int per_xcd = (int)((ngroups + 7) / 8) * 32;
-        table.assign((size_t)8 * per_xcd, 0xffffffffu);
-        for (size_t t = 0; t < all.size(); ++t) {
-            const size_t gi = t >> 5;
-            table[(gi & 7) * per_xcd + (gi >> 3) * 32 + (t & 31)] = all[t];
+        // K-split of the last, partial round (in-place kernel): 1596 tiles of a 14336-wide Hessian are 6.23 rounds
+        // of 256 CUs, and the 7th round would run 60 tiles on 256 CUs for a whole tile time.  The R = N mod 256
+        // tiles left after the full rounds are cut into s token ranges each, s minimising ceil(R s / 256) / s
+        // (14336: s = 4, +0.25 instead of +1 round; 3 x 4096: R = 152, s = 3, +0.67 instead of +1); every unit
+        // stores raw fp32 sums and syrk_reduce_kernel adds them in fixed order (deterministic).
+        const size_t N = all.size(), full = (N / 256) * 256, R = N - full;
+        int sp = 1;
+        size_t cap_units = 0;
+        bool can_split = kind == 2 && R > 0;
+        for (int k = 0; k < m && can_split; ++k) {
+            const size_t slots = syrk_partial_slots(grp.p[k].Tp, (size_t)grp.p[k].nt * (grp.p[k].nt + 1) / 2);
+            if (slots == 0) can_split = false;
+            cap_units += slots;
         }
+        if (cap_units > 512) cap_units = 512;
+        if (can_split) {
+            double best = 1.0;
+            for (int c = 2; c <= 8 && R * c <= cap_units; ++c) {
+                const double cost = (double)((R * c + 255) / 256) / c;
+                if (cost < best - 1e-9) { best = cost; sp = c; }
+            }
+        }
+        std::vector<uint32_t> unit, uaux, rlist;
+        for (size_t t = 0; t < N; ++t) {
+            if (t < full || sp == 1) {
+                unit.push_back(all[t]);
+                uaux.push_back(0xffffffffu);
+            } else {
+                const uint32_t first = (uint32_t)((t - full) * sp);
+                rlist.push_back(all[t]);
+                rlist.push_back(first << 8 | (uint32_t)sp);
+                for (int k = 0; k < sp; ++k) {
+                    unit.push_back(all[t]);
+                    uaux.push_back((first + k) << 12 | (uint32_t)k << 6 | (uint32_t)sp);
+                }
+            }
+        }
+        const size_t ngroups = (unit.size() + 31) / 32;
+        const int per_xcd = (int)((ngroups + 7) / 8) * 32;
+        const size_t tl = (size_t)8 * per_xcd;
+        table.assign(2 * tl + rlist.size(), 0xffffffffu);  // [table | aux | reduce list]
+        for (size_t t = 0; t < unit.size(); ++t) {
+            const size_t gi = t >> 5, pos = (gi & 7) * per_xcd + (gi >> 3) * 32 + (t & 31);
+            table[pos] = unit[t];
+            table[tl + pos] = uaux[t];
+        }
+        for (size_t t = 0; t < rlist.size(); ++t) table[2 * tl + t] = rlist[t];
         wp = reinterpret_cast<unsigned char*>(((uintptr_t)wp + 255) & ~(uintptr_t)255);
         if (wp + table.size() * 4 > ws_end) GQ_FAIL(GQ_E_WORKSPACE, "gq_h_accumulate: workspace too small for the tile table");
         GQ_HIP(hipMemcpyAsync(wp, table.data(), table.size() * 4, hipMemcpyHostToDevice, st));  // pageable: staged before return
         grp.table = reinterpret_cast<const uint32_t*>(wp);
         grp.per_xcd = per_xcd;
+        grp.aux = sp > 1 ? grp.table + tl : nullptr;
         wp += table.size() * 4;
+        if (sp > 1) {
+            wp = reinterpret_cast<unsigned char*>(((uintptr_t)wp + 255) & ~(uintptr_t)255);
+            grp.partial = reinterpret_cast<float*>(wp);
+            wp += R * sp * (size_t)BT * BT * 4;
+            if (wp > ws_end) GQ_FAIL(GQ_E_WORKSPACE, "gq_h_accumulate: workspace too small for the K-split partial sums");
+            n_reduce = (int)R;
+            reduce_list = grp.table + 2 * tl;
+        }
     }
     ProfScope ps(PT_SYRK, st);
     const bool bf = x_dtype == GQ_BF16;
@@ -968,6 +1082,10 @@ static int syrk16_launch(int kind, const int* idx, int m, float* const* H, const
         const dim3 grid((unsigned)(8 * grp.per_xcd)), blk(512);  // one tile per workgroup (fewer would walk the lists)
         if (bf) hipLaunchKernelGGL(syrk16_256n_kernel<true>, grid, blk, S_LDS_BYTES, st, grp);
         else hipLaunchKernelGGL(syrk16_256n_kernel<false>, grid, blk, S_LDS_BYTES, st, grp);
+        if (n_reduce > 0) {
+            GQ_LAUNCH_CHECK();
+            hipLaunchKernelGGL(syrk_reduce_kernel, dim3((unsigned)n_reduce, 16), dim3(256), 0, st, grp, reduce_list);
+        }
     } else if (kind == 1) {
         const dim3 grid((unsigned)(8 * grp.per_xcd)), blk(512);
         if (bf) hipLaunchKernelGGL(syrk16_256e_kernel<true>, grid, blk, S_LDS_BYTES, st, grp);

@@ -367,6 +367,43 @@ def test_group_search_lane_kernel_equals_wide_kernel(ops, q_type, dt):
                            b.view(torch.uint8) if b.dtype != torch.float32 else b.view(torch.int32))
 
 
+@pytest.mark.parametrize("Cs", [(2048,), (4096, 2304, 2048)])
+def test_h_accumulate_k_split_of_the_last_round(ops, Cs):
+    """Long token ranges (T >= 8192): the tiles of the last, partial round of 256 CUs are cut into token ranges
+    whose raw sums are combined by syrk_reduce_kernel in fixed order.  Checked against fp64 on every element of
+    the smallest Hessian and on sampled elements of the others, against the unsplit schedule (GQ_SYRK_NOSPLIT=1,
+    fp32 summation-order tolerance), for exact symmetry, the beta/alpha telescoping and run-to-run determinism."""
+    torch.manual_seed(77)
+    T = 8192 + 384
+    Xs = [(torch.randn(T, C, device="cuda") * torch.exp(torch.randn(C, device="cuda") * 0.5)).half() for C in Cs]
+    H0s = [torch.randn(C, C, device="cuda") for C in Cs]
+    H0s = [h + h.T for h in H0s]
+    outs = []
+    for env in (None, None, "1"):
+        if env:
+            os.environ["GQ_SYRK_NOSPLIT"] = env
+        try:
+            Hs = [h.clone() for h in H0s]
+            ops.h_accumulate_grouped(Hs, Xs, [0.5] * len(Cs), [2.0 / T] * len(Cs))
+            outs.append(Hs)
+        finally:
+            os.environ.pop("GQ_SYRK_NOSPLIT", None)
+    for a, b, c_, X, H0, C in zip(outs[0], outs[1], outs[2], Xs, H0s, Cs):
+        assert torch.equal(a, b)                      # deterministic
+        assert torch.equal(a, a.T)
+        assert (a - c_).abs().max().item() <= 2e-6 * a.abs().max().item()
+        if C == min(Cs):
+            ref = 0.5 * H0.double() + (2.0 / T) * (X.double().T @ X.double())
+            assert (a.double() - ref).abs().max().item() <= 3e-6 * ref.abs().max().item()
+        else:
+            i = torch.randint(0, C, (4096,), device="cuda")
+            j = torch.randint(0, C, (4096,), device="cuda")
+            ref = 0.5 * H0[i, j].double() + (2.0 / T) * (X[:, i].double() * X[:, j].double()).sum(0)
+            assert (a[i, j].double() - ref).abs().max().item() <= 3e-6 * a.abs().max().item()
+    if len(Cs) == 1:
+        assert not torch.equal(outs[0][0], outs[2][0])  # the split schedule really ran (different rounding)
+
+
 def test_h_accumulate_grouped_full_size(ops):
     """BASELINE shapes (C = 14336 and 4096 in one grouped launch, ragged token counts): several rounds of the
     balanced tile table, the partial last round, the mirrored epilogue and the beta/alpha telescoping, checked on
