@@ -1,5 +1,6 @@
+"""SYRK alone on the GPU with and without the K-split of the last round (GQ_SYRK_NOSPLIT=1): C=<width> python profiles/ksplit_probe.py"""
 import os, sys, time, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gptq_gguf_toolkit_amd import ops
 C, T = int(os.environ.get("C", 14336)), 65536
 X = (torch.randn(T, C, device="cuda") * torch.exp(torch.randn(C, device="cuda") * 0.5)).half()
