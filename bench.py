@@ -42,8 +42,8 @@ from gptq_gguf_toolkit_amd import _cabi, dist_utils, ops  # noqa: E402
 
 Q4_K = 12
 # L2-miss read bytes per SYRK launch of THIS command (rocprofv3 --pmc FETCH_SIZE x 2 KB, profiles/pmc_bench_fetch.sh,
-# profiles/r01_syrk_pmc.txt), by sequences per launch: 64 -> (2 x 11.2 + 2 x 58.2) / 4, 128 -> (22.4 + 113.4) / 2
-SYRK_TRAFFIC_GB_PER_LAUNCH = {64: 34.68, 128: 67.89}
+# profiles/r01_syrk_pmc.txt), by sequences per launch: 64 -> (2 x 15.7 + 2 x 60.0) / 4
+SYRK_TRAFFIC_GB_PER_LAUNCH = {64: 37.67}
 # Llama-3-8B block: name -> (R, C, input group)
 LLAMA3_8B = {
     "q_proj": (4096, 4096, "attn_in"), "k_proj": (1024, 4096, "attn_in"), "v_proj": (1024, 4096, "attn_in"),
@@ -93,8 +93,7 @@ def quantize_block(shapes, W16, X, owners, rank, world, q_type=Q4_K, block_size=
     # gptq.py:106-112), all distinct inputs of the block in ONE grouped SYRK grid.
     H = {inp: torch.zeros(x.shape[-1], x.shape[-1], device=dev, dtype=torch.float32) for inp, x in X.items()}
     # Two grouped grids, ONE AFTER THE OTHER on the main stream: the narrow inputs first (12 ms), then the widest
-    # one (48 ms) alone on the chip.  The chains of the narrow inputs start at 12 ms and run in the shadow of
-    # the second grid; the widest chain (prepare -> column loop, 43 ms alone) then finds an almost empty GPU.
+    # one (43 ms) alone on the chip; then the four chains (prepare -> column loop) on their streams.
     # Measured against the widest-first / concurrent-grids schedule: 105.4 vs 107.3 ms per step on one box, equal
     # on another; never worse, and no side stream is needed.
     names = sorted(X, key=lambda i: -X[i].shape[-1])
@@ -128,6 +127,12 @@ def quantize_block(shapes, W16, X, owners, rank, world, q_type=Q4_K, block_size=
         ev = torch.cuda.Event()
         ev.record(st)
         for i in grp:
+            ev_ready[i] = ev
+    if world == 1 and not os.environ.get("GQ_BENCH_CONCURRENT_GRIDS"):
+        # every chain starts after BOTH grids: a resident SYRK grid (one 128 KiB-LDS, 8-wave workgroup per CU) leaves
+        # the chains of the narrow inputs nothing but the gaps between its tiles anyway, and without them in its
+        # way the SYRK sustains 1.24 instead of 1.22 PFLOP/s (step 104.5 vs 104.9 ms on the same box)
+        for i in ev_ready:
             ev_ready[i] = ev
     if world > 1:  # widest first: its chain is the critical one and starts as soon as ITS Hessian is reduced
         for inp in names:
