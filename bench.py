@@ -136,7 +136,7 @@ def quantize_block(shapes, W16, X, owners, rank, world, q_type=Q4_K, block_size=
             ev_ready[i] = ev
     if world > 1:  # widest first: its chain is the critical one and starts as soon as ITS Hessian is reduced
         for inp in names:
-            dist.all_reduce(H[inp], op=dist.ReduceOp.AVG)  # RCCL over xGMI
+            dist_utils.allreduce_hessian(H[inp])  # RCCL over xGMI, upper-triangular tiles only
             ev = torch.cuda.Event()
             ev.record(main)
             ev_ready[inp] = ev

@@ -15,7 +15,7 @@ F32, F16, BF16 = 0, 1, 2
 WS_H_ACCUMULATE, WS_H_PREPARE, WS_GPTQ_QUANTIZE = 1, 2, 3
 
 EXPORTS = (
-    "gq_abi_version", "gq_last_error", "gq_type_info", "gq_workspace_bytes", "gq_h_accumulate", "gq_h_accumulate_grouped", "gq_h_prepare", "gq_w_prepare",
+    "gq_abi_version", "gq_last_error", "gq_type_info", "gq_workspace_bytes", "gq_h_accumulate", "gq_h_accumulate_grouped", "gq_h_prepare", "gq_w_prepare", "gq_h_pack_upper", "gq_h_unpack_upper",
     "gq_scale_search", "gq_group_search", "gq_gptq_quantize", "gq_gptq_quantize_perm", "gq_rtn_quantize", "gq_dequantize", "gq_pack", "gq_trailing_update",
     "gq_prof_enable", "gq_prof_ntags", "gq_prof_name", "gq_prof_collect", "gq_prof_collect2",
 )
@@ -70,6 +70,8 @@ def lib():
     L.gq_h_accumulate_grouped.argtypes = [ci, vp, vp, vp, vp, vp, vp, ci, vp, sz, vp]
     L.gq_h_prepare.argtypes = [vp, vp, i64, i64, cf, vp, vp, vp, vp, sz, vp]
     L.gq_w_prepare.argtypes = [vp, vp, i64, i64, vp, vp]
+    L.gq_h_pack_upper.argtypes = [vp, i64, vp, vp]
+    L.gq_h_unpack_upper.argtypes = [vp, i64, vp, vp]
     L.gq_scale_search.argtypes = [vp, i64, i64, ci, sp, vp, i64, vp, i64, vp, i64, vp, i64, vp]
     L.gq_group_search.argtypes = [vp, ci, i64, i64, ci, sp, vp, vp, vp, vp, vp, vp, vp]
     L.gq_gptq_quantize.argtypes = [vp, vp, i64, i64, ci, ci, ci, sp, vp, vp, vp, vp, vp, vp, sz, vp]

@@ -28,6 +28,8 @@ int h_accumulate_grouped(int, float* const*, const void* const*, const int64_t*,
 size_t h_prepare_workspace_bytes(int64_t, int64_t);
 int h_prepare(float*, float*, int64_t, int64_t, float, float*, int*, uint8_t*, void*, size_t, hipStream_t);
 int w_prepare(const uint8_t*, float*, int64_t, int64_t, int*, hipStream_t);
+int h_pack_upper(const float*, int64_t, float*, hipStream_t);
+int h_unpack_upper(const float*, int64_t, float*, hipStream_t);
 }  // namespace gq
 
 #include <algorithm>
@@ -107,6 +109,9 @@ int gq_h_prepare(float* H, float* W, int64_t R, int64_t C, float rel_damp, float
 int gq_w_prepare(const uint8_t* col_flags, float* W, int64_t R, int64_t C, int* mismatch, void* stream) {
     return w_prepare(col_flags, W, R, C, mismatch, (hipStream_t)stream);
 }
+
+int gq_h_pack_upper(const float* H, int64_t C, float* buf, void* stream) { return h_pack_upper(H, C, buf, (hipStream_t)stream); }
+int gq_h_unpack_upper(const float* buf, int64_t C, float* H, void* stream) { return h_unpack_upper(buf, C, H, (hipStream_t)stream); }
 
 int gq_scale_search(const float* x, int64_t rows, int64_t ld, int q_type, const gq_search_t* p, uint16_t* d,
                     int64_t d_stride, uint8_t* s, int64_t s_ld, uint16_t* dmin, int64_t dmin_stride, uint8_t* m,

@@ -1099,6 +1099,62 @@ static int syrk16_launch(int kind, const int* idx, int m, float* const* H, const
     return GQ_OK;
 }
 
+// ---- the one collective of the path (reference gptq.py:131-132) moves the upper triangle only ----
+// H is exactly symmetric, so the all-reduce needs (nt (nt + 1) / 2) 128 x 128 tiles instead of nt^2: pack copies the
+// tiles ti <= tj into a contiguous buffer (row-major over the triangle), unpack writes them back and mirrors them
+// below the diagonal -- half the bytes on the xGMI links, and the result is symmetric bit for bit on every rank
+// whatever order the ring reduces in.
+__global__ __launch_bounds__(256) void h_pack_upper_kernel(const float* __restrict__ H, int64_t C, float* __restrict__ buf) {
+    const int64_t nt = C / HT;
+    int64_t ti, tj;
+    tri_tile(blockIdx.x, nt, ti, tj);
+    const float* src = H + ti * HT * C + tj * HT;
+    float* dst = buf + (size_t)blockIdx.x * (HT * HT);
+#pragma unroll 4
+    for (int idx = threadIdx.x; idx < HT * HT / 4; idx += 256) {
+        const int r = idx / (HT / 4), c4 = (idx % (HT / 4)) * 4;
+        *reinterpret_cast<float4*>(dst + r * HT + c4) = *reinterpret_cast<const float4*>(src + r * C + c4);
+    }
+}
+__global__ __launch_bounds__(256) void h_unpack_upper_kernel(const float* __restrict__ buf, int64_t C, float* __restrict__ H) {
+    __shared__ float tile[HT][HT + 1];
+    const int64_t nt = C / HT;
+    int64_t ti, tj;
+    tri_tile(blockIdx.x, nt, ti, tj);
+    const float* src = buf + (size_t)blockIdx.x * (HT * HT);
+    float* dst = H + ti * HT * C + tj * HT;
+    for (int idx = threadIdx.x; idx < HT * HT / 4; idx += 256) {
+        const int r = idx / (HT / 4), c4 = (idx % (HT / 4)) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(src + r * HT + c4);
+        *reinterpret_cast<float4*>(dst + r * C + c4) = v;
+        tile[r][c4] = v.x; tile[r][c4 + 1] = v.y; tile[r][c4 + 2] = v.z; tile[r][c4 + 3] = v.w;
+    }
+    if (ti == tj) return;  // a diagonal tile is symmetric itself (mirrored SYRK epilogue, elementwise reduction)
+    __syncthreads();
+    float* mir = H + tj * HT * C + ti * HT;
+    for (int idx = threadIdx.x; idx < HT * HT / 4; idx += 256) {
+        const int r = idx / (HT / 4), c4 = (idx % (HT / 4)) * 4;  // row r of the mirrored tile = column r of the tile
+        *reinterpret_cast<float4*>(mir + r * C + c4) = make_float4(tile[c4][r], tile[c4 + 1][r], tile[c4 + 2][r], tile[c4 + 3][r]);
+    }
+}
+
+int h_pack_upper(const float* H, int64_t C, float* buf, hipStream_t st) {
+    if (!H || !buf) GQ_FAIL(GQ_E_NULL, "gq_h_pack_upper: null pointer");
+    if (C <= 0 || (C % HT)) GQ_FAIL(GQ_E_BAD_SHAPE, "gq_h_pack_upper: C=%ld (C %% 128 != 0)", (long)C);
+    const int64_t nt = C / HT;
+    hipLaunchKernelGGL(h_pack_upper_kernel, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(256), 0, st, H, C, buf);
+    GQ_LAUNCH_CHECK();
+    return GQ_OK;
+}
+int h_unpack_upper(const float* buf, int64_t C, float* H, hipStream_t st) {
+    if (!H || !buf) GQ_FAIL(GQ_E_NULL, "gq_h_unpack_upper: null pointer");
+    if (C <= 0 || (C % HT)) GQ_FAIL(GQ_E_BAD_SHAPE, "gq_h_unpack_upper: C=%ld (C %% 128 != 0)", (long)C);
+    const int64_t nt = C / HT;
+    hipLaunchKernelGGL(h_unpack_upper_kernel, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(256), 0, st, buf, C, H);
+    GQ_LAUNCH_CHECK();
+    return GQ_OK;
+}
+
 int h_accumulate_grouped(int n, float* const* H, const void* const* X, const int64_t* T, const int64_t* C,
                          const float* beta, const float* alpha, int x_dtype, void* ws, size_t ws_bytes,
                          hipStream_t st) {

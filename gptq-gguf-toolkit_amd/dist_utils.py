@@ -50,20 +50,32 @@ def allreduce_hessian(H, num_samples=None):
     num_samples is None)."""
     if not (is_dist_available_and_initialized() and get_world_size() > 1):
         return num_samples
-    if num_samples is None:
-        dist.all_reduce(H, op=dist.ReduceOp.AVG)
-        return None
     import torch
-    counts = torch.zeros(get_world_size(), dtype=torch.float64, device=H.device)
-    counts[get_rank()] = float(num_samples)
-    dist.all_reduce(counts, op=dist.ReduceOp.SUM)
-    total = float(counts.sum().item())
-    if bool((counts == counts[0]).all()):
-        dist.all_reduce(H, op=dist.ReduceOp.AVG)
-    elif total > 0:
-        H.mul_(float(num_samples) / total)
-        dist.all_reduce(H, op=dist.ReduceOp.SUM)
-    return int(total)
+    # H is exactly symmetric: only its upper 128x128 tiles travel (gq_h_pack_upper / gq_h_unpack_upper), half the
+    # bytes on the xGMI links, and the reduced H is symmetric bit for bit on every rank
+    packed = H.is_cuda and H.dtype == torch.float32 and H.is_contiguous() and H.shape[0] % 128 == 0 \
+        and H.shape[0] >= 1024 and os.environ.get("GQ_ALLREDUCE_FULL") is None
+    if packed:
+        from . import ops
+        payload = ops.h_pack_upper(H)
+    else:
+        payload = H
+    total = None
+    if num_samples is None:
+        dist.all_reduce(payload, op=dist.ReduceOp.AVG)
+    else:
+        counts = torch.zeros(get_world_size(), dtype=torch.float64, device=H.device)
+        counts[get_rank()] = float(num_samples)
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+        total = int(counts.sum().item())
+        if bool((counts == counts[0]).all()):
+            dist.all_reduce(payload, op=dist.ReduceOp.AVG)
+        elif total > 0:
+            payload.mul_(float(num_samples) / total)
+            dist.all_reduce(payload, op=dist.ReduceOp.SUM)
+    if packed:
+        ops.h_unpack_upper(payload, H)
+    return total
 
 
 def assign_owners(costs: Dict[str, float], world_size: int) -> Dict[str, int]:

@@ -117,6 +117,26 @@ def w_prepare(col_flags: torch.Tensor, W: torch.Tensor) -> torch.Tensor:
     return mm
 
 
+def h_pack_upper(H: torch.Tensor) -> torch.Tensor:
+    """The 128x128 tiles of H on and above the diagonal as one contiguous fp32 buffer (the all-reduce payload)."""
+    _need_cuda(H)
+    C = H.shape[0]
+    assert H.dtype == torch.float32 and H.is_contiguous() and H.shape == (C, C) and C % 128 == 0
+    nt = C // 128
+    buf = torch.empty(nt * (nt + 1) // 2, 128, 128, dtype=torch.float32, device=H.device)
+    check(lib().gq_h_pack_upper(_ptr(H), C, _ptr(buf), _stream(H)), "gq_h_pack_upper")
+    return buf
+
+
+def h_unpack_upper(buf: torch.Tensor, H: torch.Tensor) -> torch.Tensor:
+    """Inverse of h_pack_upper: writes the tiles back into H and mirrors them below the diagonal."""
+    _need_cuda(buf, H)
+    C = H.shape[0]
+    assert H.dtype == torch.float32 and H.is_contiguous() and buf.dtype == torch.float32 and buf.is_contiguous()
+    check(lib().gq_h_unpack_upper(_ptr(buf), C, _ptr(H), _stream(H)), "gq_h_unpack_upper")
+    return H
+
+
 def scale_search(x: torch.Tensor, q_type: int, rmin=-1.0, rdelta=0.1, nstep=20):
     """get_scale_and_zero on x[rows,256] (row stride free).  Returns (d f16[rows], s[rows,ng], dmin f16[rows], m)."""
     _need_cuda(x)

@@ -110,6 +110,14 @@ int gq_h_prepare(float* H, float* W, int64_t R, int64_t C, float rel_damp, float
    leader's U is exactly the U the reference would compute for this Linear. */
 int gq_w_prepare(const uint8_t* col_flags, float* W, int64_t R, int64_t C, int* mismatch, void* stream);
 
+/* The payload of the path's one collective (gptq.py:131-132, all_reduce of H): H is exactly symmetric, so only
+   the 128x128 tiles on and above the diagonal travel.  gq_h_pack_upper copies them into buf
+   (fp32 [nt (nt+1)/2][128][128], tiles row-major over the upper triangle, nt = C/128; C % 128 == 0);
+   gq_h_unpack_upper writes a reduced buf back into H and mirrors it below the diagonal.  The caller
+   all-reduces buf in between (RCCL): half the bytes of reducing H itself. */
+int gq_h_pack_upper(const float* H, int64_t C, float* buf, void* stream);
+int gq_h_unpack_upper(const float* buf, int64_t C, float* H, void* stream);
+
 /* replaces quant_utils.py:90-145 (Quantizer.get_scale_and_zero) incl.
    make_k_quants :199-274 / make_quants :147-197, on one [rows,256] panel with row
    stride ld (elements).  d/dmin element r at d[r*d_stride]; s/m row r at s + r*s_ld. */

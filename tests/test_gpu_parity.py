@@ -404,6 +404,27 @@ def test_h_accumulate_k_split_of_the_last_round(ops, Cs):
         assert not torch.equal(outs[0][0], outs[2][0])  # the split schedule really ran (different rounding)
 
 
+@pytest.mark.parametrize("C", [128, 1280, 4096])
+def test_h_pack_unpack_upper(ops, C):
+    """The all-reduce payload: pack(H) holds every 128x128 tile on or above the diagonal exactly once; unpack
+    restores a symmetric H bit for bit and mirrors whatever the (reduced) buffer holds below the diagonal."""
+    torch.manual_seed(C)
+    A = torch.randn(C, C, device="cuda")
+    H = A + A.T
+    buf = ops.h_pack_upper(H)
+    nt = C // 128
+    assert buf.shape == (nt * (nt + 1) // 2, 128, 128)
+    tiles = H.view(nt, 128, nt, 128).permute(0, 2, 1, 3)
+    got = sorted(float(t.double().sum()) for t in buf)
+    want = sorted(float(tiles[i, j].double().sum()) for i in range(nt) for j in range(i, nt))
+    assert got == want
+    H2 = torch.full_like(H, float("nan"))
+    ops.h_unpack_upper(buf, H2)
+    assert torch.equal(H2, H)
+    ops.h_unpack_upper(buf * 0.5, H2)   # what a collective would hand back
+    assert torch.equal(H2, 0.5 * H) and torch.equal(H2, H2.T)
+
+
 def test_h_accumulate_grouped_full_size(ops):
     """BASELINE shapes (C = 14336 and 4096 in one grouped launch, ragged token counts): several rounds of the
     balanced tile table, the partial last round, the mirrored epilogue and the beta/alpha telescoping, checked on
