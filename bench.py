@@ -42,8 +42,8 @@ from gptq_gguf_toolkit_amd import _cabi, dist_utils, ops  # noqa: E402
 
 Q4_K = 12
 # L2-miss read bytes per SYRK launch of THIS command (rocprofv3 --pmc FETCH_SIZE x 2 KB, profiles/pmc_bench_fetch.sh,
-# profiles/r01_syrk_pmc.txt), by sequences per launch: 64 -> (2 x 15.7 + 2 x 60.0) / 4
-SYRK_TRAFFIC_GB_PER_LAUNCH = {64: 37.67}
+# profiles/r01_syrk_pmc.txt), by sequences per launch: 32 -> (4 x 7.9 + 4 x 33.7) / 8, 64 -> (2 x 15.7 + 2 x 60.0) / 4
+SYRK_TRAFFIC_GB_PER_LAUNCH = {32: 20.68, 64: 37.67}
 # Llama-3-8B block: name -> (R, C, input group)
 LLAMA3_8B = {
     "q_proj": (4096, 4096, "attn_in"), "k_proj": (1024, 4096, "attn_in"), "v_proj": (1024, 4096, "attn_in"),
@@ -283,7 +283,7 @@ def main():
     ap.add_argument("--calib-seqs", type=int, default=None)
     ap.add_argument("--seq-len", type=int, default=None)
     ap.add_argument("--hessian-batch", type=int, default=None,
-                    help="sequences folded into H per SYRK launch (default: 64; 1 = reference cadence)")
+                    help="sequences folded into H per SYRK launch (default: 32; 1 = reference cadence)")
     ap.add_argument("--streams", type=int, default=4, help="HIP streams for the independent per-input chains (0: one)")
     ap.add_argument("--row-chunks", type=int, default=1,
                     help="row chunks (side streams) for the column loop of the block's widest Linear")
@@ -322,9 +322,10 @@ def main():
 
     W16 = make_weights(shapes, dev)
     X = make_inputs(shapes, nseq_local, L, dev, seed=1 + rank)
-    # two SYRK launches per grid (64 sequences = 131072 tokens each): the kernel sustains 3 % more than over one
-    # 262144-token launch on every box tried (1196-1215 vs 1159-1178 TFLOP/s; 32-48 sequences are within noise of 64)
-    hb = args.hessian_batch or min(64, nseq_local)
+    # four SYRK launches per grid (32 sequences = 65536 tokens each): the kernel sustains more over short token
+    # ranges (same box, TFLOP/s of the SYRK in this bench: 128 seq/launch 1236-1252, 64: 1267, 43: 1278, 32: 1280-1291,
+    # 21-24: 1281-1297, 16: 1266-1280 -- below 32 the extra read-modify-write of H and the launches eat the gain)
+    hb = args.hessian_batch or min(32, nseq_local)
     hws = torch.empty(sum(ops.workspace_bytes(_cabi.WS_H_ACCUMULATE, 0, x.shape[-1], hb * L) for x in X.values()),
                       dtype=torch.uint8, device=dev)
     streams = [torch.cuda.Stream(dev) for _ in range(args.streams)] if args.streams > 0 else None

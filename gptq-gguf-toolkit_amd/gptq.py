@@ -53,7 +53,7 @@ class GPTQ:
         self._ws = None
         # activations are buffered (288 GB of HBM per GPU) and folded into H in long-K SYRK launches:
         # b samples at once give beta = n/(n+b), alpha = 2/(n+b), the telescoped form of b single updates
-        self.flush_tokens = 1 << 17
+        self.flush_tokens = 1 << 16    # 65536 tokens per SYRK launch: the sweet spot measured in bench.py
         self._buf = None
         self._fill = 0
         self._buf_b = 0
