@@ -17,7 +17,8 @@ from torch.nn.modules.conv import _ConvNd
 
 from . import dist_utils, model_utils
 from . import ops as _ops
-from .quant_utils import GGML_QUANT_SIZES, GGMLQuantizationType, _check_scale
+from .quant_utils import (GGML_QUANT_SIZES, GGMLQuantizationType, QuantizationScale, _check_scale,
+                          check_mse_equivalent)
 
 
 class GPTQ:
@@ -179,6 +180,10 @@ class GPTQ:
         if q_type == GGMLQuantizationType.Q3_K:  # reference gptq.py:204-206 mutates the handle
             self.act_order = False
             self.static_groups = False
+        if self.quant_scale is QuantizationScale.MSE:
+            # the lazy scale search sees error-compensated weights: keep a factor 4 between the original weights
+            # and the value at which the reference's MSE branch stops being the absmax search
+            check_mse_equivalent(q_type, float(self.W.max().item()), margin=4.0)
         if self.act_order:
             return self._compute_act_order(q_type)
         U = self._prepare()

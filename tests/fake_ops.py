@@ -70,6 +70,11 @@ def dequantize(q_type, q, d, s, dmin, m, out_dtype=torch.float32):
     return torch.from_numpy(w).to(out_dtype)
 
 
+def scale_search(x, q_type, rmin=-1.0, rdelta=0.1, nstep=20):
+    d, s, dmin, m = O.scale_search(x.numpy(), q_type, rmin, rdelta, nstep)
+    return _f16(d), torch.from_numpy(s), _f16(dmin), torch.from_numpy(m)
+
+
 def install(monkeypatch=None):
     """Point the host modules at this backend (they normally call the HIP library)."""
     import sys

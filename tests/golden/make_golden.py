@@ -445,6 +445,30 @@ MIXED = {"q_proj": "Q3_K", "k_proj": "Q2_K", "v_proj": "Q4_K", "o_proj": "Q5_K",
          "down_proj": "Q3_K", "up_proj": "Q4_K", "embed_tokens": "Q6_K", "lm_head": "Q6_K"}  # README.md:94-106
 
 
+def g12_mse_scale():
+    """make_quants with quant_scale="mse" (quant_utils.py:164-191).  The grid search divides by
+    scale1.clamp_min(1e-9).round() (:180): for every group whose absmax scale is <= 0.5 that divisor is 0, all 81
+    candidates quantize to q_int = 0 with the same loss, and the first one (alpha = 1, the absmax scale) is kept --
+    the branch returns exactly the absmax result.  Recorded: weight-like panels (N(0, 0.02^2), N(0, 0.3^2), edge
+    rows) for Q3_K / Q6_K, outputs of get_scale_and_zero in both modes, plus one wide panel (sigma = 30) where
+    the branch really differs."""
+    out = {}
+    set_sqrt("ieee")
+    for qt in (T.Q3_K, T.Q6_K):
+        for tag, sigma in (("w", 0.02), ("mid", 0.3), ("wide", 30.0)):
+            torch.manual_seed(1200 + int(qt))
+            x = torch.randn(64, 256) * sigma
+            if tag == "w":
+                x[:10] = edge_rows(x[:10].reshape(-1, 16).clone(), 16)[:160].reshape(10, 256)
+            out[f"{qt.name}_{tag}_x"] = x.numpy()
+            for mode in ("absmax", "mse"):
+                q, bits, G = configured(qt, quant_scale=ref_qu.QuantizationScale(mode))
+                d, s, dmin, m = q.get_scale_and_zero(x.clone(), qt)
+                out[f"{qt.name}_{tag}_{mode}_d"] = d.view(torch.int16).numpy().view(np.uint16)
+                out[f"{qt.name}_{tag}_{mode}_s"] = s.numpy()
+    save("g12_mse_scale", **out)
+
+
 def g10_driver():
     import tempfile
     set_sqrt("ieee")
@@ -478,5 +502,7 @@ if __name__ == "__main__":
         g10_driver()
     elif "g11" in sys.argv[1:]:
         g11_act_order()
+    elif "g12" in sys.argv[1:]:
+        g12_mse_scale()
     else:
         _main_all()

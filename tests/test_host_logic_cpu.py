@@ -38,6 +38,29 @@ def test_quant_config_rules(tmp_path):
         (1e-2, 128, "Q4_K", -1.0, 0.1, 20, "absmax")
 
 
+def test_quant_scale_mse_is_absmax_in_the_weight_regime(monkeypatch):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import fake_ops
+    fake_ops.install()
+    from gptq_gguf_toolkit_amd.quant_utils import GGML_QUANT_SIZES, GGMLQuantizationType, Quantizer
+    torch.manual_seed(3)
+    x = torch.randn(32, 256) * 0.05
+    for qt in (GGMLQuantizationType.Q3_K, GGMLQuantizationType.Q6_K, GGMLQuantizationType.Q4_K):
+        bits, _, smq, G, SG, sdt, _ = GGML_QUANT_SIZES[qt]
+        outs = []
+        for mode in ("absmax", "mse"):
+            q = Quantizer()
+            q.configure(bits, smq, G, sdt, SG, quant_scale=mode)
+            outs.append(q.get_scale_and_zero(x.clone(), qt))
+        assert all(torch.equal(a, b) for a, b in zip(*outs))
+    q = Quantizer()
+    bits, _, smq, G, SG, sdt, _ = GGML_QUANT_SIZES[GGMLQuantizationType.Q3_K]
+    q.configure(bits, smq, G, sdt, SG, quant_scale="mse")
+    with pytest.raises(NotImplementedError, match="mse"):
+        q.get_scale_and_zero(x * 100.0, GGMLQuantizationType.Q3_K)   # 4.0 or more: the reference's branch differs
+    q.get_scale_and_zero(x * 100.0, GGMLQuantizationType.Q4_K)        # make_k_quants ignores quant_scale
+
+
 def test_sharding_and_owner_assignment():
     from gptq_gguf_toolkit_amd.dist_utils import assign_owners, shard_calibration
     data = list(range(11))

@@ -65,6 +65,22 @@ def test_g1_search_params(oracle):
     assert bits_eq(sc, g["Q4_K_nstep0_scale"]) and bits_eq(ze, g["Q4_K_nstep0_zero"])
 
 
+@pytest.mark.parametrize("name", ["Q3_K", "Q6_K"])
+def test_g12_mse_branch_equals_absmax_for_weights(oracle, name):
+    """--quant_scale mse (quant_utils.py:164-191): the reference's own outputs in both modes.  For weight-like
+    panels (every value below zero = (maxq+1)/2) the MSE grid search returns the absmax result bit for bit, which
+    is what the build computes; the wide panel shows the regime that is refused (NotImplementedError)."""
+    g = load_golden("g12_mse_scale")
+    for tag in ("w", "mid"):
+        assert np.array_equal(g[f"{name}_{tag}_mse_d"], g[f"{name}_{tag}_absmax_d"])
+        assert np.array_equal(g[f"{name}_{tag}_mse_s"], g[f"{name}_{tag}_absmax_s"])
+        d, s, dmin, m = oracle.scale_search(g[f"{name}_{tag}_x"], TYPES[name])
+        assert np.array_equal(d, g[f"{name}_{tag}_mse_d"]) and np.array_equal(s, g[f"{name}_{tag}_mse_s"])
+        assert float(g[f"{name}_{tag}_x"].max()) < (4.0 if name == "Q3_K" else 32.0)
+    assert not np.array_equal(g[f"{name}_wide_mse_s"], g[f"{name}_wide_absmax_s"])
+    assert float(g[f"{name}_wide_x"].max()) >= (4.0 if name == "Q3_K" else 32.0)
+
+
 @pytest.mark.parametrize("name", list(TYPES))
 def test_g2_scale_search(oracle, name):
     g = load_golden("g2_scale_search")
