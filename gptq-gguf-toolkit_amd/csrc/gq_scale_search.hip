@@ -64,12 +64,24 @@ __device__ __forceinline__ float group_max8(float v) {
 }
 
 // Group reductions for LPG lanes per group (8: the DPP forms above; 1: the whole group in one lane).
-// Element e of a group lives on lane e % LPG as local element e / LPG, and feeds ATen accumulator
-// e % 8 == local accumulator (e / LPG) % NA with NA = 8 / LPG, so both mappings add in the same order.
+// LPG = 8: element e of a group lives on lane e % 8 (one accumulator per lane).  LPG = 2: the 16-byte chunk c of the
+// group lives on lane c % 2, so the even lane owns ATen accumulators 0-3 and the odd lane 4-7.  LPG = 1: everything
+// in one lane.  In every mapping local element k feeds local accumulator k % NA (NA = 8 / LPG) in increasing order
+// of e, and the eight accumulators are summed 0 -> 7: the same additions in the same order.
 template <int LPG, int NA>
 __device__ __forceinline__ float group_sum(const float (&acc)[NA]) {
     if constexpr (LPG == 8) {
         return group_sum8(acc[0]);
+    } else if constexpr (LPG == 2) {
+        // lane pair: the even lane owns accumulators 0-3, the odd lane 4-7.  ((((a0+a1)+a2)+a3)+a4)+..+a7: the even
+        // lane's partial travels to the odd lane, which adds its four in order; the total travels back.
+        float t = acc[0];
+#pragma unroll
+        for (int j = 1; j < NA; ++j) t = t + acc[j];
+        float u = dpp_f<0xA0>(t, t);  // quad_perm [0,0,2,2]: the even lane's partial on both lanes
+#pragma unroll
+        for (int j = 0; j < NA; ++j) u = u + acc[j];
+        return dpp_f<0xF5>(u, u);     // quad_perm [1,1,3,3]: the odd lane's total on both lanes
     } else {
         float s = acc[0];
 #pragma unroll
@@ -80,12 +92,18 @@ __device__ __forceinline__ float group_sum(const float (&acc)[NA]) {
 template <int LPG>
 __device__ __forceinline__ float group_min(float v) {
     if constexpr (LPG == 8) return group_min8(v);
-    else return v;
+    else if constexpr (LPG == 2) {
+        const float t = dpp_f<0xB1>(v, v);  // quad_perm [1,0,3,2]: the partner lane
+        return t < v ? t : v;
+    } else return v;
 }
 template <int LPG>
 __device__ __forceinline__ float group_max(float v) {
     if constexpr (LPG == 8) return group_max8(v);
-    else return v;
+    else if constexpr (LPG == 2) {
+        const float t = dpp_f<0xB1>(v, v);
+        return t > v ? t : v;
+    } else return v;
 }
 // acc[k % NA] (+)= term, first touch assigns
 #define GQ_ACC(acc, k, term)                       \
@@ -321,59 +339,63 @@ __global__ __launch_bounds__(256) void scale_search_kernel(
 // 64/NG row-panels.  Same arithmetic in the same order as the kernel above (see group_sum), but no
 // cross-lane reductions and the per-group scalar algebra is done once instead of on 8 lanes: about
 // half the VALU work per group.  Rows are read with 16-B loads (the launcher checks alignment).
-template <int GSZ, int BITS, bool KSEARCH, bool SIGNED, int SMQ, int RM>
+template <int GSZ, int BITS, bool KSEARCH, bool SIGNED, int SMQ, int RM, int LPG>
 __global__ __launch_bounds__(64) void scale_search_lane_kernel(
     const void* __restrict__ x, int64_t rows, int64_t ld, SearchParams sp,
     uint16_t* __restrict__ d, int64_t d_stride, uint8_t* __restrict__ s, int64_t s_ld,
     uint16_t* __restrict__ dmin, int64_t dmin_stride, uint8_t* __restrict__ m, int64_t m_ld,
     float* __restrict__ gs_out, float* __restrict__ gz_out) {
-    constexpr int NG = 256 / GSZ;  // lanes per row
-    constexpr int RPW = 64 / NG;   // rows per wave
+    static_assert(LPG == 1 || LPG == 2, "one lane or a lane pair per group");
+    constexpr int NG = 256 / GSZ;        // groups per row
+    constexpr int LPR = NG * LPG;        // lanes per row
+    constexpr int RPW = 64 / LPR;        // rows per wave
+    constexpr int NS = GSZ / LPG;        // values per lane
     const int lane = threadIdx.x;
-    const int row_l = lane / NG;
-    const int g = lane % NG;
+    const int row_l = lane / LPR;
+    const int g = (lane % LPR) / LPG;
+    const int h = lane % LPG;            // which 16-byte chunks of the group: c % LPG == h
     const int64_t row = (int64_t)blockIdx.x * RPW + row_l;
     const bool live = row < rows;
     const int64_t base = (live ? row : 0) * ld + g * GSZ;
-    float xv[GSZ];
+    float xv[NS];
     if constexpr (RM == 0) {
         const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(x) + base);
 #pragma unroll
-        for (int k = 0; k < GSZ / 4; ++k) {
-            float4 v = p[k];
+        for (int k = 0; k < NS / 4; ++k) {
+            float4 v = p[k * LPG + h];
             xv[4 * k] = v.x; xv[4 * k + 1] = v.y; xv[4 * k + 2] = v.z; xv[4 * k + 3] = v.w;
         }
     } else {
-        const uint4* p = reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(x) + base);
+        const uint2* p = reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(x) + base);
 #pragma unroll
-        for (int k = 0; k < GSZ / 8; ++k) {
-            uint4 v = p[k];
-            const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+        for (int k = 0; k < NS / 4; ++k) {  // chunks of four 16-bit values
+            uint2 v = p[k * LPG + h];
+            const uint32_t u[2] = {v.x, v.y};
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
+            for (int t = 0; t < 2; ++t) {
                 uint16_t lo = (uint16_t)(u[t] & 0xffffu), hi = (uint16_t)(u[t] >> 16);
-                xv[8 * k + 2 * t] = RM == 1 ? h2f(lo) : bf2f(lo);
-                xv[8 * k + 2 * t + 1] = RM == 1 ? h2f(hi) : bf2f(hi);
+                xv[4 * k + 2 * t] = RM == 1 ? h2f(lo) : bf2f(lo);
+                xv[4 * k + 2 * t + 1] = RM == 1 ? h2f(hi) : bf2f(hi);
             }
         }
     }
 
     float gscale, gzero;
-    if constexpr (KSEARCH) k_search<GSZ, BITS, RM, 1>(xv, sp, gscale, gzero);
-    else absmax_search<GSZ, BITS, RM, 1>(xv, gscale, gzero);
-    if (gs_out && live) {  // make_k_quants / make_quants outputs (gq_group_search)
+    if constexpr (KSEARCH) k_search<NS, BITS, RM, LPG>(xv, sp, gscale, gzero);
+    else absmax_search<NS, BITS, RM, LPG>(xv, gscale, gzero);
+    if (gs_out && live && h == 0) {  // make_k_quants / make_quants outputs (gq_group_search)
         gs_out[row * NG + g] = gscale;
         gz_out[row * NG + g] = gzero;
     }
-    // quant_utils.py:121-143: row maxima over the NG lanes of the row
+    // quant_utils.py:121-143: row maxima over the lanes of the row
     float max_scale = gscale, max_zero = gzero;
 #pragma unroll
-    for (int o = 1; o < NG; o <<= 1) {
+    for (int o = LPG; o < LPR; o <<= 1) {
         float a = __shfl_xor(max_scale, o), b = __shfl_xor(max_zero, o);
         max_scale = a > max_scale ? a : max_scale;
         max_zero = b > max_zero ? b : max_zero;
     }
-    if (live) {
+    if (live && h == 0) {
         constexpr float smq = (float)SMQ;
         float inv_scale = max_scale > 0.0f ? R<RM>(R<RM>(1.0f / max_scale) * smq) : 0.0f;  // :128
         float inv_zero = max_zero > 0.0f ? R<RM>(R<RM>(1.0f / max_zero) * smq) : 0.0f;     // :129
@@ -401,24 +423,32 @@ static int launch_ss(const void* x, int64_t rows, int64_t ld, int q_type, const 
     const double rmin = p ? p->rmin : -1.0, rdelta = p ? p->rdelta : 0.1;
     const double maxq = (double)((1 << ti.bits) - 1);
     for (int i = 0; i < 24; ++i) sp.num[i] = (float)(rmin + rdelta * (double)i + maxq);
-    // lane-per-group kernel when the rows can be read with 16-B loads and there are enough groups to put a
-    // wave on half the SIMDs (>= 512 waves): it does half the VALU work per group, but one wave takes ~35 us
-    // whatever the size, against ~17 us for a small launch of the 8-lanes-per-group kernel (measured,
-    // profiles/ss_probe.py).  GQ_SS_WIDE=1 / 0 forces the wide / lane kernel (A/B measurements, parity test).
+    // Three mappings with identical arithmetic (profiles/ss_probe.py): one lane per group does half the VALU work
+    // of the 8-lane kernel but a wave takes ~35 us whatever the size -- used from one wave per SIMD up
+    // (rows * groups >= 65536); a lane PAIR per group halves that latency at +12 % work -- the middle range, where the
+    // launch is latency-bound (a 4096-row Q4_K panel: 1024 waves, one per SIMD: 23 us against 36 / 31 us for the other
+    // two; rows * groups >= 16384); 8 lanes per group for small
+    // panels and rows that cannot be read with 16-byte (8-byte for 16-bit inputs) loads.
+    // GQ_SS_WIDE=1 / 0 / 2 forces the 8-lane / 1-lane / 2-lane kernel (A/B measurements, parity test).
     const size_t esz = RM == 0 ? 4 : 2;
     const bool aligned = (reinterpret_cast<uintptr_t>(x) % 16 == 0) && ((size_t)ld * esz) % 16 == 0;
     const char* wide_env = getenv("GQ_SS_WIDE");
-    bool lane_kernel = aligned && rows * (256 / ti.group) >= 32768;
-    if (wide_env && wide_env[0] == '1') lane_kernel = false;
-    if (wide_env && wide_env[0] == '0') lane_kernel = aligned;
-    const int rpw = lane_kernel ? (64 / (256 / ti.group)) : (ti.group == 32 ? 4 : 2);
-    dim3 grid((unsigned)((rows + rpw - 1) / rpw)), block(lane_kernel ? 64 : 256);
+    const int64_t ngroups = rows * (256 / ti.group);
+    int lpg = !aligned ? 8 : (ngroups >= 65536 ? 1 : (ngroups >= 16384 ? 2 : 8));
+    if (wide_env && wide_env[0] == '1') lpg = 8;
+    if (wide_env && wide_env[0] == '0' && aligned) lpg = 1;
+    if (wide_env && wide_env[0] == '2' && aligned) lpg = 2;
+    const int rpw = lpg == 8 ? (ti.group == 32 ? 4 : 2) : 64 / ((256 / ti.group) * lpg);
+    dim3 grid((unsigned)((rows + rpw - 1) / rpw)), block(lpg == 8 ? 256 : 64);
     ProfScope ps(PT_SCALE_SEARCH, st);
 #define GQ_SS(G, B, K, S, Q)                                                                                       \
     do {                                                                                                           \
-        if (lane_kernel)                                                                                           \
-            hipLaunchKernelGGL((scale_search_lane_kernel<G, B, K, S, Q, RM>), grid, block, 0, st, x, rows, ld, sp, \
-                               d, d_stride, s, s_ld, dmin, dmin_stride, m, m_ld, gs_out, gz_out);                  \
+        if (lpg == 1)                                                                                              \
+            hipLaunchKernelGGL((scale_search_lane_kernel<G, B, K, S, Q, RM, 1>), grid, block, 0, st, x, rows, ld,  \
+                               sp, d, d_stride, s, s_ld, dmin, dmin_stride, m, m_ld, gs_out, gz_out);              \
+        else if (lpg == 2)                                                                                         \
+            hipLaunchKernelGGL((scale_search_lane_kernel<G, B, K, S, Q, RM, 2>), grid, block, 0, st, x, rows, ld,  \
+                               sp, d, d_stride, s, s_ld, dmin, dmin_stride, m, m_ld, gs_out, gz_out);              \
         else                                                                                                       \
             hipLaunchKernelGGL((scale_search_kernel<G, B, K, S, Q, RM>), grid, block, 0, st, x, rows, ld, sp, d,   \
                                d_stride, s, s_ld, dmin, dmin_stride, m, m_ld, gs_out, gz_out);                     \

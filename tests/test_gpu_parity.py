@@ -333,7 +333,7 @@ def test_h_accumulate_natural_layout_equals_relayout(ops, dt):
 @pytest.mark.parametrize("dt", [torch.float32, torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("q_type", [10, 11, 12, 13, 14])
 def test_group_search_lane_kernel_equals_wide_kernel(ops, q_type, dt):
-    """The lane-per-group search kernel (GQ_SS_WIDE=0; default for large panels) and the 8-lanes-per-group kernel (GQ_SS_WIDE=1, also the
+    """The lane-per-group search kernel (GQ_SS_WIDE=0; default for large panels), the lane-pair kernel (2; mid-size panels) and the 8-lanes-per-group kernel (1, also the
     fallback for rows that are not 16-B aligned) add in the same order: every output is bit-identical, on ragged
     row counts, constant groups, all-zero rows and a misaligned view (which takes the wide kernel by itself)."""
     torch.manual_seed(31 + q_type)
@@ -345,15 +345,16 @@ def test_group_search_lane_kernel_equals_wide_kernel(ops, q_type, dt):
     x[8, 40:72] = x[8, 40:72].abs()
     x = x.to(dt)
     outs = []
-    for env in ("0", "1"):
+    for env in ("0", "1", "2"):   # one lane / eight lanes / a lane pair per group
         os.environ["GQ_SS_WIDE"] = env
         try:
             outs.append(ops.group_search(x, q_type))
         finally:
             os.environ.pop("GQ_SS_WIDE", None)
-    for a, b in zip(*outs):
-        assert torch.equal(a.view(torch.uint8) if a.dtype != torch.float32 else a.view(torch.int32),
-                           b.view(torch.uint8) if b.dtype != torch.float32 else b.view(torch.int32))
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert torch.equal(a.view(torch.uint8) if a.dtype != torch.float32 else a.view(torch.int32),
+                               b.view(torch.uint8) if b.dtype != torch.float32 else b.view(torch.int32))
     # misaligned rows: a view that starts one element into a wider buffer
     buf = torch.zeros(rows, 264, device="cuda", dtype=dt)
     buf[:, 1:257] = x
