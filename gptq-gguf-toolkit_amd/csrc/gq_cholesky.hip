@@ -77,6 +77,70 @@ __global__ __launch_bounds__(256) void w_prepare_kernel(float* __restrict__ W, i
     }
 }
 
+// 16-byte variants of the two column scans (C % 4 == 0, 16-byte aligned W): a workgroup owns 64 columns as 16
+// float4 lanes x 16 row lanes and keeps 8 rows per thread in flight -- 32 KB per workgroup instead of 1 KB, which
+// is what a column scan with only C/64 workgroups needs to approach HBM speed (14336 x 4096: 712 -> ~150 us).
+__global__ __launch_bounds__(256) void col_flags4_kernel(const float* __restrict__ H, const float* __restrict__ W,
+                                                         int64_t R, int64_t C, uint8_t* __restrict__ dead,
+                                                         uint8_t* __restrict__ zc) {
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int64_t j = (int64_t)blockIdx.x * 64 + 4 * tx;
+    __shared__ int nz[16][64];
+    int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    if (j < C) {
+#pragma unroll 8
+        for (int64_t r = ty; r < R; r += 16) {
+            const float4 v = *reinterpret_cast<const float4*>(W + r * C + j);
+            a0 |= (v.x != 0.0f); a1 |= (v.y != 0.0f); a2 |= (v.z != 0.0f); a3 |= (v.w != 0.0f);
+        }
+    }
+    nz[ty][4 * tx] = a0; nz[ty][4 * tx + 1] = a1; nz[ty][4 * tx + 2] = a2; nz[ty][4 * tx + 3] = a3;
+    __syncthreads();
+    const int64_t jc = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (threadIdx.x < 64 && jc < C) {
+        int a = 0;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) a |= nz[t][threadIdx.x];
+        const uint8_t dd = H[jc * C + jc] == 0.0f;
+        dead[jc] = dd;
+        zc[jc] = dd || !a;
+    }
+}
+__global__ __launch_bounds__(256) void w_prepare4_kernel(float* __restrict__ W, int64_t R, int64_t C,
+                                                         const uint8_t* __restrict__ dead,
+                                                         const uint8_t* __restrict__ zc, int* __restrict__ mismatch) {
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int64_t j = (int64_t)blockIdx.x * 64 + 4 * tx;
+    __shared__ int nz[16][64];
+    int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    if (j < C) {
+        const bool d0 = dead[j], d1 = dead[j + 1], d2 = dead[j + 2], d3 = dead[j + 3];
+        const bool anyd = d0 | d1 | d2 | d3;
+#pragma unroll 8
+        for (int64_t r = ty; r < R; r += 16) {
+            float4 v = *reinterpret_cast<const float4*>(W + r * C + j);
+            if (anyd) {  // gptq.py:141
+                if (d0) v.x = 0.0f;
+                if (d1) v.y = 0.0f;
+                if (d2) v.z = 0.0f;
+                if (d3) v.w = 0.0f;
+                *reinterpret_cast<float4*>(W + r * C + j) = v;
+            }
+            a0 |= (v.x != 0.0f); a1 |= (v.y != 0.0f); a2 |= (v.z != 0.0f); a3 |= (v.w != 0.0f);
+        }
+    }
+    nz[ty][4 * tx] = a0; nz[ty][4 * tx + 1] = a1; nz[ty][4 * tx + 2] = a2; nz[ty][4 * tx + 3] = a3;
+    __syncthreads();
+    const int64_t jc = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (threadIdx.x < 64 && jc < C) {
+        int a = 0;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) a |= nz[t][threadIdx.x];
+        const uint8_t mine = dead[jc] || !a;
+        if (mine != zc[jc]) atomicOr(mismatch, 1);
+    }
+}
+
 // H[zc,:] = 0; H[:,zc] = 0; H[zc,zc] = 1  (gptq.py:311-313; also covers H[dead,dead]=1, :135)
 __global__ __launch_bounds__(256) void mask_h_kernel(float* __restrict__ H, int64_t C, const uint8_t* __restrict__ zc) {
     const int64_t total = C * C;
@@ -470,8 +534,12 @@ int w_prepare(const uint8_t* flags, float* W, int64_t R, int64_t C, int* mismatc
     if (R <= 0 || C <= 0) GQ_FAIL(GQ_E_BAD_SHAPE, "gq_w_prepare: R=%ld C=%ld", (long)R, (long)C);
     GQ_HIP(hipMemsetAsync(mismatch, 0, sizeof(int), st));
     ProfScope ps(PT_PREP_ELEM, st);
-    hipLaunchKernelGGL(w_prepare_kernel, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, st, W, R, C, flags, flags + C,
-                       mismatch);
+    if (C % 4 == 0 && (uintptr_t)W % 16 == 0)
+        hipLaunchKernelGGL(w_prepare4_kernel, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, st, W, R, C, flags, flags + C,
+                           mismatch);
+    else
+        hipLaunchKernelGGL(w_prepare_kernel, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, st, W, R, C, flags, flags + C,
+                           mismatch);
     GQ_LAUNCH_CHECK();
     return GQ_OK;
 }
@@ -492,7 +560,10 @@ int h_prepare(float* H, float* W, int64_t R, int64_t C, float rel_damp, float* U
     GQ_HIP(hipMemsetAsync(not_invertible, 0, sizeof(int), st));
     {
     ProfScope ps(PT_PREP_ELEM, st);
-    hipLaunchKernelGGL(col_flags_kernel, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, st, H, W, R, C, dead, zc);
+    if ((uintptr_t)W % 16 == 0)  // C % 128 == 0 here
+        hipLaunchKernelGGL(col_flags4_kernel, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, st, H, W, R, C, dead, zc);
+    else
+        hipLaunchKernelGGL(col_flags_kernel, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, st, H, W, R, C, dead, zc);
     GQ_LAUNCH_CHECK();
     hipLaunchKernelGGL(zero_dead_cols_kernel, dim3(2048), dim3(256), 0, st, W, R, C, dead);
     GQ_LAUNCH_CHECK();
