@@ -45,11 +45,14 @@ __global__ __launch_bounds__(256) void col_flags_kernel(const float* __restrict_
     }
 }
 
+// One workgroup per 64 columns: nothing but the 64 flags is touched when none of them is dead (the usual case).
 __global__ __launch_bounds__(256) void zero_dead_cols_kernel(float* __restrict__ W, int64_t R, int64_t C,
                                                              const uint8_t* __restrict__ dead) {
-    const int64_t total = R * C;
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x)
-        if (dead[t % C]) W[t] = 0.0f;  // gptq.py:141
+    const int64_t j = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+    const bool dd = j < C && dead[j];
+    if (!__syncthreads_or(dd)) return;
+    if (dd)
+        for (int64_t r = threadIdx.x >> 6; r < R; r += 4) W[r * C + j] = 0.0f;  // gptq.py:141
 }
 
 // Follower of a shared Hessian: apply the leader's dead-channel set to this W and compare this
@@ -143,10 +146,20 @@ __global__ __launch_bounds__(256) void w_prepare4_kernel(float* __restrict__ W, 
 
 // H[zc,:] = 0; H[:,zc] = 0; H[zc,zc] = 1  (gptq.py:311-313; also covers H[dead,dead]=1, :135)
 __global__ __launch_bounds__(256) void mask_h_kernel(float* __restrict__ H, int64_t C, const uint8_t* __restrict__ zc) {
-    const int64_t total = C * C;
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t i = t / C, j = t % C;
-        if (zc[i] || zc[j]) H[t] = (i == j) ? 1.0f : 0.0f;
+    // workgroup b owns the indices 64 b .. 64 b + 63: for every flagged one it clears row and column and sets the
+    // diagonal to 1.  Without flags (the usual case) a workgroup reads its 64 flags and returns.
+    __shared__ int flagged[64];
+    const int64_t i0 = (int64_t)blockIdx.x * 64;
+    if (threadIdx.x < 64) flagged[threadIdx.x] = (i0 + threadIdx.x < C) && zc[i0 + threadIdx.x];
+    __syncthreads();
+    for (int t = 0; t < 64; ++t) {
+        if (!flagged[t]) continue;  // workgroup-uniform
+        const int64_t i = i0 + t;
+        for (int64_t j = threadIdx.x; j < C; j += blockDim.x) {
+            const float v = (i == j) ? 1.0f : 0.0f;
+            H[i * C + j] = v;
+            H[j * C + i] = v;
+        }
     }
 }
 
@@ -565,10 +578,10 @@ int h_prepare(float* H, float* W, int64_t R, int64_t C, float rel_damp, float* U
     else
         hipLaunchKernelGGL(col_flags_kernel, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, st, H, W, R, C, dead, zc);
     GQ_LAUNCH_CHECK();
-    hipLaunchKernelGGL(zero_dead_cols_kernel, dim3(2048), dim3(256), 0, st, W, R, C, dead);
+    hipLaunchKernelGGL(zero_dead_cols_kernel, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, st, W, R, C, dead);
     GQ_LAUNCH_CHECK();
     if (col_flags_out) GQ_HIP(hipMemcpyAsync(col_flags_out, dead, 2 * (size_t)C, hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL(mask_h_kernel, dim3(4096), dim3(256), 0, st, H, C, zc);
+    hipLaunchKernelGGL(mask_h_kernel, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, st, H, C, zc);
     GQ_LAUNCH_CHECK();
     hipLaunchKernelGGL(damp_kernel, dim3(1), dim3(1024), 0, st, H, C, rel_damp);
     GQ_LAUNCH_CHECK();
