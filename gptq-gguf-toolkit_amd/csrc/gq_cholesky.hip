@@ -328,6 +328,139 @@ __device__ __forceinline__ float rdlane(float v, int l) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }
 
+// ---- 32x32 factor + inverse in registers (wave 0 of diag_blk_kernel): lane i holds row i of the block in a[0..31].
+// Every update needs a broadcast L[c][j] = lane c's a[j]: v_readlane into an SGPR, then one VALU op.  Written as
+// inline-asm batches of four (4 v_readlane, then 4 v_fma that each read an SGPR written >= 3 instructions earlier: no
+// wait states): left to the compiler the 496 broadcasts of the factor loop are kept alive for the inverse loop, which
+// needs the same values, and the SGPR file spills into VGPR lanes (v_writelane + s_nop per element: ~9 cycles per
+// instruction measured, 23k cycles per 32x32 sub-block).
+template <int C>
+__device__ __forceinline__ void d_upd4(float (&a)[32], float aj) {  // a[C..C+3] -= aj * L[C..C+3][j]
+    int t0, t1, t2, t3;
+    asm volatile(
+        "v_readlane_b32 %4, %8, %9\n\tv_readlane_b32 %5, %8, %10\n\tv_readlane_b32 %6, %8, %11\n\t"
+        "v_readlane_b32 %7, %8, %12\n\t"
+        "v_fma_f32 %0, -%8, %4, %0\n\tv_fma_f32 %1, -%8, %5, %1\n\tv_fma_f32 %2, -%8, %6, %2\n\tv_fma_f32 %3, -%8, %7, %3"
+        : "+v"(a[C]), "+v"(a[C + 1]), "+v"(a[C + 2]), "+v"(a[C + 3]), "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3)
+        : "v"(aj), "n"(C), "n"(C + 1), "n"(C + 2), "n"(C + 3));
+}
+template <int C>
+__device__ __forceinline__ void d_upd8(float (&a)[32], float aj) {  // a[C..C+7] -= aj * L[C..C+7][j]
+    int t0, t1, t2, t3, t4, t5, t6, t7;
+    asm volatile(
+        "v_readlane_b32 %8, %16, %17\n\tv_readlane_b32 %9, %16, %18\n\tv_readlane_b32 %10, %16, %19\n\t"
+        "v_readlane_b32 %11, %16, %20\n\tv_readlane_b32 %12, %16, %21\n\tv_readlane_b32 %13, %16, %22\n\t"
+        "v_readlane_b32 %14, %16, %23\n\tv_readlane_b32 %15, %16, %24\n\t"
+        "v_fma_f32 %0, -%16, %8, %0\n\tv_fma_f32 %1, -%16, %9, %1\n\tv_fma_f32 %2, -%16, %10, %2\n\t"
+        "v_fma_f32 %3, -%16, %11, %3\n\tv_fma_f32 %4, -%16, %12, %4\n\tv_fma_f32 %5, -%16, %13, %5\n\t"
+        "v_fma_f32 %6, -%16, %14, %6\n\tv_fma_f32 %7, -%16, %15, %7"
+        : "+v"(a[C]), "+v"(a[C + 1]), "+v"(a[C + 2]), "+v"(a[C + 3]), "+v"(a[C + 4]), "+v"(a[C + 5]), "+v"(a[C + 6]),
+          "+v"(a[C + 7]), "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4), "=&s"(t5), "=&s"(t6), "=&s"(t7)
+        : "v"(aj), "n"(C), "n"(C + 1), "n"(C + 2), "n"(C + 3), "n"(C + 4), "n"(C + 5), "n"(C + 6), "n"(C + 7));
+}
+template <int C>
+__device__ __forceinline__ void d_upd1(float (&a)[32], float aj) {
+    int t0;
+    asm volatile("v_readlane_b32 %1, %2, %3\n\ts_nop 1\n\tv_fma_f32 %0, -%2, %1, %0" : "+v"(a[C]), "=&s"(t0) : "v"(aj), "n"(C));
+}
+template <int C>
+__device__ __forceinline__ void d_updates(float (&a)[32], float aj) {  // columns C..31
+    if constexpr (C + 7 <= 31) {
+        d_upd8<C>(a, aj);
+        d_updates<C + 8>(a, aj);
+    } else if constexpr (C + 3 <= 31) {
+        d_upd4<C>(a, aj);
+        d_updates<C + 4>(a, aj);
+    } else if constexpr (C <= 31) {
+        d_upd1<C>(a, aj);
+        d_updates<C + 1>(a, aj);
+    }
+}
+template <int J>
+__device__ __forceinline__ void d_factor(float (&a)[32], int i, float& myinv, bool& bad) {
+    asm volatile("s_nop 1" : "+v"(a[J]));  // a[J] may be the last VGPR written inside the previous step's asm
+    float pj = rdlane(a[J], J);
+    if (!(pj > 0.0f)) {  // wave-uniform; also NaN
+        bad = true;
+        pj = 1.0f;
+    }
+    // 1/sqrt by v_rsq_f32 + one Newton step (<= 2 ulp) instead of an IEEE sqrt and an IEEE division: the 128
+    // pivots of a block are a serial chain, ~35 dependent instructions shorter each this way.  U is a
+    // tolerance-class output: the pivot itself carries the rounding of a 14336-term sum.
+    float inv = __builtin_amdgcn_rsqf(pj);
+    inv = fmaf(inv, fmaf(-0.5f * pj * inv, inv, 0.5f), inv);
+    const float ljj = pj * inv;
+    // (lane == J) masks are loop-invariant: the compiler would precompute all 64 of them, run out of SGPRs and
+    // spill them into VGPR lanes; an opaque copy of the lane index makes it compare in place (one v_cmp)
+    int ii = i;
+    asm volatile("" : "+v"(ii));
+    const bool mine = ii == J;
+    if (mine) myinv = inv;
+    a[J] = mine ? ljj : a[J] * inv;
+    // the asm below starts with a v_readlane of the VGPR the VALU has just written: the compiler's hazard
+    // recogniser cannot see into the asm text (measured: wrong pivots without these wait states)
+    asm volatile("s_nop 1" : "+v"(a[J]));
+    d_updates<J + 1>(a, a[J]);
+    if constexpr (J < 31) d_factor<J + 1>(a, i, myinv, bad);
+}
+// acc[k] += L[R][P+k] * x[P+k]: four independent chains (the dot product of row R of L with the inverse column)
+template <int R, int P>
+__device__ __forceinline__ void d_dot4(const float (&a)[32], const float (&x)[32], float (&acc)[4]) {
+    int t0, t1, t2, t3;
+    asm volatile(
+        "v_readlane_b32 %4, %8, %16\n\tv_readlane_b32 %5, %9, %16\n\tv_readlane_b32 %6, %10, %16\n\t"
+        "v_readlane_b32 %7, %11, %16\n\t"
+        "v_fma_f32 %0, %4, %12, %0\n\tv_fma_f32 %1, %5, %13, %1\n\tv_fma_f32 %2, %6, %14, %2\n\tv_fma_f32 %3, %7, %15, %3"
+        : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3)
+        : "v"(a[P]), "v"(a[P + 1]), "v"(a[P + 2]), "v"(a[P + 3]), "v"(x[P]), "v"(x[P + 1]), "v"(x[P + 2]), "v"(x[P + 3]),
+          "n"(R));
+}
+template <int R, int P>
+__device__ __forceinline__ void d_dot8(const float (&a)[32], const float (&x)[32], float (&acc)[4]) {
+    int t0, t1, t2, t3, t4, t5, t6, t7;
+    asm volatile(
+        "v_readlane_b32 %4, %12, %28\n\tv_readlane_b32 %5, %13, %28\n\tv_readlane_b32 %6, %14, %28\n\t"
+        "v_readlane_b32 %7, %15, %28\n\tv_readlane_b32 %8, %16, %28\n\tv_readlane_b32 %9, %17, %28\n\t"
+        "v_readlane_b32 %10, %18, %28\n\tv_readlane_b32 %11, %19, %28\n\t"
+        "v_fma_f32 %0, %4, %20, %0\n\tv_fma_f32 %1, %5, %21, %1\n\tv_fma_f32 %2, %6, %22, %2\n\t"
+        "v_fma_f32 %3, %7, %23, %3\n\tv_fma_f32 %0, %8, %24, %0\n\tv_fma_f32 %1, %9, %25, %1\n\t"
+        "v_fma_f32 %2, %10, %26, %2\n\tv_fma_f32 %3, %11, %27, %3"
+        : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4),
+          "=&s"(t5), "=&s"(t6), "=&s"(t7)
+        : "v"(a[P]), "v"(a[P + 1]), "v"(a[P + 2]), "v"(a[P + 3]), "v"(a[P + 4]), "v"(a[P + 5]), "v"(a[P + 6]), "v"(a[P + 7]),
+          "v"(x[P]), "v"(x[P + 1]), "v"(x[P + 2]), "v"(x[P + 3]), "v"(x[P + 4]), "v"(x[P + 5]), "v"(x[P + 6]), "v"(x[P + 7]),
+          "n"(R));
+}
+template <int R, int P>
+__device__ __forceinline__ void d_dot1(const float (&a)[32], const float (&x)[32], float& acc) {
+    int t0;
+    asm volatile("v_readlane_b32 %1, %2, %4\n\ts_nop 1\n\tv_fma_f32 %0, %1, %3, %0" : "+v"(acc), "=&s"(t0) : "v"(a[P]), "v"(x[P]), "n"(R));
+}
+template <int R, int P>
+__device__ __forceinline__ void d_dot(const float (&a)[32], const float (&x)[32], float (&acc)[4]) {  // p = P..R-1
+    if constexpr (P + 7 < R) {
+        d_dot8<R, P>(a, x, acc);
+        d_dot<R, P + 8>(a, x, acc);
+    } else if constexpr (P + 3 < R) {
+        d_dot4<R, P>(a, x, acc);
+        d_dot<R, P + 4>(a, x, acc);
+    } else if constexpr (P < R) {
+        d_dot1<R, P>(a, x, acc[P & 3]);
+        d_dot<R, P + 1>(a, x, acc);
+    }
+}
+template <int R>
+__device__ __forceinline__ void d_inverse(const float (&a)[32], float (&x)[32], int i, float myinv) {  // lane i = column i
+    const float irr = rdlane(myinv, R);
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    d_dot<R, 0>(a, x, acc);
+    const float dot = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    int ii = i;
+    asm volatile("" : "+v"(ii));
+    x[R] = (R < ii) ? 0.0f : ((R == ii) ? irr : -dot * irr);
+    if constexpr (R < 31) d_inverse<R + 1>(a, x, i, myinv);
+}
+
 // C[32x32] (accumulator) = sum_k Arow[i][k] * Brow[j][k], k < 32*nk32: both operands row-major in LDS
 // (lane (i = l&31, kh = l>>5) reads A[i][2p+kh] and B[j=l&31][2p+kh]); strides in floats.
 __device__ __forceinline__ f32x16 mfma_nt_32(const float* Ap, int lda_, const float* Bp, int ldb_, int lane) {
@@ -375,37 +508,14 @@ __global__ __launch_bounds__(256) void diag_blk_kernel(float* __restrict__ A, in
 #pragma unroll
             for (int c = 0; c < 32; ++c) a[c] = S[(c0 + i) * LDQ + c0 + c];
             bool bad = false;
-#pragma unroll
-            for (int j = 0; j < 32; ++j) {
-                float pj = rdlane(a[j], j);
-                if (!(pj > 0.0f)) {  // wave-uniform; also NaN
-                    bad = true;
-                    pj = 1.0f;
-                }
-                // 1/sqrt by v_rsq_f32 + one Newton step (<= 2 ulp) instead of an IEEE sqrt and an IEEE division:
-                // the 128 pivots of a block are a serial chain, ~35 dependent instructions shorter each this way.
-                // U is a tolerance-class output: the pivot itself carries the rounding of a
-                // 14336-term sum.
-                float inv = __builtin_amdgcn_rsqf(pj);
-                inv = fmaf(inv, fmaf(-0.5f * pj * inv, inv, 0.5f), inv);
-                const float ljj = pj * inv;
-                if (i == j) myinv = inv;
-                a[j] = (i == j) ? ljj : a[j] * inv;
-#pragma unroll
-                for (int c = j + 1; c < 32; ++c) a[c] = fmaf(-a[j], rdlane(a[j], c), a[c]);
-            }
-#pragma unroll
-            for (int r = 0; r < 32; ++r) {  // lane i = column i of the inverse
-                const float irr = rdlane(myinv, r);
-                float acc = 0.0f;
-#pragma unroll
-                for (int p = 0; p < r; ++p) acc = fmaf(rdlane(a[p], r), x[p], acc);
-                x[r] = (r < i) ? 0.0f : ((r == i) ? irr : -acc * irr);
-            }
+            d_factor<0>(a, i, myinv, bad);
+            d_inverse<0>(a, x, i, myinv);
             if (lane < 32) {
 #pragma unroll
                 for (int c = 0; c < 32; ++c) {
-                    S[(c0 + i) * LDQ + c0 + c] = (c <= i) ? a[c] : 0.0f;
+                    int ii = i;  // opaque: no 32 precomputed (c <= lane) masks spilled into VGPR lanes
+                    asm volatile("" : "+v"(ii));
+                    S[(c0 + i) * LDQ + c0 + c] = (c <= ii) ? a[c] : 0.0f;
                     X[(c0 + c) * LDQ + c0 + i] = x[c];
                 }
                 if (bad && lane == 0) *flag = 1;
