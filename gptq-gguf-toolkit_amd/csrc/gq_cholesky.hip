@@ -487,14 +487,23 @@ __global__ __launch_bounds__(256) void diag_blk_kernel(float* __restrict__ A, in
     float* X = smem + NB * LDQ;   // [NB][LDQ]  L^-1 (lower), zeros above
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     float* Tw = X + NB * LDQ + wid * 32 * TQ;  // wave-private scratch tile
-    for (int idx = tid; idx < NB * NB / 4; idx += 256) {  // 16-byte global accesses (lda % 4 == 0)
-        const int r = idx / (NB / 4), c = (idx % (NB / 4)) * 4;
-        const float4 v = *reinterpret_cast<const float4*>(A + r * lda + c);
-        S[r * LDQ + c + 0] = (c + 0 <= r) ? v.x : 0.0f;
-        S[r * LDQ + c + 1] = (c + 1 <= r) ? v.y : 0.0f;
-        S[r * LDQ + c + 2] = (c + 2 <= r) ? v.z : 0.0f;
-        S[r * LDQ + c + 3] = (c + 3 <= r) ? v.w : 0.0f;
-        X[r * LDQ + c + 0] = 0.0f; X[r * LDQ + c + 1] = 0.0f; X[r * LDQ + c + 2] = 0.0f; X[r * LDQ + c + 3] = 0.0f;
+    {   // 16-byte global accesses (lda % 4 == 0).  All 16 loads of a thread are issued before the first LDS write
+        // (one memory latency instead of several); chunks entirely above the diagonal are not read at all.
+        float4 v[NB * NB / 4 / 256];
+#pragma unroll
+        for (int q = 0; q < NB * NB / 4 / 256; ++q) {
+            const int idx = tid + q * 256, r = idx / (NB / 4), c = (idx % (NB / 4)) * 4;
+            v[q] = (c <= r) ? *reinterpret_cast<const float4*>(A + r * lda + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int q = 0; q < NB * NB / 4 / 256; ++q) {
+            const int idx = tid + q * 256, r = idx / (NB / 4), c = (idx % (NB / 4)) * 4;
+            S[r * LDQ + c + 0] = (c + 0 <= r) ? v[q].x : 0.0f;
+            S[r * LDQ + c + 1] = (c + 1 <= r) ? v[q].y : 0.0f;
+            S[r * LDQ + c + 2] = (c + 2 <= r) ? v[q].z : 0.0f;
+            S[r * LDQ + c + 3] = (c + 3 <= r) ? v[q].w : 0.0f;
+            X[r * LDQ + c + 0] = 0.0f; X[r * LDQ + c + 1] = 0.0f; X[r * LDQ + c + 2] = 0.0f; X[r * LDQ + c + 3] = 0.0f;
+        }
     }
     __syncthreads();
     const int lc = lane & 31, lh = lane >> 5;  // MFMA D layout: col = lc, row = (e&3) + 8*(e>>2) + 4*lh
@@ -595,6 +604,7 @@ __global__ __launch_bounds__(256) void diag_blk_kernel(float* __restrict__ A, in
         const int r = idx / (NB / 4), c = (idx % (NB / 4)) * 4;
         const float* sr = S + r * LDQ + c;
         const float* xr = X + r * LDQ + c;
+        if (c > r) continue;  // above the diagonal: A keeps its (unused) values, X was zeroed by gq_h_prepare
         if (c + 3 <= r) *reinterpret_cast<float4*>(A + r * lda + c) = make_float4(sr[0], sr[1], sr[2], sr[3]);
         else
             for (int u = 0; u < 4; ++u)
