@@ -1,0 +1,284 @@
+"""Block schedule: how the Linears of ONE transformer block travel the hot path on an MI355X.
+
+The reference walks the handles of a block one after the other (quantizer.py:248-275): seven Hessians, seven
+factorisations, seven column loops, each a chain of small dependent launches on one stream.  This module is the
+product's replacement for that loop -- `Quantizer._quant_group` and `bench.py` both call it, nothing else
+schedules kernels:
+
+  hook side    `feed(name, x)` is the body of the forward hook (quantizer.py:226-232).  Linears fed by the SAME
+               tensor (q/k/v, gate/up) are detected and share one Hessian.  Activations are buffered by the
+               handles; `sample_done()` (after every calibration sample) folds the buffers of ALL distinct
+               inputs into their Hessians with grouped SYRK launches once they hold `flush_tokens` tokens:
+               the narrow inputs in one grid, then the widest input alone on the chip.
+  quantize()   phase 0  the remaining tokens are folded in; [N>1] ONE all-reduce per distinct Hessian, widest
+                        first (gptq.py:131-132 does one per handle);
+               phase 1  every input group is an independent chain (h_prepare -> per Linear: working copy,
+                        column loop, dequantize) and runs on its own HIP stream, widest chain first: the
+                        single-workgroup leaves of one factorisation and the 64-CU column-loop kernels overlap
+                        with the GEMMs of the other chains.  Followers reuse the leader's U speculatively
+                        (`gq_w_prepare` leaves a mismatch flag that is read once, after all chains);
+               phase 2  [N>1] broadcast from the owner / all-gather of row slices, in handle order on every
+                        rank; the dequantized weight is written back (quantizer.py:257-264).
+No host synchronisation happens between the first launch of phase 0 and the flag read at the end of phase 1.
+"""
+import contextlib
+import os
+from typing import Any, Callable, Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import dist_utils
+from . import ops as _ops
+from .gptq import GPTQ
+from .quant_utils import GGMLQuantizationType, dequantize_linear_weight
+
+_stream_pool: Dict[Any, List["torch.cuda.Stream"]] = {}
+
+
+def _chain_streams(device, n: int):
+    """`n` persistent side streams of `device` (none for CPU tensors: the CPU tests run the chains in line)."""
+    if n <= 0 or torch.device(device).type != "cuda":
+        return []
+    pool = _stream_pool.setdefault(torch.device(device), [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device))
+    return pool[:n]
+
+
+class _Lane:
+    """One chain's execution lane: a HIP stream with event fork/join against the caller's stream, or nothing."""
+
+    def __init__(self, stream, main):
+        self.stream, self.main = stream, main
+
+    def wait(self, event):
+        if self.stream is not None and event is not None:
+            self.stream.wait_event(event)
+
+    def run(self):
+        return torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
+
+    def join(self, tensors=()):
+        """The caller's stream waits for this lane; tensors born here stay valid for the caller's stream."""
+        if self.stream is None:
+            return
+        ev = torch.cuda.Event()
+        ev.record(self.stream)
+        self.main.wait_event(ev)
+        for t in tensors:
+            if t is not None and t.is_cuda:
+                t.record_stream(self.main)
+
+
+class BlockSchedule:
+    def __init__(self, layers: Dict[str, nn.Module], make_handle: Callable[[nn.Module, str], GPTQ],
+                 n_streams: Optional[int] = None, verbose: bool = False):
+        self.handles: Dict[str, GPTQ] = {n: make_handle(l, n) for n, l in layers.items()}
+        for h in self.handles.values():
+            h._scheduled = True  # the handle leaves threshold flushes to sample_done()
+        self._seen: Dict[Any, Any] = {}  # per block call: input identity -> (leader handle, tensor kept alive)
+        self.n_streams = int(os.environ.get("GQ_CHAIN_STREAMS", 4)) if n_streams is None else n_streams
+        self.verbose = verbose
+        self.stats = {"syrk_launches": 0, "allreduce_bytes": 0, "reused_U": 0, "own_U": 0, "refactorised": 0}
+
+    # ------------------------------------------------------------------ hook side
+    def hook(self, name: str):
+        def _hook(_, inp, out):
+            self.feed(name, inp[0])
+        return _hook
+
+    def feed(self, name: str, x: torch.Tensor) -> None:
+        """Body of the reference's forward hook (quantizer.py:229): handles[name].update(inp[0]), plus the
+        detection of Linears that see the very same tensor."""
+        h = self.handles[name]
+        key = (x.data_ptr(), tuple(x.shape), tuple(x.stride()), x.dtype, x._version)
+        hit = self._seen.get(key)
+        if hit is not None and hit[0].d_col == h.d_col and hit[0] is not h:
+            leader = hit[0]
+            assert h.shared_H_with in (None, leader), "input sharing pattern changed between samples"
+            assert h.H is None, "handle switched from own Hessian to a shared one"
+            h.shared_H_with = leader
+            leader._has_followers = True
+        else:
+            assert h.shared_H_with is None, "input sharing pattern changed between samples"
+            self._seen[key] = (h, x)
+        h.update(x)
+
+    def sample_done(self) -> None:
+        """Called after every calibration sample (one forward of the block)."""
+        self._seen.clear()
+        if any(h._fill >= h.flush_tokens for h in self.handles.values()):
+            self.flush()
+
+    def leaders(self) -> List[GPTQ]:
+        return [h for h in self.handles.values() if h.shared_H_with is None]
+
+    def flush(self) -> None:
+        """Fold every leader's buffered activations into its Hessian: grouped SYRK launches (<= 8 problems per
+        grid, one activation dtype per grid), the narrow inputs first and the widest input alone -- its tiles
+        fill the chip for ~5 ms per 64 Ki tokens, nothing is gained by mixing it with the others."""
+        todo = [h for h in self.leaders() if h._fill > 0]
+        if not todo:
+            return
+        todo.sort(key=lambda h: (-h.d_col, id(h)))
+        grids: List[List[GPTQ]] = []
+        if len(todo) > 1 and todo[0].d_col > todo[1].d_col and not os.environ.get("GQ_SYRK_ONE_GRID"):
+            rest, grids_tail = todo[1:], [[todo[0]]]
+        else:
+            rest, grids_tail = todo, []
+        by_kind: Dict[Any, List[GPTQ]] = {}
+        for h in rest:
+            by_kind.setdefault((h._buf.dtype, h._buf.device), []).append(h)
+        for grp in by_kind.values():
+            grids += [grp[i:i + 8] for i in range(0, len(grp), 8)]
+        grids += grids_tail
+        for grp in grids:
+            args = [h._flush_args() for h in grp]
+            _ops.h_accumulate_grouped([a[0] for a in args], [a[1] for a in args], [a[2] for a in args],
+                                      [a[3] for a in args])
+            self.stats["syrk_launches"] += 1
+            for h in grp:
+                h._flush_done()
+
+    # ------------------------------------------------------------------ multi-rank agreement
+    def _agree_on_sharing(self) -> None:
+        """MoE experts receive a data-dependent set of tokens per rank; a rank that routed nothing to an expert
+        never fires its hooks and cannot know that w1 and w3 share their input.  The sharing pattern decides how
+        many collectives a rank issues, so it is made rank-invariant before any of them: every rank contributes
+        the leader index it observed (-1: never fired) and adopts the maximum."""
+        names = list(self.handles)
+        idx = {id(self.handles[n]): i for i, n in enumerate(names)}
+        dev = next(iter(self.handles.values())).W_device
+        v = torch.full((len(names),), -1, dtype=torch.int64, device=dev)
+        for i, n in enumerate(names):
+            h = self.handles[n]
+            if h.shared_H_with is not None:
+                v[i] = idx[id(h.shared_H_with)]
+            elif h.H is not None or h._fill > 0:
+                v[i] = i
+        mine = v.clone()
+        torch.distributed.all_reduce(v, op=torch.distributed.ReduceOp.MAX)
+        got, mine = v.tolist(), mine.tolist()
+        for i, n in enumerate(names):
+            h = self.handles[n]
+            assert mine[i] in (-1, got[i]), f"{n}: ranks observed different input sharing ({mine[i]} vs {got[i]})"
+            if mine[i] == -1 and got[i] not in (-1, i):
+                leader = self.handles[names[got[i]]]
+                h.shared_H_with = leader
+                leader._has_followers = True
+
+    # ------------------------------------------------------------------ quantize
+    @torch.no_grad()
+    def quantize(self, qtypes: Dict[str, GGMLQuantizationType], writeback: bool = True,
+                 extra: Optional[Callable[[str, GPTQ, tuple], Any]] = None) -> Dict[str, Tuple[torch.Tensor, ...]]:
+        """-> {name: (qweight, super_group_scale, group_scale_quant, super_group_zero, group_zero_quant)} on every
+        rank, in the reference's order (gptq.py:295); with `writeback` the dequantized matrix replaces
+        layer.weight.data (quantizer.py:257-264).  `extra(name, handle, result)` runs on the chain's stream right
+        after a Linear's column loop on the rank that computed it (bench.py packs the GGUF bytes there)."""
+        handles = self.handles
+        world, rank = dist_utils.get_world_size(), dist_utils.get_rank()
+        for n, h in handles.items():
+            if qtypes[n] == GGMLQuantizationType.Q3_K:
+                h.act_order = False  # reference gptq.py:204-206
+        if world > 1:
+            costs = {n: float(h.d_row) * h.d_col * (h.d_col + 128) for n, h in handles.items()}
+            # a matrix that outweighs a fair share is quantized by every rank on its own rows (U replicated);
+            # the rest are handed out whole
+            split = {n for n in dist_utils.row_split_names(costs, world) if not handles[n].act_order}
+            for n in split:
+                handles[n].row_split = True
+            for n, r in dist_utils.assign_owners({n: c for n, c in costs.items() if n not in split}, world).items():
+                handles[n].owner_rank = r
+            if any(h.allow_no_samples for h in handles.values()):
+                self._agree_on_sharing()
+        dev = next(iter(handles.values())).W_device
+        on_gpu = torch.device(dev).type == "cuda"
+        main = torch.cuda.current_stream(dev) if on_gpu else None
+
+        # ---- phase 0: the rest of the tokens, then one all-reduce per distinct Hessian, widest first
+        self.flush()
+        ready: Dict[int, Any] = {}
+        for h in sorted(self.leaders(), key=lambda h: -h.d_col):
+            h.sync_hessian()
+            if world > 1:
+                self.stats["allreduce_bytes"] += dist_utils.hessian_payload_bytes(h.d_col)
+                if on_gpu:
+                    ready[id(h)] = torch.cuda.Event()
+                    ready[id(h)].record(main)
+        for h in handles.values():
+            h.sync_hessian()  # followers adopt their leader's H (no collective)
+        start = None
+        if on_gpu and world == 1:
+            start = torch.cuda.Event()
+            start.record(main)
+
+        # ---- phase 1: one chain per distinct Hessian, each on its own stream, the costliest first
+        chains: Dict[int, List[str]] = {}
+        for n, h in handles.items():
+            if h.owner_rank == rank or h._row_split_active():
+                chains.setdefault(id(h.shared_H_with or h), []).append(n)
+
+        def chain_cost(ns):
+            return (not any(handles[n]._row_split_active() for n in ns),
+                    -sum(float(handles[n].d_row) * handles[n].d_col ** 2 for n in ns))
+
+        order = sorted(chains.values(), key=chain_cost)
+        streams = _chain_streams(dev, min(self.n_streams, len(order)))
+        results: Dict[str, tuple] = {}
+        deq: Dict[str, torch.Tensor] = {}
+        lanes = []
+        for k, names in enumerate(order):
+            lane = _Lane(streams[k % len(streams)] if streams else None, main)
+            lead = handles[names[0]].shared_H_with or handles[names[0]]
+            lane.wait(ready.get(id(lead), start))
+            born = []
+            with lane.run():
+                # the leader first: it factorises, the followers reuse its U
+                for n in sorted(names, key=lambda n: handles[n].shared_H_with is not None):
+                    h = handles[n]
+                    if self.verbose:
+                        print(f"[rank {rank}] Quantizing {n} with {qtypes[n].name}.")
+                    h.make_working_copy()
+                    res = h.compute(qtypes[n], defer_check=True)
+                    results[n] = res
+                    born += list(res)
+                    if world == 1 and writeback:
+                        deq[n] = dequantize_linear_weight(qtypes[n], *res, out_dtype=h.layer.weight.data.dtype)
+                        born.append(deq[n])
+                    if extra is not None:
+                        out = extra(n, h, res)
+                        born += [t for t in (out if isinstance(out, (tuple, list)) else (out,))
+                                 if torch.is_tensor(t)]
+            lanes.append((lane, born))
+        for lane, born in lanes:
+            lane.join(born)
+
+        # a follower whose dead / zero-column set differs from its leader's needs its own factorisation
+        pending = [(n, handles[n]._pending_mismatch) for n in results if handles[n]._pending_mismatch is not None]
+        if pending:
+            flags = torch.cat([f.reshape(1) for _, f in pending]).tolist()  # the block's only host sync
+            for (n, _), bad in zip(pending, flags):
+                h = handles[n]
+                h._pending_mismatch = None
+                if bad:
+                    self.stats["refactorised"] += 1
+                    h.make_working_copy()
+                    results[n] = h.compute(qtypes[n], own_U=True)
+                    deq.pop(n, None)
+                else:
+                    self.stats["reused_U"] += 1
+        self.stats["own_U"] += len(results) - len(pending)
+
+        # ---- phase 2: exchange (same order on every rank), write-back
+        out: Dict[str, tuple] = {}
+        for n, h in handles.items():
+            res = h.exchange(results.get(n), qtypes[n])
+            out[n] = res
+            if writeback:
+                w = deq.get(n)
+                if w is None:
+                    w = dequantize_linear_weight(qtypes[n], *res, out_dtype=h.layer.weight.data.dtype)
+                h.layer.weight.data = w
+            h.reset()
+        return out

@@ -53,8 +53,7 @@ def allreduce_hessian(H, num_samples=None):
     import torch
     # H is exactly symmetric: only its upper 128x128 tiles travel (gq_h_pack_upper / gq_h_unpack_upper), half the
     # bytes on the xGMI links, and the reduced H is symmetric bit for bit on every rank
-    packed = H.is_cuda and H.dtype == torch.float32 and H.is_contiguous() and H.shape[0] % 128 == 0 \
-        and H.shape[0] >= 1024 and os.environ.get("GQ_ALLREDUCE_FULL") is None
+    packed = H.is_cuda and H.dtype == torch.float32 and H.is_contiguous() and _packs_upper(H.shape[0])
     if packed:
         from . import ops
         payload = ops.h_pack_upper(H)
@@ -76,6 +75,16 @@ def allreduce_hessian(H, num_samples=None):
     if packed:
         ops.h_unpack_upper(payload, H)
     return total
+
+
+def _packs_upper(C: int) -> bool:
+    return C % 128 == 0 and C >= 1024 and os.environ.get("GQ_ALLREDUCE_FULL") is None
+
+
+def hessian_payload_bytes(C: int) -> int:
+    """Bytes one rank hands to the all-reduce of a C x C Hessian (upper 128x128 tiles only when packed)."""
+    nt = C // 128
+    return 4 * (128 * 128 * nt * (nt + 1) // 2 if _packs_upper(C) else C * C)
 
 
 def assign_owners(costs: Dict[str, float], world_size: int) -> Dict[str, int]:

@@ -50,6 +50,10 @@ class GPTQ:
         self.allow_no_samples = allow_no_samples
         self.no_samples = False
         self.shared_H_with = None      # another handle fed by the SAME input tensor (q/k/v, gate/up)
+        self._has_followers = False    # some other handle names this one in shared_H_with
+        self._scheduled = False        # a BlockSchedule folds the buffers of all leaders in grouped launches
+        self._reduced = False          # H already went through sync_hessian()
+        self._pending_mismatch = None  # device flag of a speculative reuse of the leader's U (compute(defer_check))
         self._flag = None
         self._ws = None
         # activations are buffered (288 GB of HBM per GPU) and folded into H in long-K SYRK launches:
@@ -81,12 +85,14 @@ class GPTQ:
         t = x.shape[0]
         if self._buf is not None and (self._buf.dtype != x.dtype or self._fill + t > self._buf.shape[0]):
             self.flush()
+            if self._buf.dtype != x.dtype or t > self._buf.shape[0]:
+                self._buf = None  # a wider sample or another dtype than the buffer was sized for
         if self._buf is None:
             self._buf = torch.empty((max(self.flush_tokens, t), self.d_col), device=x.device, dtype=x.dtype)
         self._buf[self._fill:self._fill + t].copy_(x)
         self._fill += t
         self._buf_b += batch_size
-        if self._fill >= self.flush_tokens:
+        if self._fill >= self.flush_tokens and not self._scheduled:
             self.flush()
 
     @torch.no_grad()
@@ -94,13 +100,24 @@ class GPTQ:
         """Fold the buffered activations into H (one gq_h_accumulate over all buffered tokens)."""
         if self._fill == 0:
             return
+        H, X, beta, alpha = self._flush_args()
+        _ops.h_accumulate(H, X, beta, alpha)
+        self._flush_done()
+
+    def _flush_args(self):
+        """(H, X[T, C], beta, alpha) of the pending fold: b samples at once are the telescoped form of b single
+        updates of gptq.py:106-112."""
         n, b = self.num_samples, self._buf_b
-        _ops.h_accumulate(self.H, self._buf[:self._fill], n / (n + b), 2.0 / (n + b))
-        self.num_samples += b
+        return self.H, self._buf[:self._fill], n / (n + b), 2.0 / (n + b)
+
+    def _flush_done(self) -> None:
+        self.num_samples += self._buf_b
         self._fill = 0
         self._buf_b = 0
 
     def reset(self) -> None:
+        """Back to the state after __init__ (reference gptq.py:116-120 frees H; every piece of state this class
+        adds goes with it, so a handle can be fed and quantized again)."""
         self.W = self.layer.weight
         self.H = None
         self.num_samples = 0
@@ -108,6 +125,15 @@ class GPTQ:
         self._buf = None
         self._fill = 0
         self._buf_b = 0
+        self._reduced = False
+        self.shared_H_with = None
+        self._has_followers = False
+        self._U_cache = None
+        self._pending_mismatch = None
+        self._flag = None
+        self.no_samples = False
+        self.owner_rank = 0
+        self.row_split = False
 
     # ------------------------------------------------------------------- quantize
     @torch.no_grad()
@@ -123,7 +149,7 @@ class GPTQ:
         """One collective per DISTINCT Hessian (reference gptq.py:131-132 does one per handle)."""
         if self.shared_H_with is not None:
             leader = self.shared_H_with
-            if not getattr(leader, "_reduced", False):
+            if not leader._reduced:
                 leader.sync_hessian()
             self.H = leader.H
             self._reduced = True
@@ -134,13 +160,15 @@ class GPTQ:
             self.H = torch.zeros((self.d_col, self.d_col), device=self.W_device, dtype=torch.float32)
         self.flush()
         self._buf = None
-        if not getattr(self, "_reduced", False):
-            # sample-weighted when the ranks' counts differ (experts); plain AVG otherwise (every dense Linear)
-            total = dist_utils.allreduce_hessian(self.H, self.num_samples)
-            if total == 0:
-                assert self.allow_no_samples
-                self.H = torch.eye(self.d_col, device=self.W_device, dtype=torch.float32)
-                self.no_samples = True
+        if not self._reduced:
+            if self.allow_no_samples:
+                # experts: sample-weighted when the ranks' token counts differ (costs one host read of the counts)
+                total = dist_utils.allreduce_hessian(self.H, self.num_samples)
+                if total == 0:
+                    self.H = torch.eye(self.d_col, device=self.W_device, dtype=torch.float32)
+                    self.no_samples = True
+            else:
+                dist_utils.allreduce_hessian(self.H)  # every dense Linear: the reference's AVG, no host sync
             self._reduced = True
 
     @torch.no_grad()
@@ -151,21 +179,27 @@ class GPTQ:
         self.W = W.contiguous()
 
     @torch.no_grad()
-    def _prepare(self) -> Tensor:
+    def _prepare(self, defer_check: bool = False, own_U: bool = False) -> Tensor:
         """-> U = chol_upper(H^-1); mutates H (damping) and W (dead columns) like the reference (:304-324).
         Handles fed by the same input tensor hold the same H; U depends on (H, dead set, zero-column set
-        of W) only, so a follower whose sets equal its leader's reuses the leader's U bit-for-bit."""
-        leader = self.shared_H_with
-        if leader is not None and getattr(leader, "_U_cache", None) is not None:
+        of W) only, so a handle whose sets equal those of the handle that factorised first reuses that U
+        bit-for-bit.  `defer_check`: the comparison flag stays on the device in `_pending_mismatch` (the caller
+        reads it later and calls compute(own_U=True) on a mismatch) so that no host sync splits the chain."""
+        leader = self.shared_H_with or self
+        shared = self.shared_H_with is not None or self._has_followers
+        if shared and leader._U_cache is not None and not own_U:
             U, flag, cf = leader._U_cache
-            if int(_ops.w_prepare(cf, self.W).item()) == 0:
+            mismatch = _ops.w_prepare(cf, self.W)
+            if defer_check:
+                self._pending_mismatch, self._flag = mismatch, flag
+                return U
+            if int(mismatch.item()) == 0:
                 self._flag = flag
                 return U
-        shared = leader is not None or getattr(self, "_has_followers", False)
         H = self.H.clone() if shared else self.H  # every reference handle damps its own copy
         U, self._flag, cf = _ops.h_prepare(H, self.W, self.rel_damp, want_flags=True)
-        if getattr(self, "_has_followers", False):
-            self._U_cache = (U, self._flag, cf)
+        if shared and leader._U_cache is None:
+            leader._U_cache = (U, self._flag, cf)
         if not shared:
             self.H = H
         return U
@@ -175,7 +209,7 @@ class GPTQ:
         return bool(self._flag is not None and int(self._flag.item()) != 0)
 
     @torch.no_grad()
-    def compute(self, q_type: GGMLQuantizationType):
+    def compute(self, q_type: GGMLQuantizationType, defer_check: bool = False, own_U: bool = False):
         """Rank-local numerical body of step() (reference gptq.py:158-276); no communication."""
         if q_type == GGMLQuantizationType.Q3_K:  # reference gptq.py:204-206 mutates the handle
             self.act_order = False
@@ -186,7 +220,7 @@ class GPTQ:
             check_mse_equivalent(q_type, float(self.W.max().item()), margin=4.0)
         if self.act_order:
             return self._compute_act_order(q_type)
-        U = self._prepare()
+        U = self._prepare(defer_check, own_U)
         W = self.W
         if self._row_split_active():
             # every rank factorises (same reduced H => the same U, bit for bit) and walks its own rows
@@ -198,7 +232,7 @@ class GPTQ:
                                   self.rdelta, self.nstep)
 
     def _row_split_active(self) -> bool:
-        return bool(getattr(self, "row_split", False)) and not self.act_order and dist_utils.get_world_size() > 1
+        return bool(self.row_split) and not self.act_order and dist_utils.get_world_size() > 1
 
     @torch.no_grad()
     def _compute_act_order(self, q_type: GGMLQuantizationType):

@@ -180,8 +180,8 @@ def gptq_quantize(W: torch.Tensor, U: torch.Tensor, q_type: int, block_size=128,
     Rows of W are independent given U (gptq.py:222-270 never mixes rows), so a tall matrix is cut into
     `row_chunks` contiguous row ranges, each a separate gq_gptq_quantize call on its own HIP stream: the
     latency-bound column-loop kernel of one chunk overlaps with the trailing-update GEMM of another.
-    Results are identical to one call.  Default 1: every extra chunk multiplies the launch count, which only
-    pays on the critical chain of a block (bench.py / the driver pass it for the widest Linear)."""
+    Results are identical to one call.  Default 1 (what BlockSchedule uses): every extra chunk multiplies the
+    launch count; measured no gain inside a block's four-chain schedule."""
     _need_cuda(W, U)
     assert W.dtype == torch.float32 and U.dtype == torch.float32 and W.is_contiguous() and U.is_contiguous()
     R, C = W.shape

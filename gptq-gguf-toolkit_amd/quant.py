@@ -10,7 +10,9 @@ import os
 import sys
 import time
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # one hardware queue per HIP stream (the driver runs 4 chains), see bench.py
+# one hardware queue per HIP stream: block_schedule.BlockSchedule runs the input groups of a block as concurrent
+# chains on 4 streams, and the runtime's default of 4 queues makes two of them share one
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 import torch
 import torch.distributed as dist
@@ -150,8 +152,9 @@ def main(argv=None):
     t2 = time.perf_counter()
     dist_utils.print_on_main(f"Quantization took {(t2 - t1)} s.")
     dist_utils.barrier()
-    if args.eval_perplexity and dist_utils.is_main():
-        print("--eval_perplexity: WikiText-2 needs a dataset download and is not part of this package; skipped.")
+    if args.eval_perplexity:
+        raise NotImplementedError("--eval_perplexity: the WikiText-2 evaluation (a dataset download) is outside this "
+                                  "package; the quantized model was written to " + args.save_dir)
     if dist_utils.is_dist_available_and_initialized():
         dist.destroy_process_group()
 

@@ -3,14 +3,23 @@
 Same constructor, same walk (embed -> blocks in order -> lm_head), same hook protocol
 (forward hooks feed inp[0] of every regex-matched Linear to its handle), same data.pth
 schema (quantizer.py:268-275).  MI355X-first differences, none of which changes results:
-  * Linears of a block that are fed by the SAME input tensor (q/k/v, gate/up) share one
-    Hessian accumulation and one all-reduce instead of 3/2 identical ones;
+  * the Linears of a block go through `block_schedule.BlockSchedule`: Linears fed by the SAME input tensor
+    (q/k/v, gate/up) share one Hessian accumulation and one all-reduce instead of 3/2 identical ones, the
+    Hessians of a block are accumulated by grouped SYRK launches, and the independent input groups quantize
+    concurrently on their own HIP streams;
   * with world_size > 1 the Linears of a block are assigned to owner ranks (LPT on
     R*C*(C+128)) and quantize concurrently; the 5 result tensors are broadcast from the
     owner (the reference computes everything on rank 0, gptq.py:158);
-  * data.pth is written by rank 0 only (the reference lets every rank write the same file).
+  * data.pth is written by rank 0 only (the reference lets every rank write the same file), by a writer
+    thread behind a copy stream, so that the device-to-host copies and the file writes of block i overlap with
+    the forwards of block i+1; `quantize()` returns after the last file is closed.
+`Quantizer.timing` holds the split of the last `quantize()` call (host seconds per phase and, with
+GQ_TIMING=gpu, HIP-event seconds per phase on the main stream).
 """
 import os
+import queue
+import threading
+import time
 from typing import Any, Dict, Iterable, List, Optional
 
 import torch
@@ -18,9 +27,105 @@ import torch.nn as nn
 
 from . import dist_utils
 from . import ops as _ops
+from .block_schedule import BlockSchedule
 from .gptq import GPTQ
 from .model_utils import ForwardInterrupt, InputCollector, LINEAR_LAYERS, _to, select_layers
 from .quant_utils import GGML_QUANT_SIZES, GGMLQuantizationType, dequantize_linear_weight
+
+
+class _Saver:
+    """data.pth writer: one thread; device tensors are copied to the host on a side stream after an event that
+    marks them complete, then written with torch.save (quantizer.py:267-275).  `sync=True` (CPU tensors, or
+    GQ_SYNC_SAVE=1) writes in line like the reference."""
+
+    def __init__(self, save_dir: str, sync: bool):
+        self.save_dir, self.sync = save_dir, sync
+        self.q: "queue.Queue" = queue.Queue()
+        self.err: Optional[BaseException] = None
+        self.busy_s = 0.0
+        self.thread = None
+        self.stream = None
+
+    def _write(self, name, q_type, tensors):
+        t0 = time.perf_counter()
+        qweight, d, s, dmin, m = [t.cpu() for t in tensors]
+        os.makedirs(os.path.join(self.save_dir, name), exist_ok=True)
+        torch.save({"q_type": int(q_type), "qweight": qweight, "super_group_scale": d, "super_group_zero": dmin,
+                    "group_scale_quant": s, "group_zero_quant": m}, os.path.join(self.save_dir, name, "data.pth"))
+        self.busy_s += time.perf_counter() - t0
+
+    def _loop(self):
+        while True:
+            item = self.q.get()
+            if item is None:
+                return
+            name, q_type, tensors, ev, dev = item
+            try:
+                if self.stream is None:
+                    self.stream = torch.cuda.Stream(dev)
+                with torch.cuda.stream(self.stream):
+                    self.stream.wait_event(ev)
+                    self._write(name, q_type, tensors)
+            except BaseException as e:  # surfaced by close()
+                self.err = self.err or e
+
+    def put(self, name, q_type, tensors):
+        if self.sync or not tensors[0].is_cuda:
+            self._write(name, q_type, tensors)
+            return
+        if self.thread is None:
+            self.thread = threading.Thread(target=self._loop, name="gq-data-pth-writer", daemon=True)
+            self.thread.start()
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(tensors[0].device))
+        self.q.put((name, q_type, tensors, ev, tensors[0].device))
+
+    def close(self):
+        if self.thread is not None:
+            self.q.put(None)
+            self.thread.join()
+            self.thread = None
+        if self.err is not None:
+            raise self.err
+
+
+class _Phases:
+    """Where the time of quantize() goes: host seconds per phase, plus GPU seconds per phase from HIP events on
+    the main stream when GQ_TIMING=gpu (the events are read once, at the end)."""
+
+    def __init__(self, device):
+        self.host: Dict[str, float] = {}
+        self.gpu_events: List[Any] = []
+        self.use_gpu = os.environ.get("GQ_TIMING") == "gpu" and torch.device(device).type == "cuda"
+        self.device = device
+        self._t = time.perf_counter()
+        self._e = self._event()
+
+    def _event(self):
+        if not self.use_gpu:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(torch.cuda.current_stream(self.device))
+        return e
+
+    def mark(self, phase: str):
+        now = time.perf_counter()
+        self.host[phase] = self.host.get(phase, 0.0) + now - self._t
+        self._t = now
+        if self.use_gpu:
+            e = self._event()
+            self.gpu_events.append((phase, self._e, e))
+            self._e = e
+
+    def result(self) -> Dict[str, Any]:
+        out = {"host_s": {k: round(v, 4) for k, v in self.host.items()}}
+        if self.use_gpu:
+            torch.cuda.synchronize(self.device)
+            g: Dict[str, float] = {}
+            for phase, a, b in self.gpu_events:
+                g[phase] = g.get(phase, 0.0) + a.elapsed_time(b) * 1e-3
+            out["gpu_s"] = {k: round(v, 4) for k, v in g.items()}
+        return out
 
 
 def _first(x):
@@ -52,6 +157,19 @@ class Quantizer:
     @torch.no_grad()
     def quantize(self, quant_config: Dict[str, GGMLQuantizationType]) -> None:
         device = self.device or next(self.model.parameters()).device
+        self._saver = _Saver(self.save_dir, sync=os.environ.get("GQ_SYNC_SAVE") == "1")
+        try:
+            self._quantize(quant_config, device)
+        finally:
+            t0 = time.perf_counter()
+            self._saver.close()
+            if getattr(self, "_phases", None) is not None:
+                self._phases.host["save_tail"] = time.perf_counter() - t0
+                self.timing = self._phases.result()
+                self.timing["saver_thread_s"] = round(self._saver.busy_s, 4)
+
+    def _quantize(self, quant_config: Dict[str, GGMLQuantizationType], device) -> None:
+        ph = self._phases = _Phases(device)
         blocks = self.model.get_submodule(self.block_modules)
         pre_blocks = [(n, self.model.get_submodule(n)) for n in self.pre_block_modules]
         post_blocks = [(n, self.model.get_submodule(n)) for n in self.post_block_modules]
@@ -71,6 +189,7 @@ class Quantizer:
         input_args, input_kwargs = blocks[0].input_args, blocks[0].input_kwargs
         blocks[0] = blocks[0].module
         dist_utils.barrier()
+        ph.mark("capture")
 
         if self.quant_non_block_modules:
             for name, module in pre_blocks:
@@ -78,6 +197,7 @@ class Quantizer:
         if self.cpu_offload_modules:
             for _, m in pre_blocks:
                 m.cpu()
+        ph.mark("rtn_pre")
 
         for block_id, block in enumerate(blocks):
             if self.verbose:
@@ -85,15 +205,16 @@ class Quantizer:
             block = block.to(device)
             prefix = f"{self.block_modules}.{block_id}."
             layers = select_layers(self.model, prefix, self.quantizable_modules, LINEAR_LAYERS)
-            handles, hooks, seen = self._prepare_hooks_and_handles(layers)
+            handles, hooks = self._prepare_hooks_and_handles(layers)
+            sched = self._schedule
             for a, kw in zip(input_args, input_kwargs):  # forward #1: Hessians (quantizer.py:150-151)
-                seen.clear()
                 block(*_to(a, device=device), **_to(kw, device=device))
-            seen.clear()
+                sched.sample_done()  # grouped SYRK launches once the buffers hold flush_tokens tokens
             for h in hooks.values():
                 h.remove()
-            dist_utils.barrier()
+            ph.mark("forward1+H")
             self._quant_group(handles, quant_config)
+            ph.mark("quant_group")
             for a, kw in zip(input_args, input_kwargs):  # forward #2: propagate (quantizer.py:161-172)
                 out = _first(block(*_to(a, device=device), **_to(kw, device=device)))
                 if self.cpu_offload_activations:
@@ -106,13 +227,16 @@ class Quantizer:
                     raise ValueError("Unsupported block input format.")
             if self.cpu_offload_modules:
                 block.cpu()
-            del handles, hooks
+            del handles, hooks, sched
+            self._schedule = None
+            ph.mark("forward2")
 
         if self.quant_non_block_modules:
             for name, module in post_blocks:
                 self._quant_and_save_non_block(name, module.to(device), quant_config)
         if use_cache is not None:
             self.model.config.use_cache = use_cache
+        ph.mark("rtn_post")
         dist_utils.barrier()
 
     # --------------------------------------------------------- hooks / handles
@@ -123,74 +247,25 @@ class Quantizer:
         return GPTQ(layer, allow_no_samples=".experts." in f".{name}.", **self.quantizer_kwargs)
 
     def _prepare_hooks_and_handles(self, layers: Dict[str, nn.Module]):
-        handles: Dict[str, GPTQ] = {n: self._create_handle(l, n) for n, l in layers.items()}
-        hooks = {}
-        seen: Dict[Any, Any] = {}  # per block call: input identity -> (leader handle, tensor kept alive)
-
-        def make_hook(name):
-            def _hook(_, inp, out):
-                x = inp[0]
-                h = handles[name]
-                key = (x.data_ptr(), tuple(x.shape), tuple(x.stride()), x.dtype, x._version)
-                if key in seen and seen[key][0].d_col == h.d_col and seen[key][0] is not h:
-                    leader = seen[key][0]
-                    assert h.shared_H_with in (None, leader), "input sharing pattern changed between samples"
-                    assert h.H is None, "handle switched from own Hessian to a shared one"
-                    h.shared_H_with = leader
-                    leader._has_followers = True
-                else:
-                    assert h.shared_H_with is None, "input sharing pattern changed between samples"
-                    seen[key] = (h, x)
-                h.update(x)
-            return _hook
-
-        for name, layer in layers.items():
-            hooks[name] = layer.register_forward_hook(make_hook(name))
-        return handles, hooks, seen
+        """reference quantizer.py:221-239; the hook body lives in BlockSchedule.feed."""
+        self._schedule = BlockSchedule(layers, self._create_handle, verbose=self.verbose)
+        hooks = {name: layer.register_forward_hook(self._schedule.hook(name)) for name, layer in layers.items()}
+        return self._schedule.handles, hooks
 
     # ------------------------------------------------------------- quantize
     def _save(self, name, q_type, qweight, d, s, dmin, m):
         if not dist_utils.is_main():
             return
-        os.makedirs(os.path.join(self.save_dir, name), exist_ok=True)
-        torch.save({"q_type": int(q_type), "qweight": qweight.cpu(), "super_group_scale": d.cpu(),
-                    "super_group_zero": dmin.cpu(), "group_scale_quant": s.cpu(), "group_zero_quant": m.cpu()},
-                   os.path.join(self.save_dir, name, "data.pth"))
+        self._saver.put(name, q_type, (qweight, d, s, dmin, m))
 
     def _quant_group(self, handles: Dict[str, GPTQ], quant_config: Dict[str, GGMLQuantizationType]):
-        world, rank = dist_utils.get_world_size(), dist_utils.get_rank()
+        """reference quantizer.py:241-275: quantize every handle, write the dequantized weight back, save."""
         qtypes = {n: quant_config.get(n.split(".")[-1], GGMLQuantizationType.Q4_K) for n in handles}
-        if world > 1:
-            costs = {n: float(h.d_row) * h.d_col * (h.d_col + 128) for n, h in handles.items()}
-            # a matrix that outweighs a fair share is quantized by every rank on its own rows (U replicated);
-            # the rest are handed out whole
-            split = {n for n in dist_utils.row_split_names(costs, world) if not handles[n].act_order}
-            for n in split:
-                handles[n].row_split = True
-            for n, r in dist_utils.assign_owners({n: c for n, c in costs.items() if n not in split}, world).items():
-                handles[n].owner_rank = r
-        # phase 0: one all-reduce per distinct Hessian, same order on every rank
-        for h in handles.values():
-            h.sync_hessian()
-        # phase 1: owners run prepare + column loop, no communication in between
-        results = {}
-        order = sorted(handles, key=lambda n: not getattr(handles[n], "row_split", False))  # split matrices first
-        for n in order:
-            h = handles[n]
-            if qtypes[n] == GGMLQuantizationType.Q3_K:
-                h.act_order = False  # reference gptq.py:204-206
-            if h.owner_rank == rank or h._row_split_active():
-                if self.verbose:
-                    print(f"[rank {rank}] Quantizing {n} with {qtypes[n].name}.")
-                h.make_working_copy()
-                results[n] = h.compute(qtypes[n])
-        # phase 2: exchange, write back the dequantized weight, save
-        for n, h in handles.items():
-            qweight, d, s, dmin, m = h.exchange(results.get(n), qtypes[n])
-            h.layer.weight.data = dequantize_linear_weight(qtypes[n], qweight, d, s, dmin, m,
-                                                           out_dtype=h.layer.weight.data.dtype)
-            h.reset()
-            self._save(n, qtypes[n], qweight, d, s, dmin, m)
+        sched = self._schedule
+        assert sched is not None and sched.handles is handles
+        for n, res in sched.quantize(qtypes, writeback=True).items():
+            self._save(n, qtypes[n], *res)
+        self.schedule_stats = sched.stats
 
     def _quant_non_block_module(self, w: torch.Tensor, q_type: GGMLQuantizationType):
         """RTN for embed / lm_head (reference quantizer.py:278-330)."""

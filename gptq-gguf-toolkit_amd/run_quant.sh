@@ -22,22 +22,20 @@ python -m torch.distributed.run --nnodes=1 --nproc-per-node="$NUM_GPUS" --master
     --block_modules model.layers \
     --post_block_modules lm_head \
     --quant_non_block_modules \
-    --calibration_data "${CALIB_DATA:-fineweb_edu}" \
+    --calibration_data "${CALIB_DATA:?set CALIB_DATA to a .pt file of [1, L] token-id tensors (dataset downloads are not part of this package)}" \
     --calibration_tokens "${CALIB_TOKENS:-4194304}" \
     --calibration_sequence_length "${CALIB_SEQ_LEN:-4096}" \
     --quant_scale "${QUANT_SCALE:-absmax}" \
     --rel_damp "${REL_DAMP:-0.01}" \
     --block_size "${BLOCK_SIZE:-128}" \
     --default_bit_width "${BITS:-Q4_K}" \
-    --bit_width_configuration "${BIT_WIDTH_CONFIGURATION:-./config.json}" \
+    ${BIT_WIDTH_CONFIGURATION:+--bit_width_configuration "$BIT_WIDTH_CONFIGURATION"} \
     --rmin "${RMIN:--1.0}" \
     --rdelta "${RDELTA:-0.1}" \
     --nstep "${NSTEP:-20}" \
     --dtype "${DTYPE:-auto}" \
     --seed "${SEED:-0}" \
     ${ATTN_IMPL:+--attn_implementation "$ATTN_IMPL"} \
-    --eval_perplexity \
-    --eval_sequence_length "${EVAL_SEQ_LEN:-2048}" \
     --verbose \
     ${NON_BLOCK_FP32:+--non_block_fp32} \
     --save_dir "${SAVE_DIR:-./quantized_model}"

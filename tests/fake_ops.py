@@ -23,6 +23,13 @@ def h_accumulate(H, X, beta, alpha, ws=None):
     return H
 
 
+def h_accumulate_grouped(Hs, Xs, betas, alphas, ws=None):
+    calls["h_accumulate_grouped"] = calls.get("h_accumulate_grouped", 0) + 1
+    for H, X, b, a in zip(Hs, Xs, betas, alphas):
+        h_accumulate(H, X, b, a)
+    return Hs
+
+
 def h_prepare(H, W, rel_damp, want_flags=False):
     calls["h_prepare"] += 1
     H0 = H.numpy().copy()
@@ -70,6 +77,11 @@ def dequantize(q_type, q, d, s, dmin, m, out_dtype=torch.float32):
     return torch.from_numpy(w).to(out_dtype)
 
 
+def pack(q_type, q, d, s, dmin=None, m=None):
+    return torch.from_numpy(O.pack(q_type, q.numpy(), _bits(d), s.numpy(), None if dmin is None else _bits(dmin),
+                                   None if m is None else m.numpy()))
+
+
 def scale_search(x, q_type, rmin=-1.0, rdelta=0.1, nstep=20):
     d, s, dmin, m = O.scale_search(x.numpy(), q_type, rmin, rdelta, nstep)
     return _f16(d), torch.from_numpy(s), _f16(dmin), torch.from_numpy(m)
@@ -81,12 +93,13 @@ def install(monkeypatch=None):
     import gptq_gguf_toolkit_amd.gptq as g
     import gptq_gguf_toolkit_amd.quant_utils as qu
     import gptq_gguf_toolkit_amd.quantizer as qz
+    import gptq_gguf_toolkit_amd.block_schedule as bs
     me = sys.modules[__name__]
-    for mod in (g, qu, qz):
+    for mod in (g, qu, qz, bs):
         if monkeypatch is not None:
             monkeypatch.setattr(mod, "_ops", me)
         else:
             mod._ops = me
-    for k in calls:
+    for k in list(calls):
         calls[k] = 0
     return me

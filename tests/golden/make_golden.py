@@ -414,10 +414,72 @@ def g11_act_order():
     save("g11_act_order", **out)
 
 
+# ----------------------------------------------------------------------------- G13 two ranks (gloo)
+def _g13_worker(rank, world, port, ret):
+    """One rank of the REFERENCE's calibration-sharded run: own shard -> update, quantization_pre_step
+    (all_reduce AVG, gptq.py:131-132), step (rank 0 computes, broadcasts, gptq.py:158,286-293)."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    set_sqrt("ieee")
+    R, C = 32, 256
+    out = {}
+    for tag, qt in (("Q4_K", T.Q4_K), ("Q6_K", T.Q6_K)):
+        layer = _mk_layer(R, C, 130)
+        xs = _calib(C, 4, 64, 131)
+        xs[0][..., 9] = 0.0
+        xs[1][..., 9] = 0.0
+        xs[2][..., 9] = 0.0
+        xs[3][..., 9] = 0.0  # a dead channel on every rank
+        g = RefGPTQ(layer, rel_damp=0.01, block_size=128)
+        for x in xs[rank * 2:(rank + 1) * 2]:  # contiguous shard (quant.py:177-179)
+            g.update(x)
+        out["H_local"] = g.H.numpy().copy()
+        g.quantization_pre_step()
+        out["H_reduced"] = g.H.numpy().copy()
+        cap = {}
+        orig = g._prepare
+
+        def prep(orig=orig, cap=cap):
+            u = orig()
+            cap["U"] = u.clone()
+            return u
+
+        g._prepare = prep
+        q, d, s, dmin, m = g.step(qt)
+        if rank == 0:
+            out[f"{tag}_U_triu"] = _triu_pack(cap["U"].numpy())
+        for k, v in zip(("q", "d", "s", "dmin", "m"), (q.numpy(), u16(d), s.numpy(), u16(dmin), m.numpy())):
+            out[f"{tag}_{k}"] = v.copy()
+        if tag == "Q4_K":
+            out["W0"] = layer.weight.data.numpy().copy()
+            out["X"] = np.stack([x[0].numpy() for x in xs])
+    ret[rank] = out
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def g13_two_rank():
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_g13_worker, args=(2, 29871, ret), nprocs=2, join=True)
+    r0, r1 = ret[0], ret[1]
+    out = {"W0": r0["W0"], "X": r0["X"], "H_local_rank0": r0["H_local"], "H_local_rank1": r1["H_local"],
+           "H_reduced": r0["H_reduced"]}
+    assert np.array_equal(r0["H_reduced"], r1["H_reduced"])
+    for tag in ("Q4_K", "Q6_K"):
+        out[f"{tag}_U_triu"] = r0[f"{tag}_U_triu"]
+        for k in ("q", "d", "s", "dmin", "m"):
+            assert np.array_equal(r0[f"{tag}_{k}"], r1[f"{tag}_{k}"]), "ranks disagree in the reference run"
+            out[f"{tag}_{k}"] = r0[f"{tag}_{k}"]
+    save("g13_two_rank", **out)
+
+
 def _main_all():
     torch.set_num_threads(8)
     for fn in (g1_make_quants, g2_scale_search, g3_elementwise, g4_g5_hessian, g6_g7_step_and_pack,
-               g8_g9_rtn_dequant, g11_act_order):
+               g8_g9_rtn_dequant, g11_act_order, g12_mse_scale, g13_two_rank):
         print(fn.__name__)
         fn()
     g10_driver()
@@ -504,5 +566,7 @@ if __name__ == "__main__":
         g11_act_order()
     elif "g12" in sys.argv[1:]:
         g12_mse_scale()
+    elif "g13" in sys.argv[1:]:
+        g13_two_rank()
     else:
         _main_all()

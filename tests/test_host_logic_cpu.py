@@ -325,3 +325,73 @@ def test_two_rank_gloo_matches_single_rank(tmp_path):
         tot += a.numel()
         diff += int((a != b).sum())
     assert diff / tot < 0.02, f"{diff / tot:.3%} ints differ between 1-rank and 2-rank runs"
+
+
+def _worker_g13(rank, world, port, ret, device="cpu", backend="gloo"):
+    """The build's handle on one rank of a calibration-sharded run, fed the REFERENCE's per-rank Hessians (G13)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    if device == "cpu":
+        import fake_ops
+        fake_ops.install()
+    from gptq_gguf_toolkit_amd.gptq import GPTQ
+    g = load_golden("g13_two_rank")
+    R, C = g["W0"].shape
+    out = {}
+    for tag, qt in (("Q4_K", 12), ("Q6_K", 14)):
+        layer = torch.nn.Linear(C, R, bias=False)
+        layer.weight.data = torch.from_numpy(g["W0"].copy())
+        layer = layer.to(device)
+        h = GPTQ(layer, rel_damp=0.01, block_size=128)
+        h.H = torch.from_numpy(g[f"H_local_rank{rank}"].copy()).to(device)
+        h.num_samples = 2
+        h.quantization_pre_step()  # all_reduce AVG over the ranks (gptq.py:131-132)
+        out["H_reduced"] = h.H.cpu().numpy().copy()
+        res = h.step(qt)           # the owner computes, everyone receives (gptq.py:286-293)
+        out[tag] = [t.cpu() for t in res]
+    ret[rank] = out
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def check_g13(ret):
+    g = load_golden("g13_two_rank")
+    Href = g["H_reduced"]
+    dead = np.diag(Href) == 1.0
+    for r in (0, 1):
+        H = ret[r]["H_reduced"].copy()
+        H[np.diag_indices_from(H)] = np.where(dead & (np.diag(H) == 0), 1.0, np.diag(H))  # fix of gptq.py:134
+        assert np.array_equal(H, Href), f"rank {r}: reduced H differs from the reference's all_reduce(AVG)"
+    rates = {}
+    for tag in ("Q4_K", "Q6_K"):
+        a, b = ret[0][tag], ret[1][tag]
+        assert all(torch.equal(x, y) for x, y in zip(a, b)), f"{tag}: ranks hold different results"
+        q, d, s, dmin, m = a
+        rates[tag] = float((q.numpy() != g[f"{tag}_q"]).mean())
+        assert rates[tag] < 0.02, f"{tag}: {rates[tag]:.3%} ints differ from the reference's 2-rank run"
+        assert float((s.numpy() != g[f"{tag}_s"]).mean()) < 0.05
+    return rates
+
+
+def test_two_rank_run_vs_reference_two_rank_golden(oracle):
+    """SURVEY 8c G11 (stored as G13): the REFERENCE run on 2 gloo ranks (per-rank shards -> all_reduce AVG ->
+    rank 0 steps -> broadcast).  The build's 2-rank run from the same per-rank Hessians must hold the same reduced
+    H bit for bit and the same results on both ranks (ints up to the tolerance-class Cholesky: a rate); and given
+    the reference's own U the oracle reproduces the reference's ints exactly (dead channel included)."""
+    g = load_golden("g13_two_rank")
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_g13, args=(2, 27000 + os.getpid() % 2000, ret), nprocs=2, join=True)
+    check_g13(ret)
+    W = g["W0"].copy()
+    dead = np.diag(g["H_reduced"]) == 1.0
+    W[:, dead] = 0.0
+    for tag, qt in (("Q4_K", 12), ("Q6_K", 14)):
+        C = W.shape[1]
+        U = np.zeros((C, C), np.float32)
+        U[np.triu_indices(C)] = g[f"{tag}_U_triu"]
+        _, q, d, s, dmin, m = oracle.gptq_step(W, U, qt, block_size=128)
+        assert np.array_equal(q, g[f"{tag}_q"]) and np.array_equal(d, g[f"{tag}_d"]) and np.array_equal(s, g[f"{tag}_s"])
+        assert np.array_equal(dmin, g[f"{tag}_dmin"]) and np.array_equal(m, g[f"{tag}_m"])
