@@ -15,7 +15,7 @@ F32, F16, BF16 = 0, 1, 2
 WS_H_ACCUMULATE, WS_H_PREPARE, WS_GPTQ_QUANTIZE = 1, 2, 3
 
 EXPORTS = (
-    "gq_abi_version", "gq_last_error", "gq_type_info", "gq_workspace_bytes", "gq_h_accumulate", "gq_h_accumulate_grouped", "gq_h_prepare", "gq_w_prepare", "gq_h_pack_upper", "gq_h_unpack_upper",
+    "gq_abi_version", "gq_last_error", "gq_type_info", "gq_workspace_bytes", "gq_h_accumulate", "gq_h_accumulate_grouped", "gq_h_accumulate_segments", "gq_h_stage", "gq_h_prepare", "gq_w_prepare", "gq_h_pack_upper", "gq_h_unpack_upper",
     "gq_scale_search", "gq_group_search", "gq_gptq_quantize", "gq_gptq_quantize_perm", "gq_rtn_quantize", "gq_dequantize", "gq_pack", "gq_trailing_update",
     "gq_prof_enable", "gq_prof_ntags", "gq_prof_name", "gq_prof_collect", "gq_prof_collect2",
 )
@@ -68,6 +68,8 @@ def lib():
     L.gq_workspace_bytes.restype = sz
     L.gq_h_accumulate.argtypes = [vp, vp, ci, i64, i64, cf, cf, vp, sz, vp]
     L.gq_h_accumulate_grouped.argtypes = [ci, vp, vp, vp, vp, vp, vp, ci, vp, sz, vp]
+    L.gq_h_accumulate_segments.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp, ci, vp, sz, vp]
+    L.gq_h_stage.argtypes = [vp, vp, i64, vp]
     L.gq_h_prepare.argtypes = [vp, vp, i64, i64, cf, vp, vp, vp, vp, sz, vp]
     L.gq_w_prepare.argtypes = [vp, vp, i64, i64, vp, vp]
     L.gq_h_pack_upper.argtypes = [vp, i64, vp, vp]

@@ -15,14 +15,21 @@ schedules kernels:
                phase 1  every input group is an independent chain (h_prepare -> per Linear: working copy,
                         column loop, dequantize) and runs on its own HIP stream, widest chain first: the
                         single-workgroup leaves of one factorisation and the 64-CU column-loop kernels overlap
-                        with the GEMMs of the other chains.  Followers reuse the leader's U speculatively
-                        (`gq_w_prepare` leaves a mismatch flag that is read once, after all chains);
+                        with the GEMMs of the other chains.  A follower reuses its leader's U when both weights
+                        have the same all-zero columns (U depends on H, the dead channels and that set only,
+                        gptq.py:307-313); the sets are compared on the device when the block's first sample has
+                        shown who shares what, and the answer reaches the host long before quantize();
                phase 2  [N>1] broadcast from the owner / all-gather of row slices, in handle order on every
                         rank; the dequantized weight is written back (quantizer.py:257-264).
-No host synchronisation happens between the first launch of phase 0 and the flag read at the end of phase 1.
+quantize() never synchronises the host with the device (dense Linears): everything is ordered by streams and
+events, so the caller's next launches (the block's second forward, or the next block of a benchmark) queue up
+behind the chains.  The device-side flags of the reused factorisations are kept in `BlockSchedule.unverified`
+and asserted by `verify()` (the Quantizer calls it once, at the end of the model).
 """
 import contextlib
 import os
+import sys
+import time
 from typing import Any, Callable, Dict, List, Optional, Tuple
 
 import torch
@@ -71,16 +78,26 @@ class _Lane:
                 t.record_stream(self.main)
 
 
+def _zero_columns(w: torch.Tensor) -> torch.Tensor:
+    """bool[C]: columns of the Linear's weight that are zero in every row (gptq.py:307-308 looks for them)."""
+    return (w.detach().reshape(w.shape[0], -1) == 0).all(dim=0)
+
+
 class BlockSchedule:
+    unverified: List[torch.Tensor] = []  # device flags of speculative U reuses, see verify()
+
     def __init__(self, layers: Dict[str, nn.Module], make_handle: Callable[[nn.Module, str], GPTQ],
                  n_streams: Optional[int] = None, verbose: bool = False):
         self.handles: Dict[str, GPTQ] = {n: make_handle(l, n) for n, l in layers.items()}
+        self._zero_cols = {n: _zero_columns(l.weight) for n, l in layers.items()}
+        self._sharing = None  # ([follower names], host bool tensor "zero-column sets differ", event)
         for h in self.handles.values():
             h._scheduled = True  # the handle leaves threshold flushes to sample_done()
         self._seen: Dict[Any, Any] = {}  # per block call: input identity -> (leader handle, tensor kept alive)
         self.n_streams = int(os.environ.get("GQ_CHAIN_STREAMS", 4)) if n_streams is None else n_streams
         self.verbose = verbose
         self.stats = {"syrk_launches": 0, "allreduce_bytes": 0, "reused_U": 0, "own_U": 0, "refactorised": 0}
+        self.owners: Dict[str, Any] = {}  # name -> owner rank or "rows/<world>" of the last quantize()
 
     # ------------------------------------------------------------------ hook side
     def hook(self, name: str):
@@ -108,8 +125,44 @@ class BlockSchedule:
     def sample_done(self) -> None:
         """Called after every calibration sample (one forward of the block)."""
         self._seen.clear()
+        if self._sharing is None:
+            self._publish_sharing()
         if any(h._fill >= h.flush_tokens for h in self.handles.values()):
             self.flush()
+
+    def _publish_sharing(self) -> None:
+        """After the block's first sample: for every follower, "its weight's all-zero columns differ from its
+        leader's" is computed on the device and copied to pinned host memory behind an event."""
+        name_of = {id(h): n for n, h in self.handles.items()}
+        followers = [n for n, h in self.handles.items() if h.shared_H_with is not None]
+        host = ev = None
+        if followers:
+            neq = torch.stack([(self._zero_cols[n] != self._zero_cols[name_of[id(self.handles[n].shared_H_with)]]).any()
+                               for n in followers])
+            if neq.is_cuda:
+                host = torch.empty(len(followers), dtype=torch.bool, pin_memory=True)
+                host.copy_(neq, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(neq.device))
+            else:
+                host = neq
+        self._sharing = (followers, host, ev)
+
+    def _needs_own_factorisation(self) -> Dict[str, bool]:
+        if self._sharing is None or not self._sharing[0]:
+            return {}
+        followers, host, ev = self._sharing
+        if ev is not None:
+            ev.synchronize()  # recorded during the first sample of the block: long complete
+        return dict(zip(followers, host.tolist()))
+
+    @classmethod
+    def verify(cls) -> None:
+        """One host read for all blocks so far: no reused factorisation saw a different column set."""
+        flags, cls.unverified = cls.unverified, []
+        if flags and bool(torch.stack([f.reshape(()) for f in flags]).any().item()):
+            raise RuntimeError("a Linear reused its leader's Cholesky factor although their dead / zero-column sets "
+                               "differ (gq_w_prepare flag)")
 
     def leaders(self) -> List[GPTQ]:
         return [h for h in self.handles.values() if h.shared_H_with is None]
@@ -129,7 +182,7 @@ class BlockSchedule:
             rest, grids_tail = todo, []
         by_kind: Dict[Any, List[GPTQ]] = {}
         for h in rest:
-            by_kind.setdefault((h._buf.dtype, h._buf.device), []).append(h)
+            by_kind.setdefault((h._pending_dtype(), h._pending_device()), []).append(h)
         for grp in by_kind.values():
             grids += [grp[i:i + 8] for i in range(0, len(grp), 8)]
         grids += grids_tail
@@ -192,6 +245,7 @@ class BlockSchedule:
                 handles[n].owner_rank = r
             if any(h.allow_no_samples for h in handles.values()):
                 self._agree_on_sharing()
+            self.owners = {n: (f"rows/{world}" if h._row_split_active() else h.owner_rank) for n, h in handles.items()}
         dev = next(iter(handles.values())).W_device
         on_gpu = torch.device(dev).type == "cuda"
         main = torch.cuda.current_stream(dev) if on_gpu else None
@@ -223,12 +277,19 @@ class BlockSchedule:
             return (not any(handles[n]._row_split_active() for n in ns),
                     -sum(float(handles[n].d_row) * handles[n].d_col ** 2 for n in ns))
 
+        own = self._needs_own_factorisation()
         order = sorted(chains.values(), key=chain_cost)
-        streams = _chain_streams(dev, min(self.n_streams, len(order)))
+        # the costliest chain stays on the caller's stream (it ends last anyway), the others get side streams
+        on_main = 1 if os.environ.get("GQ_CHAIN_MAIN", "1") == "1" else 0
+        streams = [None] * on_main + _chain_streams(dev, min(self.n_streams, len(order)) - on_main)
         results: Dict[str, tuple] = {}
         deq: Dict[str, torch.Tensor] = {}
         lanes = []
+        trace = os.environ.get("GQ_SCHED_TRACE")
+        t_host = time.perf_counter()
         for k, names in enumerate(order):
+            if trace:
+                print(f"  [sched] +{1e3 * (time.perf_counter() - t_host):7.2f} ms: enqueue chain {k} {names}", file=sys.stderr)
             lane = _Lane(streams[k % len(streams)] if streams else None, main)
             lead = handles[names[0]].shared_H_with or handles[names[0]]
             lane.wait(ready.get(id(lead), start))
@@ -240,7 +301,15 @@ class BlockSchedule:
                     if self.verbose:
                         print(f"[rank {rank}] Quantizing {n} with {qtypes[n].name}.")
                     h.make_working_copy()
-                    res = h.compute(qtypes[n], defer_check=True)
+                    # follower with the same zero columns as its leader: reuse (flag kept for verify());
+                    # different: own factorisation; unknown (first fed after the first sample): checked below
+                    res = h.compute(qtypes[n], defer_check=True, own_U=own.get(n, False))
+                    if n in own and h._pending_mismatch is not None:
+                        BlockSchedule.unverified.append(h._pending_mismatch)
+                        h._pending_mismatch = None
+                        self.stats["reused_U"] += 1
+                    elif own.get(n, False):
+                        self.stats["refactorised"] += 1
                     results[n] = res
                     born += list(res)
                     if world == 1 and writeback:
@@ -253,11 +322,14 @@ class BlockSchedule:
             lanes.append((lane, born))
         for lane, born in lanes:
             lane.join(born)
+        if trace:
+            print(f"  [sched] +{1e3 * (time.perf_counter() - t_host):7.2f} ms: all chains enqueued", file=sys.stderr)
 
-        # a follower whose dead / zero-column set differs from its leader's needs its own factorisation
+        # followers whose sharing was not known after the block's first sample (an expert that got its first token
+        # later): the device flag is read now -- the one host sync, MoE blocks only
         pending = [(n, handles[n]._pending_mismatch) for n in results if handles[n]._pending_mismatch is not None]
         if pending:
-            flags = torch.cat([f.reshape(1) for _, f in pending]).tolist()  # the block's only host sync
+            flags = torch.cat([f.reshape(1) for _, f in pending]).tolist()
             for (n, _), bad in zip(pending, flags):
                 h = handles[n]
                 h._pending_mismatch = None
@@ -268,7 +340,7 @@ class BlockSchedule:
                     deq.pop(n, None)
                 else:
                     self.stats["reused_U"] += 1
-        self.stats["own_U"] += len(results) - len(pending)
+        self.stats["own_U"] = len(results) - self.stats["reused_U"]
 
         # ---- phase 2: exchange (same order on every rank), write-back
         out: Dict[str, tuple] = {}

@@ -24,12 +24,13 @@ int gptq_quantize(float*, const float*, int64_t, int64_t, int, int, int, const g
 size_t h_accumulate_workspace_bytes(int64_t, int64_t);
 int h_accumulate(float*, const void*, int, int64_t, int64_t, float, float, void*, size_t, hipStream_t);
 int h_accumulate_grouped(int, float* const*, const void* const*, const int64_t*, const int64_t*, const float*, const float*,
-                         int, void*, size_t, hipStream_t);
+                         int, void*, size_t, hipStream_t, const void* const* const*, const int64_t*);
 size_t h_prepare_workspace_bytes(int64_t, int64_t);
 int h_prepare(float*, float*, int64_t, int64_t, float, float*, int*, uint8_t*, void*, size_t, hipStream_t);
 int w_prepare(const uint8_t*, float*, int64_t, int64_t, int*, hipStream_t);
 int h_pack_upper(const float*, int64_t, float*, hipStream_t);
 int h_unpack_upper(const float*, int64_t, float*, hipStream_t);
+int h_stage(void*, const void*, int64_t, hipStream_t);
 }  // namespace gq
 
 #include <algorithm>
@@ -95,10 +96,27 @@ int gq_h_accumulate(float* H, const void* X, int x_dtype, int64_t T, int64_t C, 
 }
 
 int gq_h_accumulate_grouped(int n, float* const* H_host, const void* const* X_host, const int64_t* T_host,
-                            const int64_t* C_host, const float* beta_host, const float* alpha_host, int x_dtype, void* ws,
-                            size_t ws_bytes, void* stream) {
+                            const int64_t* C_host, const float* beta_host, const float* alpha_host, int x_dtype,
+                            void* ws, size_t ws_bytes, void* stream) {
     return h_accumulate_grouped(n, H_host, X_host, T_host, C_host, beta_host, alpha_host, x_dtype, ws, ws_bytes,
-                                (hipStream_t)stream);
+                                (hipStream_t)stream, nullptr, nullptr);
+}
+
+int gq_h_accumulate_segments(int n, float* const* H_host, const void* const* const* blocks_host, const int64_t* nblocks_host,
+                             const int64_t* block_tokens_host, const int64_t* C_host, const float* beta_host,
+                             const float* alpha_host, int x_dtype, void* ws, size_t ws_bytes, void* stream) {
+    if (n <= 0 || n > 8) GQ_FAIL(GQ_E_BAD_SHAPE, "gq_h_accumulate_segments: n=%d not in 1..8", n);
+    if (!blocks_host || !nblocks_host || !block_tokens_host) GQ_FAIL(GQ_E_NULL, "gq_h_accumulate_segments: null pointer");
+    const void* X[8];
+    int64_t T[8];
+    for (int i = 0; i < n; ++i) {
+        if (!blocks_host[i] || nblocks_host[i] <= 0 || block_tokens_host[i] <= 0)
+            GQ_FAIL(GQ_E_BAD_SHAPE, "gq_h_accumulate_segments: problem %d has no blocks", i);
+        X[i] = blocks_host[i][0];
+        T[i] = nblocks_host[i] * block_tokens_host[i];
+    }
+    return h_accumulate_grouped(n, H_host, X, T, C_host, beta_host, alpha_host, x_dtype, ws, ws_bytes, (hipStream_t)stream,
+                                blocks_host, nblocks_host);
 }
 
 int gq_h_prepare(float* H, float* W, int64_t R, int64_t C, float rel_damp, float* U, int* not_invertible,
@@ -110,6 +128,7 @@ int gq_w_prepare(const uint8_t* col_flags, float* W, int64_t R, int64_t C, int* 
     return w_prepare(col_flags, W, R, C, mismatch, (hipStream_t)stream);
 }
 
+int gq_h_stage(void* dst, const void* src, int64_t nbytes, void* stream) { return h_stage(dst, src, nbytes, (hipStream_t)stream); }
 int gq_h_pack_upper(const float* H, int64_t C, float* buf, void* stream) { return h_pack_upper(H, C, buf, (hipStream_t)stream); }
 int gq_h_unpack_upper(const float* buf, int64_t C, float* H, void* stream) { return h_unpack_upper(buf, C, H, (hipStream_t)stream); }
 

@@ -92,7 +92,18 @@ struct SyrkProblem {
     int64_t C, Tp;
     float beta, alpha;
     int tile_begin, nt;
+    // syrk16_256n_kernel only: X given as separate blocks of hs_per_seg * 32 tokens each (the per-sample activation
+    // tensors of the forward hooks, read where they lie); segs[k] = device address of block k.  0: Xt is contiguous.
+    const uint64_t* segs;
+    int hs_per_seg;
 };
+
+// scalar load that never overlaps the hand-counted lgkmcnt waits of the SYRK pipeline: issued and waited in one go
+__device__ __forceinline__ uint64_t sload64_now(const uint64_t* p) {
+    uint64_t v;
+    asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(v) : "s"(p) : "memory");
+    return v;
+}
 struct SyrkGroup {
     int n, total_tiles;
     SyrkProblem p[H_MAX_GROUP];
@@ -571,7 +582,20 @@ __global__ __launch_bounds__(512, 2) void syrk16_256n_kernel(const SyrkGroup grp
     // 8 (w & 3) .. +7 of every half-stage as four 1 KiB pieces of two rows each
     const int op = wid >> 2, rb = 8 * (wid & 3);
     const int64_t hstride = 32 * C * 2;        // bytes per half-stage
-    const char* gsrc = reinterpret_cast<const char*>(P.Xt) + (op ? tj : ti) * 512 + u0 * 4 * hstride;
+    const int64_t colofs = (op ? tj : ti) * 512;
+    const char* gsrc = reinterpret_cast<const char*>(P.Xt) + colofs + u0 * 4 * hstride;
+    // segmented X: half-stage (u0 * 4 + h) lies in block (..) / hs_per_seg at row 32 * ((..) % hs_per_seg)
+    int hsps = P.hs_per_seg, seg_within = 0;
+    const uint64_t* segp = P.segs;
+    const char* segbase = nullptr;
+    if (hsps) {
+        const int h0 = (int)(u0 * 4);
+        segp += h0 / hsps;
+        seg_within = h0 % hsps;
+        segbase = reinterpret_cast<const char*>(sload64_now(segp)) + colofs;
+        gsrc = segbase + (int64_t)seg_within * hstride;
+    }
+    asm volatile("" : "+s"(hsps), "+s"(segp));  // opaque SGPR values: never re-loaded from the kernel arguments
     unsigned voff0, voff1, voff2, voff3;
     {
         const int hrow = lane >> 5, s16 = lane & 31;
@@ -597,8 +621,19 @@ __global__ __launch_bounds__(512, 2) void syrk16_256n_kernel(const SyrkGroup grp
                  :: "v"(vo), "s"(gbase), "s"(ldsw + (unsigned)((slot_) * S_BUF_BYTES + (u) * 1024)) : "memory")
 #define GQ_NADV()                                                                                     \
     do {                                                                                              \
-        hnext = hnext + 1 < nhs ? hnext + 1 : nhs - 1;                                                \
-        gbase = gsrc + (int64_t)hnext * hstride;                                                      \
+        if (hnext + 1 < nhs) {                                                                        \
+            ++hnext;                                                                                  \
+            if (hsps) {                                                                               \
+                if (++seg_within == hsps) {                                                           \
+                    seg_within = 0;                                                                   \
+                    ++segp;                                                                           \
+                    segbase = reinterpret_cast<const char*>(sload64_now(segp)) + colofs;              \
+                }                                                                                     \
+                gbase = segbase + (int64_t)seg_within * hstride;                                      \
+            } else {                                                                                  \
+                gbase = gsrc + (int64_t)hnext * hstride;                                              \
+            }                                                                                         \
+        }                                                                                             \
     } while (0)
     // ---- fragment addresses (see header): lane = (k-group kc, row-in-group q, 8-byte chunk ch)
     unsigned bAlo, bAhi, bBlo, bBhi;
@@ -951,7 +986,7 @@ size_t h_accumulate_workspace_bytes(int64_t T, int64_t C) {
     const size_t nt = (size_t)(C / BT);
     const size_t ntile = nt * (nt + 1) / 2;
     // tile table + unit attributes + reduce list of the 256x256 kernels (K-split adds up to 512 units)
-    const size_t table = (ntile + 512 + 320) * 4 * 2 + 512 * 8 + 256;
+    const size_t table = (ntile + 512 + 320) * 4 * 2 + 512 * 8 + 256 + (size_t)(T / 128 + 2) * 8;  // + block addresses
     if (syrk_in_place(T, C)) return table + syrk_partial_slots(T, ntile) * (size_t)BT * BT * 4 + 256;
     const int64_t Tp = (T + 2 * HK - 1) / (2 * HK) * (2 * HK);
     return (size_t)C * (size_t)Tp * 2 + 256 + table;
@@ -961,7 +996,8 @@ size_t h_accumulate_workspace_bytes(int64_t T, int64_t C) {
 // image, 2 = 256x256 ring kernel reading X in place
 static int syrk16_launch(int kind, const int* idx, int m, float* const* H, const void* const* X, const int64_t* T,
                          const int64_t* C, const float* beta, const float* alpha, int x_dtype, unsigned char*& wp,
-                         unsigned char* ws_end, hipStream_t st) {
+                         unsigned char* ws_end, hipStream_t st, const void* const* const* segs = nullptr,
+                         const int64_t* nseg = nullptr) {
     const dim3 block(256);
     SyrkGroup grp;
     grp.n = m;
@@ -982,7 +1018,7 @@ static int syrk16_launch(int kind, const int* idx, int m, float* const* H, const
             Xt = img;
         }
         const int nt = (int)(C[i] / (kind ? BT : HT));
-        grp.p[k] = SyrkProblem{H[i], Xt, C[i], Tp, beta[i], alpha[i], tiles, nt};
+        grp.p[k] = SyrkProblem{H[i], Xt, C[i], Tp, beta[i], alpha[i], tiles, nt, nullptr, 0};
         if (!kind) {
             const int ns = (nt + 7) / 8;  // 8x8 super-tiles per dimension
             tiles += ns * (ns + 1) / 2;
@@ -1061,6 +1097,19 @@ static int syrk16_launch(int kind, const int* idx, int m, float* const* H, const
         }
         for (size_t t = 0; t < rlist.size(); ++t) table[2 * tl + t] = rlist[t];
         wp = reinterpret_cast<unsigned char*>(((uintptr_t)wp + 255) & ~(uintptr_t)255);
+        // block address lists of the problems whose X arrives in separate blocks, behind the tile table
+        if (table.size() & 1) table.push_back(0xffffffffu);
+        for (int k = 0; k < m && segs; ++k) {
+            const int i = idx[k];
+            if (!segs[i] || nseg[i] <= 1) continue;
+            grp.p[k].segs = reinterpret_cast<const uint64_t*>(wp + table.size() * 4);
+            grp.p[k].hs_per_seg = (int)(T[i] / nseg[i] / 32);
+            for (int64_t b = 0; b < nseg[i]; ++b) {
+                const uint64_t a = (uint64_t)(uintptr_t)segs[i][b];
+                table.push_back((uint32_t)a);
+                table.push_back((uint32_t)(a >> 32));
+            }
+        }
         if (wp + table.size() * 4 > ws_end) GQ_FAIL(GQ_E_WORKSPACE, "gq_h_accumulate: workspace too small for the tile table");
         GQ_HIP(hipMemcpyAsync(wp, table.data(), table.size() * 4, hipMemcpyHostToDevice, st));  // pageable: staged before return
         grp.table = reinterpret_cast<const uint32_t*>(wp);
@@ -1138,6 +1187,43 @@ __global__ __launch_bounds__(256) void h_unpack_upper_kernel(const float* __rest
     }
 }
 
+// Staging copy of the hook side (GPTQ.update keeps the activations of up to 64 Ki tokens until they are folded into H
+// by one long-K SYRK): a plain HBM-bound copy, 16-byte accesses, 4 loads in flight per thread.  A kernel instead
+// of hipMemcpyAsync: the runtime's blit path costs 20-40 us per call and serialises on the stream, 512 calls per
+// transformer block.
+__global__ __launch_bounds__(256) void stage_rows_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src, int64_t n16) {
+    const int64_t stride = (int64_t)gridDim.x * 256 * 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 * 4 + threadIdx.x; i < n16; i += stride) {
+        uint4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (i + k * 256 < n16) v[k] = src[i + k * 256];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (i + k * 256 < n16) dst[i + k * 256] = v[k];
+    }
+}
+__global__ __launch_bounds__(256) void stage_bytes_kernel(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
+}
+int h_stage(void* dst, const void* src, int64_t nbytes, hipStream_t st) {
+    if (nbytes < 0) GQ_FAIL(GQ_E_BAD_SHAPE, "gq_h_stage: nbytes=%ld", (long)nbytes);
+    if (nbytes == 0) return GQ_OK;
+    if (!dst || !src) GQ_FAIL(GQ_E_NULL, "gq_h_stage: null pointer");
+    if ((((uintptr_t)dst | (uintptr_t)src | (uintptr_t)nbytes) & 15) == 0) {
+        const int64_t n16 = nbytes / 16;
+        const int64_t wgs = (n16 + 1023) / 1024;
+        hipLaunchKernelGGL(stage_rows_kernel, dim3((unsigned)(wgs < 4096 ? wgs : 4096)), dim3(256), 0, st, (uint4*)dst,
+                           (const uint4*)src, n16);
+    } else {
+        const int64_t wgs = (nbytes + 255) / 256;
+        hipLaunchKernelGGL(stage_bytes_kernel, dim3((unsigned)(wgs < 4096 ? wgs : 4096)), dim3(256), 0, st, (uint8_t*)dst,
+                           (const uint8_t*)src, nbytes);
+    }
+    GQ_LAUNCH_CHECK();
+    return GQ_OK;
+}
+
 int h_pack_upper(const float* H, int64_t C, float* buf, hipStream_t st) {
     if (!H || !buf) GQ_FAIL(GQ_E_NULL, "gq_h_pack_upper: null pointer");
     if (C <= 0 || (C % HT)) GQ_FAIL(GQ_E_BAD_SHAPE, "gq_h_pack_upper: C=%ld (C %% 128 != 0)", (long)C);
@@ -1157,7 +1243,7 @@ int h_unpack_upper(const float* buf, int64_t C, float* H, hipStream_t st) {
 
 int h_accumulate_grouped(int n, float* const* H, const void* const* X, const int64_t* T, const int64_t* C,
                          const float* beta, const float* alpha, int x_dtype, void* ws, size_t ws_bytes,
-                         hipStream_t st) {
+                         hipStream_t st, const void* const* const* segs, const int64_t* nseg) {
     if (n <= 0 || n > H_MAX_GROUP) GQ_FAIL(GQ_E_BAD_SHAPE, "gq_h_accumulate_grouped: n=%d not in 1..%d", n, H_MAX_GROUP);
     if (!H || !X || !T || !C || !beta || !alpha) GQ_FAIL(GQ_E_NULL, "gq_h_accumulate_grouped: null pointer");
     const dim3 block(256);
@@ -1178,6 +1264,15 @@ int h_accumulate_grouped(int n, float* const* H, const void* const* X, const int
         if (!H[i] || !X[i]) GQ_FAIL(GQ_E_NULL, "gq_h_accumulate: null pointer");
         if (T[i] <= 0 || C[i] <= 0 || (C[i] % HT)) GQ_FAIL(GQ_E_BAD_SHAPE, "gq_h_accumulate: T=%ld C=%ld (C %% 128 != 0)", (long)T[i], (long)C[i]);
         need += h_accumulate_workspace_bytes(T[i], C[i]);
+        if (segs && segs[i] && nseg[i] > 1) {
+            // separate blocks are only read in place: whole ring turns per block, 16-byte aligned rows
+            if (T[i] % nseg[i] || (T[i] / nseg[i]) % (2 * HK) || !syrk_in_place(T[i], C[i]) || getenv("GQ_SYRK_128"))
+                GQ_FAIL(GQ_E_UNSUPPORTED, "gq_h_accumulate_segments: %ld blocks of %ld tokens, C=%ld: blocks must hold a "
+                        "multiple of 128 tokens and C %% 256 == 0 (stage the rows into one buffer instead)",
+                        (long)nseg[i], (long)(T[i] / nseg[i]), (long)C[i]);
+            for (int64_t b = 0; b < nseg[i]; ++b)
+                if (!segs[i][b] || ((uintptr_t)segs[i][b] & 15)) GQ_FAIL(GQ_E_NULL, "gq_h_accumulate_segments: block %ld of problem %d is null or not 16-byte aligned", (long)b, i);
+        }
     }
     if (!ws || ws_bytes < need) GQ_FAIL(GQ_E_WORKSPACE, "gq_h_accumulate: workspace %zu < %zu bytes", ws_bytes, need);
     static bool attr_set = false;
@@ -1202,7 +1297,8 @@ int h_accumulate_grouped(int n, float* const* H, const void* const* X, const int
     unsigned char* ws_end = reinterpret_cast<unsigned char*>(ws) + ws_bytes;
     for (int kind = 2; kind >= 0; --kind)
         if (cnt[kind]) {
-            const int rc = syrk16_launch(kind, idx[kind], cnt[kind], H, X, T, C, beta, alpha, x_dtype, wp, ws_end, st);
+            const int rc = syrk16_launch(kind, idx[kind], cnt[kind], H, X, T, C, beta, alpha, x_dtype, wp, ws_end, st,
+                                         kind == 2 ? segs : nullptr, nseg);
             if (rc) return rc;
         }
     return GQ_OK;
@@ -1210,7 +1306,7 @@ int h_accumulate_grouped(int n, float* const* H, const void* const* X, const int
 
 int h_accumulate(float* H, const void* X, int x_dtype, int64_t T, int64_t C, float beta, float alpha, void* ws,
                  size_t ws_bytes, hipStream_t st) {
-    return h_accumulate_grouped(1, &H, &X, &T, &C, &beta, &alpha, x_dtype, ws, ws_bytes, st);
+    return h_accumulate_grouped(1, &H, &X, &T, &C, &beta, &alpha, x_dtype, ws, ws_bytes, st, nullptr, nullptr);
 }
 
 }  // namespace gq

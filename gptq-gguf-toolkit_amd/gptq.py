@@ -7,6 +7,7 @@ Same constructor, same `update / quantize / reset` protocol and return order
   _prepare              -> gq_h_prepare      (K2 + K3)
   step                  -> gq_gptq_quantize  (K4 + K5 + K6)
 """
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -60,7 +61,10 @@ class GPTQ:
         # b samples at once give beta = n/(n+b), alpha = 2/(n+b), the telescoped form of b single updates
         self.flush_tokens = 1 << 16    # 65536 tokens per SYRK launch: the sweet spot measured in bench.py
         self._buf = None
-        self._fill = 0
+        self._fill = 0                 # pending tokens (kept blocks + staged rows)
+        self._staged = 0               # rows of _buf in use
+        self._segs = []                # zero-copy: (tensor, version at hook time) per pending sample
+        self._zero_copy = os.environ.get("GQ_STAGE_COPY") != "1"
         self._buf_b = 0
         self._U_cache = None
 
@@ -83,21 +87,47 @@ class GPTQ:
         if x.dtype not in (torch.float16, torch.bfloat16, torch.float32):
             x = x.float()
         t = x.shape[0]
-        if self._buf is not None and (self._buf.dtype != x.dtype or self._fill + t > self._buf.shape[0]):
-            self.flush()
-            if self._buf.dtype != x.dtype or t > self._buf.shape[0]:
-                self._buf = None  # a wider sample or another dtype than the buffer was sized for
-        if self._buf is None:
-            self._buf = torch.empty((max(self.flush_tokens, t), self.d_col), device=x.device, dtype=x.dtype)
-        self._buf[self._fill:self._fill + t].copy_(x)
+        # Zero-copy: the hook's tensor is kept (a reference, no copy) and the SYRK reads it where the forward left
+        # it (gq_h_accumulate_segments) -- as long as every pending sample is one contiguous 16-bit [L, C] block of
+        # the same L (a multiple of 128 tokens).  Anything else is staged into one buffer (gq_h_stage).
+        if self._zero_copy and self._staged == 0 and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) \
+                and x.is_contiguous() and t % 128 == 0 and self.d_col % 256 == 0 and x.data_ptr() % 16 == 0 \
+                and (not self._segs or (self._segs[0][0].shape == x.shape and self._segs[0][0].dtype == x.dtype)):
+            self._segs.append((x, x._version))
+        else:
+            self._stage(x)
         self._fill += t
         self._buf_b += batch_size
         if self._fill >= self.flush_tokens and not self._scheduled:
             self.flush()
 
+    def _stage(self, x: Tensor) -> None:
+        """Append x [t, C] to the staging buffer (behind the kept zero-copy blocks, which move into it first)."""
+        if self._pending_dtype() not in (None, x.dtype):
+            self.flush()  # one activation dtype per fold
+        pend, self._segs = [y for y, _ in self._segs], []
+        need = self._staged + sum(y.shape[0] for y in pend) + x.shape[0]
+        if self._buf is not None and (self._buf.dtype != x.dtype or need > self._buf.shape[0]):
+            if self._staged:  # the staged rows are exactly the samples counted so far (pend is empty in this mode)
+                self.flush()
+                need = x.shape[0]
+            self._buf = None
+        if self._buf is None:
+            self._buf = torch.empty((max(self.flush_tokens + x.shape[0], need), self.d_col), device=x.device,
+                                    dtype=x.dtype)
+        for y in pend + [x]:
+            _ops.h_stage(self._buf, self._staged, y)
+            self._staged += y.shape[0]
+
+    def _pending_dtype(self):
+        return self._segs[0][0].dtype if self._segs else (self._buf.dtype if self._buf is not None else None)
+
+    def _pending_device(self):
+        return self._segs[0][0].device if self._segs else (self._buf.device if self._buf is not None else None)
+
     @torch.no_grad()
     def flush(self) -> None:
-        """Fold the buffered activations into H (one gq_h_accumulate over all buffered tokens)."""
+        """Fold the pending activations into H (one gq_h_accumulate over all pending tokens)."""
         if self._fill == 0:
             return
         H, X, beta, alpha = self._flush_args()
@@ -105,14 +135,24 @@ class GPTQ:
         self._flush_done()
 
     def _flush_args(self):
-        """(H, X[T, C], beta, alpha) of the pending fold: b samples at once are the telescoped form of b single
-        updates of gptq.py:106-112."""
+        """(H, X, beta, alpha) of the pending fold; X is [T, C] or the list of kept [L, C] blocks.  b samples at
+        once are the telescoped form of b single updates of gptq.py:106-112."""
         n, b = self.num_samples, self._buf_b
-        return self.H, self._buf[:self._fill], n / (n + b), 2.0 / (n + b)
+        if self._segs:
+            for x, v in self._segs:
+                if x._version != v:
+                    raise RuntimeError("a Linear input was modified in place after its forward hook ran; set "
+                                       "GQ_STAGE_COPY=1 to copy activations at hook time")
+            X = [x for x, _ in self._segs]
+        else:
+            X = self._buf[:self._staged]
+        return self.H, X, n / (n + b), 2.0 / (n + b)
 
     def _flush_done(self) -> None:
         self.num_samples += self._buf_b
         self._fill = 0
+        self._staged = 0
+        self._segs = []
         self._buf_b = 0
 
     def reset(self) -> None:
@@ -124,6 +164,8 @@ class GPTQ:
         self._ws = None
         self._buf = None
         self._fill = 0
+        self._staged = 0
+        self._segs = []
         self._buf_b = 0
         self._reduced = False
         self.shared_H_with = None
@@ -173,7 +215,8 @@ class GPTQ:
 
     @torch.no_grad()
     def make_working_copy(self) -> None:
-        W = self.layer.weight.detach().clone().float()  # gptq.py:138
+        W = self.layer.weight.detach()
+        W = W.clone() if W.dtype == torch.float32 else W.float()  # gptq.py:138 (clone().float(): one pass, not two)
         if isinstance(self.layer, _ConvNd):
             W = W.flatten(1, -1)
         self.W = W.contiguous()
@@ -198,7 +241,7 @@ class GPTQ:
                 return U
         H = self.H.clone() if shared else self.H  # every reference handle damps its own copy
         U, self._flag, cf = _ops.h_prepare(H, self.W, self.rel_damp, want_flags=True)
-        if shared and leader._U_cache is None:
+        if shared and leader._U_cache is None and not own_U:
             leader._U_cache = (U, self._flag, cf)
         if not shared:
             self.H = H

@@ -55,7 +55,9 @@ def workspace_bytes(op: int, R=0, C=0, T=0, block_size=0) -> int:
 
 
 def h_accumulate(H: torch.Tensor, X: torch.Tensor, beta: float, alpha: float, ws: Optional[torch.Tensor] = None):
-    """H = beta*H + alpha * X^T X in place.  X: [T, C] fp16/bf16/fp32 contiguous."""
+    """H = beta*H + alpha * X^T X in place.  X: [T, C] fp16/bf16/fp32 contiguous (or a list of equal [L, C] blocks)."""
+    if isinstance(X, (list, tuple)):
+        return h_accumulate_grouped([H], [X], [beta], [alpha], ws)[0]
     _need_cuda(H, X)
     assert H.dtype == torch.float32 and H.is_contiguous() and X.is_contiguous() and X.dim() == 2
     T, C = X.shape
@@ -69,27 +71,53 @@ def h_accumulate(H: torch.Tensor, X: torch.Tensor, beta: float, alpha: float, ws
 
 
 def h_accumulate_grouped(Hs, Xs, betas, alphas, ws: Optional[torch.Tensor] = None):
-    """Up to 8 Hessians in one grid: Hs[i] = betas[i]*Hs[i] + alphas[i] * Xs[i]^T Xs[i]."""
+    """Up to 8 Hessians in one grid: Hs[i] = betas[i]*Hs[i] + alphas[i] * Xs[i]^T Xs[i].
+    Xs[i] is a [T, C] tensor, or a LIST of [L, C] tensors (equal L, contiguous): the per-sample activation
+    tensors of the forward hooks, read where they lie (gq_h_accumulate_segments)."""
     n = len(Hs)
     assert n == len(Xs) == len(betas) == len(alphas) and 1 <= n <= 8
-    _need_cuda(*Hs, *Xs)
-    dt = Xs[0].dtype
-    for H, X in zip(Hs, Xs):
-        assert H.dtype == torch.float32 and H.is_contiguous() and X.is_contiguous() and X.dim() == 2
-        assert X.dtype == dt and H.shape == (X.shape[1], X.shape[1])
-    need = sum(workspace_bytes(_cabi.WS_H_ACCUMULATE, 0, X.shape[1], X.shape[0]) for X in Xs)
+    blocks = [list(X) if isinstance(X, (list, tuple)) else [X] for X in Xs]
+    _need_cuda(*Hs, *[b for bl in blocks for b in bl])
+    dt = blocks[0][0].dtype
+    for H, bl in zip(Hs, blocks):
+        assert H.dtype == torch.float32 and H.is_contiguous()
+        for X in bl:
+            assert X.is_contiguous() and X.dim() == 2 and X.dtype == dt and X.shape == bl[0].shape
+        assert H.shape == (bl[0].shape[1], bl[0].shape[1])
+    Ts = [len(bl) * bl[0].shape[0] for bl in blocks]
+    need = sum(workspace_bytes(_cabi.WS_H_ACCUMULATE, 0, bl[0].shape[1], T) for bl, T in zip(blocks, Ts))
     if ws is None or ws.numel() < need:
-        ws = _ws(need, Xs[0].device)
+        ws = _ws(need, blocks[0][0].device)
     vp = ctypes.c_void_p
     Hp = (vp * n)(*[H.data_ptr() for H in Hs])
-    Xp = (vp * n)(*[X.data_ptr() for X in Xs])
-    Ts = (ctypes.c_int64 * n)(*[X.shape[0] for X in Xs])
-    Cs = (ctypes.c_int64 * n)(*[X.shape[1] for X in Xs])
+    Cs = (ctypes.c_int64 * n)(*[bl[0].shape[1] for bl in blocks])
     bs = (ctypes.c_float * n)(*[float(b) for b in betas])
     as_ = (ctypes.c_float * n)(*[float(a) for a in alphas])
-    check(lib().gq_h_accumulate_grouped(n, Hp, Xp, Ts, Cs, bs, as_, _DT[dt], _ptr(ws), ws.numel(), _stream(Xs[0])),
-          "gq_h_accumulate_grouped")
+    if all(len(bl) == 1 for bl in blocks):
+        Xp = (vp * n)(*[bl[0].data_ptr() for bl in blocks])
+        Tc = (ctypes.c_int64 * n)(*Ts)
+        check(lib().gq_h_accumulate_grouped(n, Hp, Xp, Tc, Cs, bs, as_, _DT[dt], _ptr(ws), ws.numel(),
+                                            _stream(blocks[0][0])), "gq_h_accumulate_grouped")
+        return Hs
+    lists = [(vp * len(bl))(*[X.data_ptr() for X in bl]) for bl in blocks]
+    Bp = (vp * n)(*[ctypes.cast(l, vp).value for l in lists])
+    nb = (ctypes.c_int64 * n)(*[len(bl) for bl in blocks])
+    bt = (ctypes.c_int64 * n)(*[bl[0].shape[0] for bl in blocks])
+    check(lib().gq_h_accumulate_segments(n, Hp, Bp, nb, bt, Cs, bs, as_, _DT[dt], _ptr(ws), ws.numel(),
+                                         _stream(blocks[0][0])), "gq_h_accumulate_segments")
     return Hs
+
+
+def h_stage(buf: torch.Tensor, fill: int, x: torch.Tensor):
+    """buf[fill : fill + T] = x  (x: [T, C] rows of activations, same dtype as the staging buffer `buf`)."""
+    _need_cuda(buf, x)
+    assert buf.is_contiguous() and buf.dtype == x.dtype and x.dim() == 2 and x.shape[1] == buf.shape[1]
+    assert fill + x.shape[0] <= buf.shape[0]
+    if not x.is_contiguous():
+        x = x.contiguous()
+    row = buf.shape[1] * buf.element_size()
+    check(lib().gq_h_stage(ctypes.c_void_p(buf.data_ptr() + fill * row), _ptr(x), x.shape[0] * row, _stream(buf)),
+          "gq_h_stage")
 
 
 def h_prepare(H: torch.Tensor, W: torch.Tensor, rel_damp: float, want_flags: bool = False):

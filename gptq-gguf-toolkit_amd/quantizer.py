@@ -236,6 +236,7 @@ class Quantizer:
                 self._quant_and_save_non_block(name, module.to(device), quant_config)
         if use_cache is not None:
             self.model.config.use_cache = use_cache
+        BlockSchedule.verify()  # the only host read of the reused-factorisation flags, all blocks at once
         ph.mark("rtn_post")
         dist_utils.barrier()
 

@@ -94,6 +94,22 @@ int gq_h_accumulate_grouped(int n, float* const* H_host, const void* const* X_ho
                             const int64_t* C_host, const float* beta_host, const float* alpha_host,
                             int x_dtype, void* ws, size_t ws_bytes, void* stream);
 
+/* The same with every X[i] given as nblocks[i] SEPARATE device blocks of block_tokens[i] x C[i] values each (row-major,
+   16-byte aligned, block_tokens % 128 == 0, C % 256 == 0; fp16 / bf16): the activation tensors the forward hooks
+   of gptq.py:79-114 receive, one per calibration sample, read where the forward left them -- no staging copy.
+   blocks_host[i] is a host array of nblocks[i] device pointers.  Results are bit-identical to the same rows laid
+   out contiguously.  GQ_E_UNSUPPORTED for shapes the in-place kernel does not take (use gq_h_stage then). */
+int gq_h_accumulate_segments(int n, float* const* H_host, const void* const* const* blocks_host,
+                             const int64_t* nblocks_host, const int64_t* block_tokens_host, const int64_t* C_host,
+                             const float* beta_host, const float* alpha_host, int x_dtype, void* ws, size_t ws_bytes,
+                             void* stream);
+
+/* hook side of gptq.py:96 (`input.reshape(-1, C)`, the activations GPTQ.update consumes): appends `nbytes` of
+   activation rows at `dst` inside the caller's staging buffer (device to device, any alignment).  The handle keeps
+   up to 64 Ki tokens and folds them into H with ONE gq_h_accumulate -- the telescoped form of the per-sample
+   updates of gptq.py:106-112. */
+int gq_h_stage(void* dst, const void* src, int64_t nbytes, void* stream);
+
 /* replaces gptq.py:134-135,141 (dead channels) + gptq.py:304-324 (_prepare) +
    linalg_utils.py:8-12: zero-column masking, damping, U = chol_upper(inv(H)).
    H and W are mutated exactly as in the reference (damping persists in H).

@@ -19,8 +19,14 @@ def _bits(t):
 
 def h_accumulate(H, X, beta, alpha, ws=None):
     calls["h_accumulate"] += 1
+    if isinstance(X, (list, tuple)):
+        X = torch.cat(list(X))
     H.copy_(torch.from_numpy(O.h_accumulate(H.numpy(), X.float().numpy(), beta, alpha)))
     return H
+
+
+def h_stage(buf, fill, x):
+    buf[fill:fill + x.shape[0]].copy_(x)
 
 
 def h_accumulate_grouped(Hs, Xs, betas, alphas, ws=None):

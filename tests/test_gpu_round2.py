@@ -110,10 +110,19 @@ def test_g3_elementwise_on_gpu(ops, name):
         assert np.array_equal(npy(q)[:, 0].astype(np.float32), qref), \
             f"{(npy(q)[:, 0].astype(np.float32) != qref).mean():.4%} of G3's quantize() results differ"
         assert bits_eq(npy(W)[:, 0], wref), "W[:, 0] after the column loop != dequantize(quantize(x))"
+    # a11 (quant_utils.py:277-310) starts from the STORED ints: the float -0.0 that round() gives for tiny negative
+    # inputs is 0 there, so dequantize(ints) == G3's w everywhere except the sign of those zeros
     Q = torch.zeros(n, 256, device="cuda", dtype=torch.int8 if sdt == np.int8 else torch.uint8)
     Q[:, 0] = dev(qref.astype(np.int8 if sdt == np.int8 else np.uint8))
-    deq = ops.dequantize(t, Q, dd, Sd, dm, Md)
-    assert bits_eq(npy(deq)[:, 0], wref), "gq_dequantize differs from the reference's dequantize()"
+    got = npy(ops.dequantize(t, Q, dd, Sd, dm, Md))[:, 0]
+    qi = qref.astype(np.int8 if sdt == np.int8 else np.uint8).astype(np.float32)
+    want = (d.view(np.float16).astype(np.float32) * s.astype(np.float32)) * qi \
+        - dmin.view(np.float16).astype(np.float32) * m.astype(np.float32)
+    assert np.array_equal(want, wref) and np.array_equal(np.signbit(want) != np.signbit(wref), (qref == 0) & np.signbit(qref) & (wref == 0))
+    bad = np.nonzero(got.view(np.uint32) != want.view(np.uint32))[0]
+    assert bad.size == 0, (f"gq_dequantize differs from the reference's dequantize() at {bad.size} of {n}: "
+                           + "; ".join(f"i={i} got={got[i]!r} want={want[i]!r} q={qref[i]} d={d[i]} s={s[i]} "
+                                       f"dmin={dmin[i]} m={m[i]}" for i in bad[:6]))
 
 
 # ----------------------------------------------------------------- full BASELINE shapes vs oracle row slices
@@ -187,15 +196,26 @@ def test_end_to_end_rates_vs_fp64_chain(ops, oracle):
     assert not bad
     u_err = float(np.abs(npy(U).astype(np.float64) - Uo).max() / np.abs(Uo).max())
     rows = slice(0, 1024)  # the oracle walks 1024 of the 4096 independent rows
-    Wd, oq, od, os_, odm, om = oracle.gptq_step(Wo[rows], Uo.astype(np.float32), 12, block_size=128)
-    ints = float((npy(q[rows]) != oq).mean())
-    sc = float(np.concatenate([(u16(d[rows]) != od).ravel(), (npy(s[rows]) != os_).ravel(),
-                               (u16(dmin[rows]) != odm).ravel(), (npy(m[rows]) != om).ravel()]).mean())
+    U32 = Uo.astype(np.float32)
+    Wd, oq, od, os_, odm, om = oracle.gptq_step(Wo[rows], U32, 12, block_size=128)
+
+    def rates(q_, d_, s_, dmin_, m_):
+        sc_ = np.concatenate([(d_ != od).ravel(), (s_ != os_).ravel(), (dmin_ != odm).ravel(), (m_ != om).ravel()])
+        return float((q_ != oq).mean()), float(sc_.mean())
+
+    ints, sc = rates(npy(q[rows]), u16(d[rows]), npy(s[rows]), u16(dmin[rows]), npy(m[rows]))
     dw = float(np.abs(npy(Wg[rows]) - Wd).max())
+    # the noise floor of the comparison: the same oracle with U perturbed by 1e-7 relative (below one fp32
+    # rounding).  The column loop's error feedback amplifies any last-bit difference over 4096 dependent steps.
+    rng = np.random.default_rng(0)
+    Un = (Uo * (1.0 + 1e-7 * rng.standard_normal(Uo.shape))).astype(np.float32)
+    _, nq, nd, ns, ndm, nm = oracle.gptq_step(Wo[rows], Un, 12, block_size=128)
+    f_ints, f_sc = rates(nq, nd, ns, ndm, nm)
     print(f"\n[tolerance] 4096x4096 Q4_K vs fp64 chain: H rel err {h_err:.2e}, U rel err {u_err:.2e}, "
-          f"ints differ {ints:.4%}, scale bytes differ {sc:.4%}, max |dW| {dw:.3e}")
-    assert h_err < 5e-6 and u_err < 1e-4
-    assert ints < 0.01 and sc < 0.01, (ints, sc)
+          f"ints differ {ints:.4%} (1e-7-noise floor {f_ints:.4%}), scale bytes differ {sc:.4%} (floor {f_sc:.4%}), "
+          f"max |dW| {dw:.3e}")
+    assert h_err < 1e-6 and u_err < 1e-5
+    assert ints < 2.0 * f_ints + 0.002 and sc < 2.0 * f_sc + 0.005, (ints, f_ints, sc, f_sc)
     assert dw < 0.05
 
 
@@ -255,6 +275,7 @@ def test_block_schedule_equals_per_handle_quantize(ops):
         ref_layer = torch.nn.Linear(l.in_features, l.out_features, bias=False, device="cuda", dtype=torch.float16)
         ref_layer.weight.data = W0[n].clone()
         h = GPTQ(ref_layer, rel_damp=0.01, block_size=128)
+        h.flush_tokens = 192  # the same fold cadence: H is a sum in launch order
         for i in range(6):
             h.update(xs[n][i])
         ref = h.quantize(qt[n])
@@ -360,3 +381,73 @@ def test_two_rank_gpu_run_vs_reference_two_rank_golden():
     mp.spawn(_g13_gpu_worker, args=(2, 25000 + os.getpid() % 2000, ret, backend), nprocs=2, join=True)
     rates = hl.check_g13(ret)
     print(f"\n[two ranks, {backend}] ints differing from the reference's 2-rank run: {rates}")
+
+
+# ----------------------------------------------------------------- zero-copy Hessian accumulation
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_h_accumulate_segments_equal_contiguous(ops, dt):
+    """gq_h_accumulate_segments (the per-sample activation tensors read where they lie) == the same rows in one
+    buffer, bit for bit: two problems in one grid, blocks of 256 and 2048 tokens, long enough for the K-split of
+    the last round (T >= 8192), beta != 0."""
+    torch.manual_seed(7)
+    shapes = [(2048, 6, 2048), (4096, 40, 256)]  # (C, blocks, tokens per block)
+    Hs_a, Hs_b, Xc, Xl = [], [], [], []
+    for C, nb, L in shapes:
+        blocks = [(torch.randn(L, C, device="cuda") * (1 + i % 3)).to(dt) for i in range(nb)]
+        pad = torch.empty(7 * 16, device="cuda")  # blocks are separate allocations at unrelated addresses
+        Xl.append(blocks)
+        Xc.append(torch.cat(blocks))
+        H0 = torch.randn(C, C, device="cuda")
+        H0 = H0 + H0.T
+        Hs_a.append(H0.clone())
+        Hs_b.append(H0.clone())
+        del pad
+    ops.h_accumulate_grouped(Hs_a, Xc, [0.25, 0.5], [0.01, 0.02])
+    ops.h_accumulate_grouped(Hs_b, Xl, [0.25, 0.5], [0.01, 0.02])
+    for a, b in zip(Hs_a, Hs_b):
+        assert torch.equal(a, b)
+    # one segmented problem next to one contiguous problem
+    Ha, Hb = [torch.zeros(2048, 2048, device="cuda"), torch.zeros(4096, 4096, device="cuda")], \
+             [torch.zeros(2048, 2048, device="cuda"), torch.zeros(4096, 4096, device="cuda")]
+    ops.h_accumulate_grouped(Ha, [Xc[0], Xc[1]], [0.0, 0.0], [1.0, 1.0])
+    ops.h_accumulate_grouped(Hb, [Xl[0], Xc[1]], [0.0, 0.0], [1.0, 1.0])
+    assert torch.equal(Ha[0], Hb[0]) and torch.equal(Ha[1], Hb[1])
+    from gptq_gguf_toolkit_amd._cabi import GQError
+    with pytest.raises(GQError, match="multiple of 128"):
+        ops.h_accumulate_grouped([torch.zeros(2048, 2048, device="cuda")],
+                                 [[torch.zeros(96, 2048, device="cuda", dtype=dt)] * 4], [0.0], [1.0])
+
+
+def test_handle_zero_copy_and_staged_paths_agree(ops):
+    """GPTQ.update keeps references to [L, C] hook tensors (zero copy) or stages ragged / odd inputs into one buffer
+    (gq_h_stage): same H either way; an input modified in place after its hook is reported, not silently used."""
+    from gptq_gguf_toolkit_amd.gptq import GPTQ
+    torch.manual_seed(2)
+    lin = torch.nn.Linear(1024, 64, bias=False, device="cuda", dtype=torch.float16)
+    xs = [(torch.randn(1, 256, 1024, device="cuda")).half() for _ in range(5)]
+    a = GPTQ(lin)
+    b = GPTQ(lin)
+    b._zero_copy = False
+    for x in xs:
+        a.update(x)
+        b.update(x)
+    assert len(a._segs) == 5 and a._staged == 0 and len(b._segs) == 0 and b._staged == 5 * 256
+    a.flush()
+    b.flush()
+    assert torch.equal(a.H, b.H) and a.num_samples == b.num_samples == 5
+    # ragged tail: 3 kept blocks, then a 100-token sample -> everything moves into the staging buffer, in order
+    c, d = GPTQ(lin), GPTQ(lin)
+    d._zero_copy = False
+    tail = torch.randn(1, 100, 1024, device="cuda").half()
+    for x in xs[:3] + [tail] + xs[3:]:
+        c.update(x)
+        d.update(x)
+    assert not c._segs and c._staged == 5 * 256 + 100
+    c.flush()
+    d.flush()
+    assert torch.equal(c.H, d.H)
+    e = GPTQ(lin)
+    e.update(xs[0])
+    xs[0].add_(1.0)
+    with pytest.raises(RuntimeError, match="modified in place"):
+        e.flush()
