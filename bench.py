@@ -277,7 +277,12 @@ def tolerance_parity(wl, W16, X, n_seq=8):
         t0 = time.perf_counter()
         H64 = (2.0 / n_seq) * (xs.double().T @ xs.double())  # fp64 reference Hessian (torch, on the GPU)
         h_err = float((H.double() - H64).abs().max() / H64.abs().max())
-        Uo, _, Wo, bad = O.h_prepare_f64(H64.cpu().numpy(), Wf.cpu().numpy(), 0.01)  # fp64 LAPACK chain
+        # gptq.py:304-324 in fp64 (torch.linalg on the GPU: the host LAPACK of the box takes a minute at C = 4096)
+        Hd = H64.clone()
+        Hd.diagonal().add_(0.01 * Hd.diagonal().mean())
+        Uo = torch.linalg.cholesky(torch.cholesky_inverse(torch.linalg.cholesky(Hd)), upper=True).cpu().numpy()
+        Wo = Wf.cpu().numpy()
+        del Hd
         U32 = Uo.astype(np.float32)
         Wd, oq, od, os_, odm, om = O.gptq_step(Wo, U32, q_type, block_size=128)
         rng = np.random.default_rng(0)
@@ -298,7 +303,7 @@ def tolerance_parity(wl, W16, X, n_seq=8):
                 "ulp_noise_floor": {"ints_differ": float((nq != oq).mean()),
                                     "scale_bytes_differ": scale_rate((nd, ns, ndm, nm), (od, os_, odm, om))},
                 "checker_s": round(dt, 1),
-                "vs": "fp64 H (torch), fp64 LAPACK Cholesky chain, the oracle's C restatement of GPTQ.step"}
+                "vs": "fp64 H and fp64 Cholesky chain (torch.linalg), the oracle's C restatement of GPTQ.step"}
     except Exception as e:
         return {"error": repr(e)}
 

@@ -117,8 +117,10 @@ def main(argv=None):
     device = f"cuda:{int(os.environ.get('LOCAL_RANK', rank))}"
     torch.cuda.set_device(device)
 
+    import transformers
+    dtype_kw = "dtype" if int(transformers.__version__.split(".")[0]) >= 5 else "torch_dtype"  # renamed in 5.x
     model = AutoModelForCausalLM.from_pretrained(
-        args.model_name_or_path, trust_remote_code=True, torch_dtype=args.dtype,
+        args.model_name_or_path, trust_remote_code=True, **{dtype_kw: args.dtype},
         low_cpu_mem_usage=args.low_cpu_mem_usage, attn_implementation=args.attn_implementation)
     if not args.cpu_offload_modules:
         model = model.to(device)

@@ -218,32 +218,6 @@ def h_prepare(H, W, rel_damp=0.01):
     return U, H, W, bool(bad)
 
 
-def h_prepare_f64(H, W, rel_damp=0.01):
-    """gptq.py:134-141, 304-324 with the Cholesky chain in fp64 LAPACK (numpy / scipy): the accuracy anchor for
-    the tolerance-class stage at sizes where the scalar C loop of gqo_h_prepare would take minutes.
-    H may be fp64 (e.g. an fp64 X^T X).  Returns (U fp64, H_mutated fp64, W_mutated fp32, not_invertible)."""
-    import scipy.linalg as sl
-    H = np.array(H, np.float64, order="C", copy=True)
-    W = np.array(W, np.float32, order="C", copy=True)
-    C = H.shape[0]
-    idx = np.arange(C)
-    dead = np.diag(H) == 0
-    H[idx[dead], idx[dead]] = 1.0
-    W[:, dead] = 0.0
-    zc = (W == 0).all(axis=0)
-    H[zc, :] = 0.0
-    H[:, zc] = 0.0
-    H[idx[zc], idx[zc]] = 1.0
-    H[idx, idx] += rel_damp * np.mean(np.diag(H))
-    try:
-        L = np.linalg.cholesky(H)
-        Hinv = sl.cho_solve((L, True), np.eye(C))
-        U = sl.cholesky((Hinv + Hinv.T) * 0.5, lower=False)
-        return U, H, W, False
-    except np.linalg.LinAlgError:
-        return np.eye(C), H, W, True
-
-
 def make_quants_lp(x, q_type, rmode, rmin=-1.0, rdelta=0.1, nstep=20):
     """make_k_quants / make_quants on x[n,G] with fp16 (rmode=1) / bf16 (rmode=2) / fp32 (0) per-op rounding."""
     ti = type_info(q_type)

@@ -49,7 +49,13 @@ def test_driver_tree_vs_reference(quantized):
     # RTN modules have no Hessian: bit-exact.  GPTQ modules: H comes from a GPU forward + MFMA SYRK vs the
     # reference's CPU forward + MKL addmm, so near-tie flips are expected (0.1-0.8 % on CPU alone).
     assert rates["model.embed_tokens"] == 0.0 and rates["lm_head"] == 0.0, rates
-    assert max(rates.values()) < 0.06, rates
+    print("\n[driver vs reference tree] share of differing ints per module:")
+    for n, r in rates.items():
+        print(f"    {n:40s} {r:.4%}")
+    # measured on MI355X (r02): block 0 <= 0.04 %, block 1 (fed by the quantized block 0) 0.1-0.55 % and 2.3 % for
+    # the Q3_K down_proj; C = 256 / 512, so the cascade of near-tie flips through
+    # the error feedback is short (see test_end_to_end_rates_vs_fp64_chain for the noise floor at C = 4096)
+    assert max(rates.values()) < 0.04 and max(v for k, v in rates.items() if ".layers.0." in k) < 0.002, rates
     with torch.no_grad():
         from make_golden_shim import tiny_calib
         logits = model(tiny_calib()[0].cuda()).logits[0, :4, :16].cpu().numpy()
@@ -64,7 +70,7 @@ def test_pack_into_gguf(quantized, tmp_path):
     _, save_dir = quantized
     hf = tmp_path / "hf"
     tiny_llama().save_pretrained(str(hf), safe_serialization=True)
-    out = convert(hf, __import__("pathlib").Path(save_dir), tmp_path / "m.gguf", "f16")
+    out = convert(hf, __import__("pathlib").Path(save_dir), tmp_path / "m.gguf", "f16", vocab=False)
     kv, ts = read_gguf(str(out))
     cfg = json.load(open(hf / "config.json"))
     assert kv["general.architecture"] == "llama" and kv["llama.block_count"] == 2
@@ -87,3 +93,57 @@ def test_pack_into_gguf(quantized, tmp_path):
         assert np.array_equal(codes, five[0].numpy().astype(np.int32))
     norm = ts["blk.0.attn_norm.weight"]
     assert norm[1] == 0 and norm[0] == (256,)  # 1-D stays F32
+
+
+def test_cli_quant_then_pack(tmp_path):
+    """a20: the CLI surface end to end -- `quant.py main([...])` with run_quant.sh's flags on a saved tiny Llama and a
+    .pt calibration file (model load -> calibration sharding -> Quantizer -> "Quantization took"), then
+    `pack_gptq_into_gguf.py main([...])`; the tree is checked against the reference driver's (G10), the GGUF read back."""
+    from make_golden_shim import MIXED, tiny_calib, tiny_llama
+    from gptq_gguf_toolkit_amd import pack_gptq_into_gguf, quant
+    from gptq_gguf_toolkit_amd.gguf_writer import read_gguf
+    hf, save = tmp_path / "hf", tmp_path / "quantized"
+    tiny_llama().save_pretrained(str(hf), safe_serialization=True)
+    torch.save(tiny_calib(), str(tmp_path / "calib.pt"))
+    (tmp_path / "bits.json").write_text(json.dumps(MIXED))
+    import io
+    from contextlib import redirect_stdout
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        quant.main(["--model_name_or_path", str(hf), "--quantizable_modules", r".*layers.*((q|k|v|o|gate|up|down)_proj)$",
+                    "--pre_block_modules", "model.embed_tokens", "--block_modules", "model.layers",
+                    "--post_block_modules", "lm_head", "--quant_non_block_modules", "--calibration_data",
+                    str(tmp_path / "calib.pt"), "--calibration_tokens", str(8 * 64), "--calibration_sequence_length", "64",
+                    "--quant_scale", "absmax", "--rel_damp", "0.01", "--block_size", "128", "--default_bit_width", "Q4_K",
+                    "--bit_width_configuration", str(tmp_path / "bits.json"), "--rmin", "-1.0", "--rdelta", "0.1",
+                    "--nstep", "20", "--dtype", "float32", "--seed", "0", "--attn_implementation", "eager",
+                    "--save_dir", str(save)])
+    assert "Quantization took" in buf.getvalue()
+    g = load_golden("g10_driver")
+    assert sorted(os.listdir(save)) == list(g["names"])
+    for n in g["names"]:
+        d = torch.load(os.path.join(save, n, "data.pth"), weights_only=True)
+        assert d["q_type"] == int(g[f"{n}|q_type"]) and tuple(d["qweight"].shape) == g[f"{n}|qweight"].shape
+        assert float((d["qweight"].numpy() != g[f"{n}|qweight"]).mean()) < 0.04
+    pack_gptq_into_gguf.main([str(hf), "--dir_model_quant", str(save), "--outfile", str(tmp_path / "m.gguf"),
+                              "--outtype", "f16", "--no_vocab"])
+    kv, ts = read_gguf(str(tmp_path / "m.gguf"))
+    assert kv["general.architecture"] == "llama" and kv["llama.block_count"] == 2 and len(ts) == 2 * 9 + 3
+    assert ts["blk.1.ffn_down.weight"][1] == 11 and ts["token_embd.weight"][1] == 14  # Q3_K / Q6_K per MIXED
+
+
+def test_moe_driver_on_gpu(tmp_path):
+    """f3: a Mixtral-layout model (per-expert nn.Linear w1/w2/w3) through the driver on the GPU: ragged [tokens, C]
+    expert inputs, an expert that never gets a token (H = I), Q3_K experts / Q6_K attention; then the packer stacks
+    the experts' payloads."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_host_logic_cpu as hl
+    from tiny_moe import moe_calib
+    model, drv = hl._run_moe_driver(str(tmp_path), moe_calib("AB"), device="cuda:0")
+    torch.cuda.synchronize()
+    hl.check_moe_tree(str(tmp_path))
+    with torch.no_grad():
+        logits = model(moe_calib("AB")[0].cuda())
+    assert bool(torch.isfinite(logits).all())
+    idle = torch.load(os.path.join(tmp_path, "model.layers.0.block_sparse_moe.experts.4.w2", "data.pth"), weights_only=True)
+    assert idle["qweight"].abs().sum() > 0  # quantized by round-to-nearest on H = I, not skipped

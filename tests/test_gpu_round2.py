@@ -192,8 +192,10 @@ def test_end_to_end_rates_vs_fp64_chain(ops, oracle):
     q, d, s, dmin, m = ops.gptq_quantize(Wg, U, 12, 128)
     H64 = (2.0 / 8) * (X.double().T @ X.double())  # fp64 reference of the Hessian (torch, on the GPU)
     h_err = float((H.double() - H64).abs().max() / H64.abs().max())
-    Uo, _, Wo, bad = oracle.h_prepare_f64(H64.cpu().numpy(), npy(W0), 0.01)
-    assert not bad
+    Hd = H64.clone()  # gptq.py:304-324 in fp64 (no dead channel / zero column in this input)
+    Hd.diagonal().add_(0.01 * Hd.diagonal().mean())
+    Uo = torch.linalg.cholesky(torch.cholesky_inverse(torch.linalg.cholesky(Hd)), upper=True).cpu().numpy()
+    Wo = npy(W0)
     u_err = float(np.abs(npy(U).astype(np.float64) - Uo).max() / np.abs(Uo).max())
     rows = slice(0, 1024)  # the oracle walks 1024 of the 4096 independent rows
     U32 = Uo.astype(np.float32)

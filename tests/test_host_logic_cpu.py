@@ -395,3 +395,215 @@ def test_two_rank_run_vs_reference_two_rank_golden(oracle):
         _, q, d, s, dmin, m = oracle.gptq_step(W, U, qt, block_size=128)
         assert np.array_equal(q, g[f"{tag}_q"]) and np.array_equal(d, g[f"{tag}_d"]) and np.array_equal(s, g[f"{tag}_s"])
         assert np.array_equal(dmin, g[f"{tag}_dmin"]) and np.array_equal(m, g[f"{tag}_m"])
+
+
+# --------------------------------------------------------------------------- Mixtral-style MoE blocks (f3)
+MOE_QCFG = {"q_proj": "Q6_K", "k_proj": "Q6_K", "v_proj": "Q6_K", "o_proj": "Q6_K", "w1": "Q3_K", "w2": "Q3_K",
+            "w3": "Q3_K", "embed_tokens": "Q6_K", "lm_head": "Q6_K"}
+
+
+def _run_moe_driver(save_dir, ids, device="cpu"):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from tiny_moe import MOE_REGEX, TinyMoE
+    from gptq_gguf_toolkit_amd.quant_utils import GGMLQuantizationType as T
+    from gptq_gguf_toolkit_amd.quantizer import Quantizer
+    model = TinyMoE().to(device)
+    data = [([], {"input_ids": t}) for t in ids]
+    drv = Quantizer(model, data_loader=data, quantizable_modules=MOE_REGEX,
+                    quantizer_kwargs=dict(rel_damp=0.01, block_size=128, act_order=False, quant_scale="absmax",
+                                          static_groups=False, rmin=-1.0, rdelta=0.1, nstep=20, verbose=False),
+                    pre_block_modules=["model.embed_tokens"], block_modules="model.layers",
+                    post_block_modules=["lm_head"], quant_non_block_modules=True, device=device, save_dir=save_dir)
+    drv.quantize({k: T[v] for k, v in MOE_QCFG.items()})
+    return model, drv
+
+
+def _worker_moe_driver(rank, world, port, tmp, ret, device="cpu", backend="gloo"):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    if device == "cpu":
+        import fake_ops
+        fake_ops.install()
+    from tiny_moe import moe_calib
+    ids = moe_calib("A" if rank == 0 else "B")  # rank 0 routes to experts {0, 1} only, rank 1 to {2, 3} only
+    model, drv = _run_moe_driver(tmp, ids, device)
+    ret[rank] = {k: v.cpu().clone() for k, v in model.state_dict().items()}
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def check_moe_tree(save_dir, n_layers=2, n_experts=5):
+    names = sorted(os.listdir(save_dir))
+    want = ["lm_head", "model.embed_tokens"]
+    for i in range(n_layers):
+        want += [f"model.layers.{i}.self_attn.{p}_proj" for p in "qkvo"]
+        want += [f"model.layers.{i}.block_sparse_moe.experts.{e}.w{k}" for e in range(n_experts) for k in (1, 2, 3)]
+    assert names == sorted(want)
+    for n in names:
+        d = torch.load(os.path.join(save_dir, n, "data.pth"), weights_only=True)
+        is_expert = ".experts." in n
+        assert d["q_type"] == (11 if is_expert else 14)
+        assert d["qweight"].dtype == torch.int8 and int(d["qweight"].min()) >= (-4 if is_expert else -32)
+
+
+def test_moe_driver_single_rank_with_idle_expert(tmp_path):
+    """A Mixtral-layout block through the Quantizer driver: expert Linears see [tokens, C] inputs, w1/w3 of an
+    expert share one Hessian, the expert no token is routed to gets H = I and is still quantized and saved."""
+    import fake_ops
+    from tiny_moe import moe_calib
+    fake_ops.install()
+    model, drv = _run_moe_driver(str(tmp_path), moe_calib("AB"))
+    check_moe_tree(str(tmp_path))
+    # per block: 4 routed experts x (w1/w3 shared + w2) + attention (q/k/v shared + o) = 10 Hessians accumulated;
+    # the idle expert has none (H = I), its w1 / w3 / w2 are three independent identity "factorisations"
+    assert fake_ops.calls["h_accumulate"] == 2 * 10
+    assert drv.schedule_stats["reused_U"] == 4 + 2  # 4 x w3 + k, v (last block's stats)
+
+
+def test_moe_two_ranks_with_rank_local_experts(tmp_path):
+    """experts that receive tokens on ONE rank only.  The rank without tokens never fires the hooks, so it
+    cannot know that w1 and w3 share an input; the sharing pattern (hence the number of collectives) is agreed on
+    across ranks before the first all-reduce.  Both ranks must end with the same model, equal to the single-rank run
+    on the union of the calibration data up to the tolerance-class stages."""
+    from tiny_moe import moe_calib
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    d2 = str(tmp_path / "w2")
+    os.makedirs(d2)
+    mp.spawn(_worker_moe_driver, args=(2, 26000 + os.getpid() % 2000, d2, ret), nprocs=2, join=True)
+    for k in ret[0]:
+        assert torch.equal(ret[0][k], ret[1][k]), f"ranks disagree on {k}"
+    check_moe_tree(d2)
+    import fake_ops
+    fake_ops.install()
+    d1 = str(tmp_path / "w1")
+    os.makedirs(d1)
+    _run_moe_driver(d1, moe_calib("AB"))
+    tot = diff = 0
+    for n in sorted(os.listdir(d1)):
+        a = torch.load(os.path.join(d1, n, "data.pth"), weights_only=True)["qweight"]
+        b = torch.load(os.path.join(d2, n, "data.pth"), weights_only=True)["qweight"]
+        tot += a.numel()
+        diff += int((a != b).sum())
+    assert diff / tot < 0.02, f"{diff / tot:.3%} ints differ between the 1-rank and the 2-rank MoE runs"
+
+
+# --------------------------------------------------------------------------- GGUF container bytes (f1)
+def test_gguf_container_bytes_vs_independent_spec_writer(tmp_path):
+    """Byte-level golden from an independent serialiser written from the GGUF v3 spec (tests/gguf_spec_writer.py):
+    header, value-type ids, string / array encoding, tensor-info order (ne[0] innermost), offsets and the 32-byte
+    alignment of every tensor, for F32 / F16 / BF16 / K-quant payloads in 1, 2 and 3 dimensions."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from gguf_spec_writer import serialise
+    from gptq_gguf_toolkit_amd.gguf_writer import GGMLType, GGUFValueType, GGUFWriter
+    rng = np.random.default_rng(0)
+    f32 = rng.standard_normal(7).astype(np.float32)                  # 28 bytes: needs padding
+    f16 = rng.standard_normal((3, 5)).astype(np.float16)             # 30 bytes
+    q4 = rng.integers(0, 256, (5, 2 * 144), dtype=np.uint8)          # Q4_K [5, 512]
+    q3e = rng.integers(0, 256, (4, 3, 110), dtype=np.uint8)          # stacked experts: Q3_K [4, 3, 256]
+    bf = rng.integers(0, 65536, (2, 6), dtype=np.uint16)             # BF16 [2, 6] as bytes
+    w = GGUFWriter(str(tmp_path / "a.gguf"), "llama")
+    w.add_string("general.type", "model")
+    w.add_uint32("llama.block_count", 2)
+    w.add_float32("llama.rope.freq_base", 500000.0)
+    w.add_bool("tokenizer.ggml.add_space_prefix", False)
+    w.add_array("tokenizer.ggml.tokens", ["a", "bc", "déf", ""], GGUFValueType.STRING)
+    w.add_array("tokenizer.ggml.token_type", [1, 1, 3, 5], GGUFValueType.INT32)
+    w.add_tensor("rope_freqs.weight", f32)
+    w.add_tensor("a.weight", f16)
+    w.add_tensor("blk.0.attn_q.weight", q4, raw_dtype=GGMLType.Q4_K)
+    w.add_tensor("blk.0.ffn_down_exps.weight", q3e, raw_dtype=GGMLType.Q3_K)
+    w.add_tensor("b.weight", bf.view(np.uint8).reshape(2, 12), raw_dtype=GGMLType.BF16)
+    w.write()
+    want = serialise(
+        [("general.architecture", "str", "llama"), ("general.type", "str", "model"), ("llama.block_count", "u32", 2),
+         ("llama.rope.freq_base", "f32", 500000.0), ("tokenizer.ggml.add_space_prefix", "bool", False),
+         ("tokenizer.ggml.tokens", ("arr", "str"), ["a", "bc", "déf", ""]),
+         ("tokenizer.ggml.token_type", ("arr", "i32"), [1, 1, 3, 5])],
+        [("rope_freqs.weight", (7,), "F32", f32.tobytes()), ("a.weight", (3, 5), "F16", f16.tobytes()),
+         ("blk.0.attn_q.weight", (5, 512), "Q4_K", q4.tobytes()),
+         ("blk.0.ffn_down_exps.weight", (4, 3, 256), "Q3_K", q3e.tobytes()), ("b.weight", (2, 6), "BF16", bf.tobytes())])
+    got = open(tmp_path / "a.gguf", "rb").read()
+    assert got == want, f"first differing byte at {next(i for i, (x, y) in enumerate(zip(got, want)) if x != y)}"
+
+
+def test_packer_metadata_order_rope_freqs_and_experts(tmp_path, monkeypatch):
+    """convert(): the Llama KV set in the reference's order (pack_gptq_into_gguf.py:412-441, :594-638, :2160-2175),
+    rope_freqs.weight first for rope_type llama3 (:2259-2287), linear scaling keys, loud refusal of
+    other scaling types and of SentencePiece vocabularies, and Mixtral's router + stacked expert tensors."""
+    import fake_ops
+    from safetensors.torch import save_file
+    from gptq_gguf_toolkit_amd import packing_utils
+    from gptq_gguf_toolkit_amd.gguf_writer import read_gguf
+    from gptq_gguf_toolkit_amd.pack_gptq_into_gguf import convert, rope_freqs_llama3
+    monkeypatch.setattr(packing_utils, "_ops", fake_ops)  # no GPU here: the oracle's bit-packer stands in
+    monkeypatch.setattr(packing_utils, "_dev", lambda t: t.contiguous())
+    h, ffn, L, E = 256, 512, 1, 3
+    cfg = {"architectures": ["MixtralForCausalLM"], "hidden_size": h, "intermediate_size": ffn, "num_hidden_layers": L,
+           "num_attention_heads": 4, "num_key_value_heads": 2, "vocab_size": 64, "max_position_embeddings": 128,
+           "rms_norm_eps": 1e-5, "rope_theta": 500000.0, "num_local_experts": E, "num_experts_per_tok": 2,
+           "rope_scaling": {"rope_type": "llama3", "factor": 32.0, "low_freq_factor": 1.0, "high_freq_factor": 4.0,
+                            "original_max_position_embeddings": 64}}
+    g = torch.Generator().manual_seed(0)
+    sd = {"model.embed_tokens.weight": torch.randn(64, h, generator=g), "model.norm.weight": torch.ones(h),
+          "lm_head.weight": torch.randn(64, h, generator=g)}
+    p = "model.layers.0."
+    for n, shape in (("self_attn.q_proj", (h, h)), ("self_attn.k_proj", (h // 2, h)), ("self_attn.v_proj", (h // 2, h)),
+                     ("self_attn.o_proj", (h, h)), ("block_sparse_moe.gate", (E, h))):
+        sd[p + n + ".weight"] = torch.randn(*shape, generator=g)
+    sd[p + "input_layernorm.weight"] = torch.ones(h)
+    sd[p + "post_attention_layernorm.weight"] = torch.ones(h)
+    for e in range(E):
+        for wid, shape in (("w1", (ffn, h)), ("w2", (h, ffn)), ("w3", (ffn, h))):
+            sd[f"{p}block_sparse_moe.experts.{e}.{wid}.weight"] = torch.randn(*shape, generator=g)
+    hf = tmp_path / "hf"
+    hf.mkdir()
+    save_file(sd, str(hf / "model.safetensors"))
+    (hf / "config.json").write_text(json.dumps(cfg))
+    # quantized results for the w2 experts only (Q3_K, signed ints) -- written as the driver writes them
+    qdir = tmp_path / "q"
+    for e in range(E):
+        d = qdir / f"model.layers.0.block_sparse_moe.experts.{e}.w2"
+        d.mkdir(parents=True)
+        torch.save({"q_type": 11, "qweight": torch.randint(-4, 4, (h, ffn), generator=g).to(torch.int8),
+                    "super_group_scale": torch.rand(h, ffn // 256, generator=g).half(),
+                    "super_group_zero": torch.zeros(h, ffn // 256).half(),
+                    "group_scale_quant": torch.randint(0, 32, (h, ffn // 16), generator=g).to(torch.int8),
+                    "group_zero_quant": torch.zeros(h, ffn // 16).to(torch.int8)}, str(d / "data.pth"))
+    out = convert(hf, qdir, tmp_path / "m.gguf", "f16", vocab=False)
+    kv, ts = read_gguf(str(out))
+    assert list(kv) == ["general.architecture", "general.type", "general.name", "general.size_label", "llama.block_count",
+                        "llama.context_length", "llama.embedding_length", "llama.feed_forward_length",
+                        "llama.attention.head_count", "llama.attention.head_count_kv", "llama.rope.freq_base",
+                        "llama.attention.layer_norm_rms_epsilon", "llama.expert_count", "llama.expert_used_count",
+                        "general.file_type", "llama.vocab_size", "llama.rope.dimension_count",
+                        "general.quantization_version"]
+    assert kv["llama.expert_count"] == E and kv["llama.rope.dimension_count"] == 64
+    assert list(ts)[0] == "rope_freqs.weight"  # generate_extra_tensors() leads the chain (:290)
+    assert np.array_equal(ts["rope_freqs.weight"][2].view(np.float32), rope_freqs_llama3(cfg).numpy())
+    assert ts["blk.0.ffn_gate_inp.weight"][1] == 0  # the router stays F32 (:358-376)
+    shape, gt, raw = ts["blk.0.ffn_down_exps.weight"]
+    assert shape == (E, h, ffn) and gt == 11 and raw.size == E * h * ffn // 256 * 110
+    d1 = torch.load(str(qdir / "model.layers.0.block_sparse_moe.experts.1.w2" / "data.pth"), weights_only=True)
+    want = packing_utils.pack_tensor(11, d1["qweight"], d1["super_group_scale"], d1["group_scale_quant"],
+                                     d1["super_group_zero"], d1["group_zero_quant"])
+    assert np.array_equal(raw.reshape(E, h, -1)[1], want)  # expert 1's packed rows sit at index 1 of the stack
+    assert ts["blk.0.ffn_gate_exps.weight"][0] == (E, ffn, h) and ts["blk.0.ffn_gate_exps.weight"][1] == 1  # F16
+    cfg["rope_scaling"] = {"type": "linear", "factor": 4.0}
+    (hf / "config.json").write_text(json.dumps(cfg))
+    kv, ts = read_gguf(str(convert(hf, qdir, tmp_path / "m2.gguf", "f16", vocab=False)))
+    assert kv["llama.rope.scaling.type"] == "linear" and kv["llama.rope.scaling.factor"] == 4.0 and "rope_freqs.weight" not in ts
+    cfg["rope_scaling"] = {"rope_type": "yarn", "factor": 4.0}
+    (hf / "config.json").write_text(json.dumps(cfg))
+    with pytest.raises(NotImplementedError, match="rope_scaling"):
+        convert(hf, qdir, tmp_path / "m3.gguf", "f16", vocab=False)
+    cfg.pop("rope_scaling")
+    (hf / "config.json").write_text(json.dumps(cfg))
+    (hf / "tokenizer.model").write_bytes(b"spm")
+    with pytest.raises(NotImplementedError, match="SentencePiece"):
+        convert(hf, qdir, tmp_path / "m4.gguf", "f16")
+    (hf / "tokenizer.model").unlink()
+    with pytest.raises(FileNotFoundError):
+        convert(hf, qdir, tmp_path / "m5.gguf", "f16")
