@@ -5,7 +5,7 @@ namespace gq {
 thread_local char g_err[512] = "";
 
 int launch_scale_search(const float*, int64_t, int64_t, int, const gq_search_t*, uint16_t*, int64_t, uint8_t*, int64_t,
-                        uint16_t*, int64_t, uint8_t*, int64_t, hipStream_t);
+                        uint16_t*, int64_t, uint8_t*, int64_t, hipStream_t, unsigned* panel = nullptr);
 int launch_dequantize(int, const uint8_t*, const uint16_t*, const uint8_t*, const uint16_t*, const uint8_t*, int64_t,
                       int64_t, void*, int, hipStream_t);
 int launch_rtn_elementwise(const void*, int, const uint16_t*, const uint8_t*, const uint16_t*, const uint8_t*, int64_t,

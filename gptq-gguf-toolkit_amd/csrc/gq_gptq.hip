@@ -15,7 +15,7 @@ namespace gq {
 
 int launch_scale_search(const float* x, int64_t rows, int64_t ld, int q_type, const gq_search_t* p,
                         uint16_t* d, int64_t d_stride, uint8_t* s, int64_t s_ld, uint16_t* dmin,
-                        int64_t dmin_stride, uint8_t* m, int64_t m_ld, hipStream_t st);
+                        int64_t dmin_stride, uint8_t* m, int64_t m_ld, hipStream_t st, unsigned* panel = nullptr);
 
 // ---------------------------------------------------------------- K5 segment
 // Processes columns [a, a+len) (len <= 128, a % 16 == 0, len % 16 == 0) of the
@@ -196,7 +196,7 @@ size_t gptq_workspace_bytes(int64_t R, int64_t C, int block_size) {
     size_t err = (size_t)R * (size_t)B * sizeof(float);
     if (B == LA_B) err *= LA;  // super-block error buffer [R, LA * B]
     size_t blk = B > SEG ? (size_t)R * (size_t)B * sizeof(float) : 0;
-    return err + blk + 256;
+    return err + blk + 256 + 256;  // + the panel word of the scale searches (quant_utils.py:250-252)
 }
 
 // perm != nullptr: act_order (gptq.py:208-216, 233-235, 272-276).  W and U are already in permuted
@@ -231,6 +231,10 @@ int gptq_quantize(float* W, const float* U, int64_t R, int64_t C, int q_type, in
     const int64_t ldE = lookahead ? (int64_t)LA * B : B;
     float* Err = reinterpret_cast<float*>(((uintptr_t)ws + 255) & ~(uintptr_t)255);
     float* Wblk = Err + (size_t)R * B * (lookahead ? LA : 1);
+    // one device word shared by all scale-search launches of this call (each leaves it at zero)
+    unsigned* panel = reinterpret_cast<unsigned*>(
+        (reinterpret_cast<uintptr_t>(Wblk + ((B > SEG) ? (size_t)R * B : 0)) + 255) & ~(uintptr_t)255);
+    if (ti.k_search && static_groups != 2) GQ_HIP(hipMemsetAsync(panel, 0, 4, st));
     const int64_t ng = C / ti.group, nsg = C / 256;
     const int gps = 256 / ti.group;
     int rc;
@@ -238,7 +242,7 @@ int gptq_quantize(float* W, const float* U, int64_t R, int64_t C, int q_type, in
     if (static_groups == 1) {  // gptq.py:184-196: all scales from the ORIGINAL W
         for (int64_t c = 0; c < C; c += 256)
             if ((rc = launch_scale_search(W + c, R, C, q_type, p, d + c / 256, nsg, s + (c / 256) * gps, ng,
-                                          dmin + c / 256, nsg, m + (c / 256) * gps, ng, st)))
+                                          dmin + c / 256, nsg, m + (c / 256) * gps, ng, st, panel)))
                 return rc;
     }
     const dim3 seg_grid((unsigned)((R + 63) / 64)), seg_block(SEG_WAVES * 64);
@@ -274,7 +278,7 @@ int gptq_quantize(float* W, const float* U, int64_t R, int64_t C, int q_type, in
                 // are stale by design
                 const int64_t sg = a / 256;
                 if ((rc = launch_scale_search(W + a, R, C, q_type, p, d + sg, nsg, s + sg * gps, ng, dmin + sg, nsg,
-                                              m + sg * gps, ng, st)))
+                                              m + sg * gps, ng, st, panel)))
                     return rc;
             }
             const float* srcp = single ? (W + a) : (Wblk + (a - c1));

@@ -134,9 +134,11 @@ struct SearchParams {
 };
 
 // quant_utils.py:199-274 for one group spread over LPG lanes; NS = G/LPG values per lane.
+// `skip`: iterations the WHOLE panel skips (bit i), `valid`: bit i set when this group has D > eps in iteration i --
+// the two halves of the panel-wide `if not valid.any(): continue` of :250-252, see panel_fixup_kernel.
 template <int NS, int BITS, int RM, int LPG>
 __device__ __forceinline__ void k_search(const float (&x)[NS], const SearchParams& sp, float& scale_out,
-                                         float& zero_out) {
+                                         float& zero_out, unsigned skip, unsigned& valid) {
     constexpr float maxq = (float)((1 << BITS) - 1);
     constexpr float G = (float)(NS * LPG);
     constexpr int NA = 8 / LPG;
@@ -187,6 +189,7 @@ __device__ __forceinline__ void k_search(const float (&x)[NS], const SearchParam
 
     if (sp.nstep >= 1) {  // :235-237
         for (int i = 0; i <= sp.nstep; ++i) {  // :240
+            if ((skip >> i) & 1u) continue;     // :250-252, decided for the whole panel
             // :241 scalar/tensor == reciprocal()*scalar; x_min is the aliased best_min (:228,:270)
             float den = R<RM>(x_max - x_min);
             den = den < eps ? eps : den;
@@ -212,6 +215,7 @@ __device__ __forceinline__ void k_search(const float (&x)[NS], const SearchParam
             const float sum_l2 = R<RM>(group_sum<LPG, NA>(a1));
             const float sum_xl = R<RM>(group_sum<LPG, NA>(a2));
             const float D = R<RM>(R<RM>(sum_w * sum_l2) - R<RM>(sum_l * sum_l));                           // :249
+            valid |= (D > eps ? 1u : 0u) << i;                                                              // :250
             float this_scale = R<RM>(R<RM>(R<RM>(sum_w * sum_xl) - R<RM>(sum_x * sum_l)) / D);             // :254
             float this_min = R<RM>(R<RM>(R<RM>(sum_l2 * sum_x) - R<RM>(sum_l * sum_xl)) / D);              // :255
             if (this_min > 0.0f) {                                                                          // :257-260
@@ -231,9 +235,9 @@ __device__ __forceinline__ void k_search(const float (&x)[NS], const SearchParam
                 return;
             }
 #endif
-            // :250-252 the panel-wide `if not valid.any(): continue` is NOT taken
-            // here: it only differs when EVERY group of the [rows,256] panel has
-            // D <= 1e-9 in this iteration (|x| <~ 1e-7 everywhere); see DESIGN.md.
+            // :250-252: a group with D <= eps still goes through the formulas as long as SOME group of the panel is
+            // valid in this iteration (NaN / inf candidates lose the comparison); when NONE is, the reference skips
+            // the iteration for everyone -- detected through `valid`, redone by panel_fixup_kernel.
             if (cand_err < best_err) {  // :266-271 (NaN compares false)
                 best_err = cand_err;
                 best_scale = this_scale;
@@ -275,13 +279,21 @@ __device__ __forceinline__ float load_x(const void* x, int64_t idx) {
     else return bf2f(reinterpret_cast<const uint16_t*>(x)[idx]);
 }
 
+// OR of the lanes' per-iteration valid bits into the panel word (one atomic per wave, skipped when nothing is new)
+__device__ __forceinline__ void publish_valid(unsigned* panel_valid, unsigned v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v |= (unsigned)__shfl_xor((int)v, o);
+    if ((threadIdx.x & 63) == 0 && (__hip_atomic_load(panel_valid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & v) != v)
+        atomicOr(panel_valid, v);
+}
+
 // One workgroup = 256 threads = 256/(NG*8) row-panels.  NG = 256/G groups per row.
 template <int GSZ, int BITS, bool KSEARCH, bool SIGNED, int SMQ, int RM>
 __global__ __launch_bounds__(256) void scale_search_kernel(
     const void* __restrict__ x, int64_t rows, int64_t ld, SearchParams sp,
     uint16_t* __restrict__ d, int64_t d_stride, uint8_t* __restrict__ s, int64_t s_ld,
     uint16_t* __restrict__ dmin, int64_t dmin_stride, uint8_t* __restrict__ m, int64_t m_ld,
-    float* __restrict__ gs_out, float* __restrict__ gz_out) {
+    float* __restrict__ gs_out, float* __restrict__ gz_out, unsigned* panel_valid) {
     constexpr int NS = GSZ / 8;
     constexpr int NG = 256 / GSZ;
     constexpr int LPR = NG * 8;         // lanes per row
@@ -301,8 +313,13 @@ __global__ __launch_bounds__(256) void scale_search_kernel(
     for (int k = 0; k < NS; ++k) xv[k] = load_x<RM>(x, base + k * 8);
 
     float gscale, gzero;
-    if constexpr (KSEARCH) k_search<NS, BITS, RM, 8>(xv, sp, gscale, gzero);
-    else absmax_search<NS, BITS, RM, 8>(xv, gscale, gzero);
+    if constexpr (KSEARCH) {
+        unsigned valid = 0;
+        k_search<NS, BITS, RM, 8>(xv, sp, gscale, gzero, 0u, valid);
+        if (panel_valid) publish_valid(panel_valid, valid);
+    } else {
+        absmax_search<NS, BITS, RM, 8>(xv, gscale, gzero);
+    }
     if (l8 == 0) {
         sh_scale[row_l][g] = gscale;
         sh_zero[row_l][g] = gzero;
@@ -344,7 +361,7 @@ __global__ __launch_bounds__(64) void scale_search_lane_kernel(
     const void* __restrict__ x, int64_t rows, int64_t ld, SearchParams sp,
     uint16_t* __restrict__ d, int64_t d_stride, uint8_t* __restrict__ s, int64_t s_ld,
     uint16_t* __restrict__ dmin, int64_t dmin_stride, uint8_t* __restrict__ m, int64_t m_ld,
-    float* __restrict__ gs_out, float* __restrict__ gz_out) {
+    float* __restrict__ gs_out, float* __restrict__ gz_out, unsigned* panel_valid) {
     static_assert(LPG == 1 || LPG == 2, "one lane or a lane pair per group");
     constexpr int NG = 256 / GSZ;        // groups per row
     constexpr int LPR = NG * LPG;        // lanes per row
@@ -381,8 +398,13 @@ __global__ __launch_bounds__(64) void scale_search_lane_kernel(
     }
 
     float gscale, gzero;
-    if constexpr (KSEARCH) k_search<NS, BITS, RM, LPG>(xv, sp, gscale, gzero);
-    else absmax_search<NS, BITS, RM, LPG>(xv, gscale, gzero);
+    if constexpr (KSEARCH) {
+        unsigned valid = 0;
+        k_search<NS, BITS, RM, LPG>(xv, sp, gscale, gzero, 0u, valid);
+        if (panel_valid) publish_valid(panel_valid, valid);
+    } else {
+        absmax_search<NS, BITS, RM, LPG>(xv, gscale, gzero);
+    }
     if (gs_out && live && h == 0) {  // make_k_quants / make_quants outputs (gq_group_search)
         gs_out[row * NG + g] = gscale;
         gz_out[row * NG + g] = gzero;
@@ -410,13 +432,91 @@ __global__ __launch_bounds__(64) void scale_search_lane_kernel(
     }
 }
 
+// quant_utils.py:250-252: `if not valid.any(): continue` looks at ALL groups of the [rows, 256] panel.  The search
+// kernels above run every iteration and record, per iteration, whether any group was valid.  This one-workgroup
+// kernel follows every search launch: if every iteration had a valid group (any panel with an entry above ~1e-6) it
+// returns at once.  Otherwise the reference skipped iterations the kernels ran: with S = the set of skipped
+// iterations (initially empty), the first iteration outside S without a valid group is one the reference skips --
+// everything before it ran on the right state -- so it joins S and the whole panel is searched again with S, until
+// no such iteration is left (at most nstep + 1 rounds; a panel of denormals or of constant groups, never a weight
+// matrix).  One lane per group, plain loads: the slow path only has to be right.  Leaves the panel word at 0.
+template <int GSZ, int BITS, bool SIGNED, int SMQ, int RM>
+__global__ __launch_bounds__(256) void panel_fixup_kernel(
+    const void* __restrict__ x, int64_t rows, int64_t ld, SearchParams sp,
+    uint16_t* __restrict__ d, int64_t d_stride, uint8_t* __restrict__ s, int64_t s_ld,
+    uint16_t* __restrict__ dmin, int64_t dmin_stride, uint8_t* __restrict__ m, int64_t m_ld,
+    float* __restrict__ gs_out, float* __restrict__ gz_out, unsigned* panel_valid) {
+    constexpr int NG = 256 / GSZ;
+    constexpr int RPB = 256 / NG;  // rows per pass of the workgroup
+    __shared__ unsigned sh_valid;
+    const unsigned full = (2u << sp.nstep) - 1u;
+    unsigned V = *panel_valid & full;
+    unsigned skip = 0;
+    const int tid = threadIdx.x, g = tid % NG, row_l = tid / NG;
+    while (true) {
+        const unsigned missing = full & ~(V | skip);
+        if (missing == 0) break;              // uniform: V and skip are the same in every thread
+        skip |= missing & (0u - missing);     // the lowest iteration nobody was valid in
+        if (tid == 0) sh_valid = 0;
+        __syncthreads();
+        for (int64_t r0 = 0; r0 < rows; r0 += RPB) {
+            const int64_t row = r0 + row_l;
+            const bool live = row < rows;
+            const int64_t base = (live ? row : 0) * ld + g * GSZ;
+            float xv[GSZ];
+#pragma unroll
+            for (int k = 0; k < GSZ; ++k) xv[k] = load_x<RM>(x, base + k);
+            float gscale, gzero;
+            unsigned valid = 0;
+            k_search<GSZ, BITS, RM, 1>(xv, sp, gscale, gzero, skip, valid);
+            if (live && valid) atomicOr(&sh_valid, valid);
+            if (gs_out && live) {
+                gs_out[row * NG + g] = gscale;
+                gz_out[row * NG + g] = gzero;
+            }
+            float max_scale = gscale, max_zero = gzero;  // quant_utils.py:121-143, as in the kernels above
+#pragma unroll
+            for (int o = 1; o < NG; o <<= 1) {
+                float a = __shfl_xor(max_scale, o), b = __shfl_xor(max_zero, o);
+                max_scale = a > max_scale ? a : max_scale;
+                max_zero = b > max_zero ? b : max_zero;
+            }
+            if (live) {
+                constexpr float smq = (float)SMQ;
+                float inv_scale = max_scale > 0.0f ? R<RM>(R<RM>(1.0f / max_scale) * smq) : 0.0f;
+                float inv_zero = max_zero > 0.0f ? R<RM>(R<RM>(1.0f / max_zero) * smq) : 0.0f;
+                float a = clampf(rintf(R<RM>(inv_scale * gscale)), 0.0f, smq);
+                float b = clampf(rintf(R<RM>(inv_zero * gzero)), 0.0f, smq);
+                s[row * s_ld + g] = SIGNED ? (uint8_t)(int8_t)a : (uint8_t)a;
+                m[row * m_ld + g] = SIGNED ? (uint8_t)(int8_t)b : (uint8_t)b;
+                if (g == 0) {
+                    d[row * d_stride] = f2h(R<RM>(max_scale / smq));
+                    dmin[row * dmin_stride] = f2h(R<RM>(max_zero / smq));
+                }
+            }
+        }
+        __syncthreads();
+        V = sh_valid & full;
+        __syncthreads();
+    }
+    if (tid == 0) *panel_valid = 0;
+}
+
 template <int RM>
 static int launch_ss(const void* x, int64_t rows, int64_t ld, int q_type, const gq_search_t* p, uint16_t* d,
                      int64_t d_stride, uint8_t* s, int64_t s_ld, uint16_t* dmin, int64_t dmin_stride, uint8_t* m,
-                     int64_t m_ld, hipStream_t st, float* gs_out = nullptr, float* gz_out = nullptr) {
+                     int64_t m_ld, hipStream_t st, float* gs_out = nullptr, float* gz_out = nullptr,
+                     unsigned* panel = nullptr) {
+    // `panel`: one zeroed device word per call chain (left at zero again); nullptr: taken from the stream's pool
     TypeInfo ti;
     if (!type_info(q_type, ti)) GQ_FAIL(GQ_E_BAD_TYPE, "gq_scale_search: unknown q_type %d", q_type);
     if (rows <= 0 || ld < 256) GQ_FAIL(GQ_E_BAD_SHAPE, "gq_scale_search: rows=%ld ld=%ld", (long)rows, (long)ld);
+    void* own = nullptr;
+    if (ti.k_search && !panel && (!p || p->nstep >= 1)) {
+        GQ_HIP(hipMallocAsync(&own, 256, st));
+        GQ_HIP(hipMemsetAsync(own, 0, 4, st));
+        panel = reinterpret_cast<unsigned*>(own);
+    }
     SearchParams sp;
     sp.nstep = p ? p->nstep : 20;
     if (sp.nstep > 23) GQ_FAIL(GQ_E_UNSUPPORTED, "gq_scale_search: nstep=%d > 23", sp.nstep);
@@ -445,13 +545,16 @@ static int launch_ss(const void* x, int64_t rows, int64_t ld, int q_type, const 
     do {                                                                                                           \
         if (lpg == 1)                                                                                              \
             hipLaunchKernelGGL((scale_search_lane_kernel<G, B, K, S, Q, RM, 1>), grid, block, 0, st, x, rows, ld,  \
-                               sp, d, d_stride, s, s_ld, dmin, dmin_stride, m, m_ld, gs_out, gz_out);              \
+                               sp, d, d_stride, s, s_ld, dmin, dmin_stride, m, m_ld, gs_out, gz_out, panel);       \
         else if (lpg == 2)                                                                                         \
             hipLaunchKernelGGL((scale_search_lane_kernel<G, B, K, S, Q, RM, 2>), grid, block, 0, st, x, rows, ld,  \
-                               sp, d, d_stride, s, s_ld, dmin, dmin_stride, m, m_ld, gs_out, gz_out);              \
+                               sp, d, d_stride, s, s_ld, dmin, dmin_stride, m, m_ld, gs_out, gz_out, panel);       \
         else                                                                                                       \
             hipLaunchKernelGGL((scale_search_kernel<G, B, K, S, Q, RM>), grid, block, 0, st, x, rows, ld, sp, d,   \
-                               d_stride, s, s_ld, dmin, dmin_stride, m, m_ld, gs_out, gz_out);                     \
+                               d_stride, s, s_ld, dmin, dmin_stride, m, m_ld, gs_out, gz_out, panel);              \
+        if (K && panel && sp.nstep >= 1)                                                                           \
+            hipLaunchKernelGGL((panel_fixup_kernel<G, B, S, Q, RM>), dim3(1), dim3(256), 0, st, x, rows, ld, sp,   \
+                               d, d_stride, s, s_ld, dmin, dmin_stride, m, m_ld, gs_out, gz_out, panel);           \
     } while (0)
     switch (q_type) {
     case GQ_Q2_K: GQ_SS(16, 2, true, false, 15); break;
@@ -462,13 +565,15 @@ static int launch_ss(const void* x, int64_t rows, int64_t ld, int q_type, const 
     }
 #undef GQ_SS
     GQ_LAUNCH_CHECK();
+    if (own) GQ_HIP(hipFreeAsync(own, st));
     return GQ_OK;
 }
 
 int launch_scale_search(const float* x, int64_t rows, int64_t ld, int q_type, const gq_search_t* p,
                         uint16_t* d, int64_t d_stride, uint8_t* s, int64_t s_ld, uint16_t* dmin,
-                        int64_t dmin_stride, uint8_t* m, int64_t m_ld, hipStream_t st) {
-    return launch_ss<0>(x, rows, ld, q_type, p, d, d_stride, s, s_ld, dmin, dmin_stride, m, m_ld, st);
+                        int64_t dmin_stride, uint8_t* m, int64_t m_ld, hipStream_t st, unsigned* panel) {
+    return launch_ss<0>(x, rows, ld, q_type, p, d, d_stride, s, s_ld, dmin, dmin_stride, m, m_ld, st, nullptr, nullptr,
+                        panel);
 }
 
 // make_k_quants / make_quants outputs (per-group fp32 scale and zero) of one [rows,256] panel in

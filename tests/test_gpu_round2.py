@@ -453,3 +453,62 @@ def test_handle_zero_copy_and_staged_paths_agree(ops):
     xs[0].add_(1.0)
     with pytest.raises(RuntimeError, match="modified in place"):
         e.flush()
+
+
+# ----------------------------------------------------------------- quant_utils.py:250-252, the panel-wide `continue`
+@pytest.mark.parametrize("wide", ["0", "1", "2"])
+@pytest.mark.parametrize("name", ["Q2_K", "Q4_K", "Q5_K"])
+def test_panel_wide_continue(ops, oracle, name, wide):
+    """make_k_quants skips a refinement iteration for EVERY group when no group of the [rows, 256] panel has
+    D > 1e-9 in it (r01: a documented deviation of the HIP kernel).  Panels where that happens -- every value ~1e-7,
+    or every group constant -- must match the oracle (which takes the `continue`) bit for bit, in all three kernel
+    mappings; and the skip must matter: the same tiny rows next to ONE ordinary row give other results."""
+    t, G = TYPES[name], GROUP[name]
+    rng = np.random.default_rng(TYPES[name])
+    rows = 301
+    tiny = (rng.standard_normal((rows, 256)) * 2e-8).astype(np.float32)  # D <= 1e-9 in every group, every iteration
+    const = np.repeat((rng.standard_normal((rows, 256 // G)) * 0.02).astype(np.float32), G, axis=1)
+    const[5] = 0.0
+    mixed = tiny.copy()
+    mixed[17] = (rng.standard_normal(256) * 0.02).astype(np.float32)
+    os.environ["GQ_SS_WIDE"] = wide
+    try:
+        outs = {}
+        for tag, x in (("tiny", tiny), ("const", const), ("mixed", mixed)):
+            gs, gz, d, s, dmin, m = ops.group_search(dev(x), t)
+            osc, oze = oracle.make_k_quants(x.reshape(-1, G), oracle.type_info(t)["bits"])
+            od, os_, odm, om = oracle.scale_search(x, t)
+            assert bits_eq(npy(gs).ravel(), osc) and bits_eq(npy(gz).ravel(), oze), f"{tag}: group scales / zeros"
+            assert np.array_equal(u16(d), od) and np.array_equal(npy(s), os_), tag
+            assert np.array_equal(u16(dmin), odm) and np.array_equal(npy(m), om), tag
+            outs[tag] = npy(gs)
+        # scale_search (the entry the column loop uses) on a strided view of a wider matrix
+        wide_m = np.zeros((rows, 768), np.float32)
+        wide_m[:, 256:512] = tiny
+        d, s, dmin, m = ops.scale_search(dev(wide_m)[:, 256:512], t)
+        od, os_, odm, om = oracle.scale_search(tiny, t)
+        assert np.array_equal(u16(d), od) and np.array_equal(npy(s), os_) and np.array_equal(npy(m), om)
+    finally:
+        os.environ.pop("GQ_SS_WIDE", None)
+    keep = np.arange(rows) != 17
+    if name != "Q5_K":  # (with 5 bits no candidate of these groups ever wins, skipped or not: oracle, both panels)
+        assert not np.array_equal(outs["tiny"][keep], outs["mixed"][keep]), "the panel-wide skip changed nothing"
+
+
+def test_panel_wide_continue_in_the_column_loop(ops, oracle):
+    """gq_gptq_quantize / gq_rtn_quantize on a matrix whose second 256-column stripe is ~1e-7 everywhere."""
+    rng = np.random.default_rng(9)
+    R, C = 192, 768
+    W = (rng.standard_normal((R, C)) * 0.02).astype(np.float32)
+    W[:, 256:512] = (rng.standard_normal((R, 256)) * 1e-7).astype(np.float32)
+    U = np.triu(rng.standard_normal((C, C)).astype(np.float32) * 0.01, 1) + np.eye(C, dtype=np.float32)
+    for t in (12, 10):
+        Wg = dev(W)
+        q, d, s, dmin, m = ops.gptq_quantize(Wg, dev(U), t, block_size=128)
+        Wd, oq, od, os_, odm, om = oracle.gptq_step(W, U, t, block_size=128)
+        assert np.array_equal(npy(q), oq) and np.array_equal(u16(d), od) and np.array_equal(npy(s), os_)
+        assert np.array_equal(u16(dmin), odm) and np.array_equal(npy(m), om) and np.array_equal(npy(Wg), Wd)
+        q, d, s, dmin, m = ops.rtn_quantize(dev(W), t)
+        oq, od, os_, odm, om = oracle.rtn_quantize(W, t)
+        assert np.array_equal(npy(q), oq) and np.array_equal(u16(d), od) and np.array_equal(npy(s), os_)
+        assert np.array_equal(npy(m), om)
