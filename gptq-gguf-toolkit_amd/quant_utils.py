@@ -92,12 +92,17 @@ class Quantizer:
         """x: (rows, 256) fp32 view -> (super_group_scale f16[rows], group_scale_quant[rows, 256/G],
         super_group_zero f16[rows], group_zero_quant[rows, 256/G])  -- reference return order (:145)."""
         assert x.ndim == 2 and x.shape[1] == QK_K, f"expected (rows, {QK_K})"
-        if x.dtype != torch.float32:
-            raise NotImplementedError("get_scale_and_zero runs on fp32 panels (reduced-precision emulation: TODO)")
         if x.stride(1) != 1:
             x = x.contiguous()
         if self.quant_scale is QuantizationScale.MSE:
             check_mse_equivalent(q_type, float(x.max().item()))
+        if x.dtype in (torch.float16, torch.bfloat16):
+            # the reference runs make_*quants in the panel's dtype (quantizer.py:109,195 pass model-dtype weights):
+            # gq_group_search rounds after every op the way ATen's CPU fp16 / bf16 kernels do
+            _, _, d, s, dmin, m = _ops.group_search(x, int(q_type), self.rmin, self.rdelta, self.nstep)
+            return d, s, dmin, m
+        if x.dtype != torch.float32:
+            x = x.float()
         d, s, dmin, m = _ops.scale_search(x, int(q_type), self.rmin, self.rdelta, self.nstep)
         return d, s, dmin, m
 

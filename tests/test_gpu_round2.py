@@ -512,3 +512,24 @@ def test_panel_wide_continue_in_the_column_loop(ops, oracle):
         oq, od, os_, odm, om = oracle.rtn_quantize(W, t)
         assert np.array_equal(npy(q), oq) and np.array_equal(u16(d), od) and np.array_equal(npy(s), os_)
         assert np.array_equal(npy(m), om)
+
+
+@pytest.mark.parametrize("tag,dt", [("f16", torch.float16), ("bf16", torch.bfloat16), ("f32", torch.float32)])
+def test_quantizer_get_scale_and_zero_in_the_panel_dtype(ops, tag, dt):
+    """quant_utils.Quantizer.get_scale_and_zero (quant_utils.py:90-145) on panels in the model dtype -- what
+    Quantizer._quant_non_block_module hands it (quantizer.py:300-310): G9 / G8 hold the reference's outputs."""
+    from gptq_gguf_toolkit_amd.quant_utils import GGML_QUANT_SIZES, GGMLQuantizationType, Quantizer
+    g = load_golden("g8_g9_rtn_dequant")
+    W = dev(g["W" if tag == "f32" else f"W_{tag}"]).to(dt)
+    pre = "" if tag == "f32" else f"{tag}_"
+    for name in ("Q4_K", "Q6_K", "Q2_K"):
+        qt = GGMLQuantizationType[name]
+        bits, _, smq, G, SG, sdt, _ = GGML_QUANT_SIZES[qt]
+        qz = Quantizer()
+        qz.configure(bits, smq, G, sdt, SG)
+        for sg in range(W.shape[1] // 256):
+            d, s, dmin, m = qz.get_scale_and_zero(W[:, sg * 256:(sg + 1) * 256], qt)
+            gps = 256 // G
+            assert np.array_equal(u16(d), g[f"{pre}{name}_d"][:, sg]) and np.array_equal(u16(dmin), g[f"{pre}{name}_dmin"][:, sg])
+            assert np.array_equal(npy(s), g[f"{pre}{name}_s"][:, sg * gps:(sg + 1) * gps])
+            assert np.array_equal(npy(m), g[f"{pre}{name}_m"][:, sg * gps:(sg + 1) * gps])
