@@ -225,7 +225,6 @@ int gptq_quantize(float* W, const float* U, int64_t R, int64_t C, int q_type, in
     // measured no gain alone and -8 % inside a block's multi-stream schedule: its long K = 1024 tiles keep
     // the column-loop workgroups, which need a whole CU's LDS, waiting.)
     const bool lookahead = (B == LA_B) && getenv("GQ_NO_LOOKAHEAD") == nullptr;
-    const bool pair = getenv("GQ_NO_PAIR") == nullptr;
     int la = LA;
     // tuning knob; even only: a 256-column scale-search group must not straddle two super-blocks
     if (const char* e = getenv("GQ_LA")) la = (atoi(e) >= 2 && atoi(e) <= LA && atoi(e) % 2 == 0) ? atoi(e) : LA;
@@ -311,24 +310,12 @@ int gptq_quantize(float* W, const float* U, int64_t R, int64_t C, int q_type, in
             continue;
         }
         const int64_t S0 = sb * la * B, S1 = (S0 + la * B < C) ? S0 + la * B : C;  // this super-block
-        if (c2 < S1) {
-            // Inside the super-block the updates are applied in pairs of blocks: an even block updates only its
-            // partner (the next 128 columns need it now), the odd block then updates the REST of the super-block
-            // with both blocks in one chained GEMM (K = 256, the accumulator restarts after 128 k).  Every column
-            // still receives the blocks' updates one after the other in block order -- the per-element operation
-            // sequence of gptq.py:270 is unchanged -- but the 7 thin launches per super-block become 4 tiny + 3
-            // twice as deep ones (4096 x 14336: near updates 1.7 -> see DESIGN.md K6).
-            if (pair && (pos & 1) == 0) {
-                const int64_t n = (c2 + B < S1) ? B : S1 - c2;
-                if ((rc = launch_trailing_update(W + c2, C, Err + pos * B, ldE, U + c1 * C + c2, C, R, n, ncols, st))) return rc;
-            } else if (pair) {
-                ProfScope ps(PT_TRAILING, st);
-                if ((rc = launch_gemm32<false, 0, false, 0, LA_B>(W + c2, C, Err + (pos - 1) * B, ldE, U + (c1 - B) * C + c2, C, R,
-                                                                  S1 - c2, 2 * B, st)))
-                    return rc;
-            } else if ((rc = launch_trailing_update(W + c2, C, Err + pos * B, ldE, U + c1 * C + c2, C, R, S1 - c2, ncols, st))) {
-                return rc;  // GQ_NO_PAIR: the rest of the super-block after every block
-            }
+        if (c2 < S1) {  // rest of the super-block, this block's errors only
+            // (measured and dropped: applying the blocks in pairs -- an even block updates its partner only, the odd
+            // block the rest with both in one chained K = 256 launch -- gives 4 tiny + 3 deeper launches instead of 7
+            // thin ones, bit-identical, but no faster: 1.79 vs 1.71 ms for 4096 x 14336; every launch is latency)
+            if ((rc = launch_trailing_update(W + c2, C, Err + pos * B, ldE, U + c1 * C + c2, C, R, S1 - c2, ncols, st)))
+                return rc;
             continue;
         }
         // end of the super-block: all its blocks at once, every later column

@@ -116,6 +116,10 @@ struct SyrkGroup {
     // = tokens [part, part+1) * T / nparts (in units of 128), raw fp32 sums stored to partial[slot] (256 x 256)
     const uint32_t* aux;
     float* partial;
+    // syrk16_256n_kernel, persistent launch (one workgroup per CU walks its XCD's list): bar[x] counts the workgroups
+    // of XCD x that finished a round; a round starts when all of them have, so the 32 tiles an XCD works on at a
+    // time stay in step and share their 12 operand panels through the XCD's L2.  nullptr: one tile per workgroup.
+    unsigned* bar;
 };
 
 template <bool BF16>
@@ -560,9 +564,24 @@ __global__ __launch_bounds__(512, 2) void syrk16_256n_kernel(const SyrkGroup grp
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid >> 2, wn = wid & 3;
-    for (int slot = (int)(blockIdx.x >> 3); slot < grp.per_xcd; slot += (int)(gridDim.x >> 3)) {
+    int round = 0;
+    for (int slot = (int)(blockIdx.x >> 3); slot < grp.per_xcd; slot += (int)(gridDim.x >> 3), ++round) {
+    if (grp.bar && round > 0) {  // XCD-wide rendezvous between rounds (persistent launch)
+        if (tid == 0) {
+            unsigned* b = grp.bar + (blockIdx.x & 7);
+            __hip_atomic_fetch_add(b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned want = (unsigned)round * (gridDim.x >> 3);
+            // a SOFT rendezvous (performance only, results do not depend on it): give up after ~30 us, so that a
+            // workgroup whose peers are not resident (another process on the same GPU) can never wait for ever
+            for (int spin = 0; spin < 64 && __hip_atomic_load(b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want; ++spin)
+                __builtin_amdgcn_s_sleep(16);
+        }
+    }
     const uint32_t ent = (uint32_t)__builtin_amdgcn_readfirstlane((int)grp.table[(blockIdx.x & 7) * grp.per_xcd + slot]);
-    if (ent == 0xffffffffu) break;
+    if (ent == 0xffffffffu) {
+        if (grp.bar) continue;  // keeps taking part in the rendezvous
+        break;
+    }
     const uint32_t aux = grp.aux ? (uint32_t)__builtin_amdgcn_readfirstlane((int)grp.aux[(blockIdx.x & 7) * grp.per_xcd + slot])
                                  : 0xffffffffu;
     __syncthreads();
@@ -986,7 +1005,7 @@ size_t h_accumulate_workspace_bytes(int64_t T, int64_t C) {
     const size_t nt = (size_t)(C / BT);
     const size_t ntile = nt * (nt + 1) / 2;
     // tile table + unit attributes + reduce list of the 256x256 kernels (K-split adds up to 512 units)
-    const size_t table = (ntile + 512 + 320) * 4 * 2 + 512 * 8 + 256 + (size_t)(T / 128 + 2) * 8;  // + block addresses
+    const size_t table = (ntile + 512 + 320) * 4 * 2 + 512 * 8 + 256 + (size_t)(T / 128 + 2) * 8 + 64;  // + block addresses, counters
     if (syrk_in_place(T, C)) return table + syrk_partial_slots(T, ntile) * (size_t)BT * BT * 4 + 256;
     const int64_t Tp = (T + 2 * HK - 1) / (2 * HK) * (2 * HK);
     return (size_t)C * (size_t)Tp * 2 + 256 + table;
@@ -1029,6 +1048,7 @@ static int syrk16_launch(int kind, const int* idx, int m, float* const* H, const
     grp.per_xcd = 0;
     grp.aux = nullptr;
     grp.partial = nullptr;
+    grp.bar = nullptr;
     int n_reduce = 0;
     const uint32_t* reduce_list = nullptr;
     std::vector<uint32_t> table;
@@ -1097,7 +1117,15 @@ static int syrk16_launch(int kind, const int* idx, int m, float* const* H, const
         }
         for (size_t t = 0; t < rlist.size(); ++t) table[2 * tl + t] = rlist[t];
         wp = reinterpret_cast<unsigned char*>(((uintptr_t)wp + 255) & ~(uintptr_t)255);
-        // block address lists of the problems whose X arrives in separate blocks, behind the tile table
+        // rendezvous counters of the persistent launch (zeroed by this upload), then the block address lists of the
+        // problems whose X arrives in separate blocks, behind the tile table
+        // default on: L2-miss reads of a 14336-wide launch 49.6 -> 37.5 GB (rocprofv3 FETCH_SIZE), +0.8 % speed
+        static const bool persist = getenv("GQ_SYRK_PERSIST") == nullptr || getenv("GQ_SYRK_PERSIST")[0] != '0';
+        size_t bar_at = 0;
+        if (kind == 2 && persist && per_xcd > 32) {
+            bar_at = table.size();
+            for (int x = 0; x < 8; ++x) table.push_back(0u);
+        }
         if (table.size() & 1) table.push_back(0xffffffffu);
         for (int k = 0; k < m && segs; ++k) {
             const int i = idx[k];
@@ -1113,6 +1141,7 @@ static int syrk16_launch(int kind, const int* idx, int m, float* const* H, const
         if (wp + table.size() * 4 > ws_end) GQ_FAIL(GQ_E_WORKSPACE, "gq_h_accumulate: workspace too small for the tile table");
         GQ_HIP(hipMemcpyAsync(wp, table.data(), table.size() * 4, hipMemcpyHostToDevice, st));  // pageable: staged before return
         grp.table = reinterpret_cast<const uint32_t*>(wp);
+        if (bar_at) grp.bar = reinterpret_cast<unsigned*>(wp) + bar_at;
         grp.per_xcd = per_xcd;
         grp.aux = sp > 1 ? grp.table + tl : nullptr;
         wp += table.size() * 4;
@@ -1128,7 +1157,8 @@ static int syrk16_launch(int kind, const int* idx, int m, float* const* H, const
     ProfScope ps(PT_SYRK, st);
     const bool bf = x_dtype == GQ_BF16;
     if (kind == 2) {
-        const dim3 grid((unsigned)(8 * grp.per_xcd)), blk(512);  // one tile per workgroup (fewer would walk the lists)
+        // one tile per workgroup, or (grp.bar) one workgroup per CU walking its XCD's list in rounds
+        const dim3 grid((unsigned)(grp.bar ? 256 : 8 * grp.per_xcd)), blk(512);
         if (bf) hipLaunchKernelGGL(syrk16_256n_kernel<true>, grid, blk, S_LDS_BYTES, st, grp);
         else hipLaunchKernelGGL(syrk16_256n_kernel<false>, grid, blk, S_LDS_BYTES, st, grp);
         if (n_reduce > 0) {

@@ -70,6 +70,8 @@ def parse_args(argv=None):
     p.add_argument("--verbose", action="store_true")
     p.add_argument("--save_dir", type=str, required=True)
     # beyond the reference
+    p.add_argument("--calibration_batch", type=int, default=1,
+                   help="calibration samples per block forward (the reference runs 1; the Hessians are the same sums)")
     p.add_argument("--non_block_fp32", action="store_true",
                    help="run the embed/lm_head scale search in fp32 (the reference runs it in the model dtype)")
     return p.parse_args(argv)
@@ -143,7 +145,8 @@ def main(argv=None):
         pre_block_modules=args.pre_block_modules, block_modules=args.block_modules,
         post_block_modules=args.post_block_modules, quant_non_block_modules=args.quant_non_block_modules,
         cpu_offload_modules=args.cpu_offload_modules, cpu_offload_activations=args.cpu_offload_activations,
-        device=device, verbose=args.verbose, save_dir=args.save_dir, non_block_fp32=args.non_block_fp32)
+        device=device, verbose=args.verbose, save_dir=args.save_dir, non_block_fp32=args.non_block_fp32,
+        calibration_batch=args.calibration_batch)
     if dist_utils.is_main():
         os.makedirs(args.save_dir, exist_ok=True)
     dist_utils.barrier()

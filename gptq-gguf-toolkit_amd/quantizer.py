@@ -34,10 +34,98 @@ from .model_utils import ForwardInterrupt, InputCollector, LINEAR_LAYERS, _to, s
 from .quant_utils import GGML_QUANT_SIZES, GGMLQuantizationType, dequantize_linear_weight
 
 
+def _same(a, b) -> bool:
+    if torch.is_tensor(a) or torch.is_tensor(b):
+        return torch.is_tensor(a) and torch.is_tensor(b) and a.shape == b.shape and a.dtype == b.dtype and \
+            (a.data_ptr() == b.data_ptr() or bool(torch.equal(a, b)))
+    if isinstance(a, (tuple, list)) and isinstance(b, (tuple, list)):
+        return len(a) == len(b) and all(_same(x, y) for x, y in zip(a, b))
+    if isinstance(a, dict) and isinstance(b, dict):
+        return a.keys() == b.keys() and all(_same(a[k], b[k]) for k in a)
+    return a is b or a == b
+
+
+def _batch_block_inputs(input_args, input_kwargs, batch: int):
+    """Merge runs of up to `batch` consecutive captured block inputs into one call: the hidden states (first
+    positional argument, or kwargs["hidden_states"]) are concatenated along dim 0; everything else must be IDENTICAL
+    across the run (position ids / embeddings, masks, flags) and is taken from its first sample.  Samples that do
+    not fit (another length, another mask) stay calls of their own."""
+    def hidden(a, kw):
+        return a[0] if len(a) > 0 else kw.get("hidden_states")
+
+    def rest(a, kw):
+        return (tuple(a[1:]), {k: v for k, v in kw.items() if k != "hidden_states" or len(a) > 0})
+
+    out_a, out_kw, i, n = [], [], 0, len(input_args)
+    while i < n:
+        j = i + 1
+        h0 = hidden(input_args[i], input_kwargs[i])
+        while j < n and j - i < batch and torch.is_tensor(h0) and h0.dim() >= 2:
+            hj = hidden(input_args[j], input_kwargs[j])
+            if not (torch.is_tensor(hj) and hj.shape == h0.shape and hj.dtype == h0.dtype
+                    and _same(rest(input_args[i], input_kwargs[i]), rest(input_args[j], input_kwargs[j]))):
+                break
+            j += 1
+        if j - i == 1:
+            out_a.append(input_args[i])
+            out_kw.append(input_kwargs[i])
+        else:
+            cat = torch.cat([hidden(input_args[k], input_kwargs[k]) for k in range(i, j)], dim=0)
+            if len(input_args[i]) > 0:
+                out_a.append((cat,) + tuple(input_args[i][1:]))
+                out_kw.append(input_kwargs[i])
+            else:
+                out_a.append(input_args[i])
+                out_kw.append(dict(input_kwargs[i], hidden_states=cat))
+        i = j
+    return out_a, out_kw
+
+
+def _write_data_pth(save_dir, name, q_type, qweight, d, s, dmin, m):
+    os.makedirs(os.path.join(save_dir, name), exist_ok=True)
+    torch.save({"q_type": int(q_type), "qweight": qweight, "super_group_scale": d, "super_group_zero": dmin,
+                "group_scale_quant": s, "group_zero_quant": m}, os.path.join(save_dir, name, "data.pth"))
+
+
+def _slot_views(slot, layout):
+    return [slot[off:off + n].view(dt).view(shape) for off, n, dt, shape in layout]
+
+
+def _writer_process(save_dir, slots, inbox, freeq, outbox):
+    """Body of the writer PROCESS.  `slots` are the parent's pinned staging buffers (shared memory): a message names
+    a slot and the layout of a module's five tensors inside it; they are copied out, the slot goes back to the parent,
+    then torch.save runs here -- with this process's interpreter lock, not the parent's."""
+    try:
+        torch.set_num_threads(1)
+        busy = 0.0
+        while True:
+            item = inbox.get()
+            if item is None:
+                break
+            t0 = time.perf_counter()
+            if item[0] == "slot":
+                _, sid, name, q_type, layout = item
+                host = [v.clone() for v in _slot_views(slots[sid], layout)]
+                freeq.put(sid)
+            else:  # a module larger than a slot: its host tensors came through the queue
+                _, name, q_type, host = item
+            _write_data_pth(save_dir, name, q_type, *host)
+            del item, host
+            busy += time.perf_counter() - t0
+        outbox.put(("ok", busy))
+    except BaseException as e:  # reported to the parent
+        outbox.put(("error", repr(e)))
+
+
 class _Saver:
-    """data.pth writer: one thread; device tensors are copied to the host on a side stream after an event that
-    marks them complete, then written with torch.save (quantizer.py:267-275).  `sync=True` (CPU tensors, or
-    GQ_SYNC_SAVE=1) writes in line like the reference."""
+    """data.pth writer (quantizer.py:267-275) off the critical path.  A thread of this process copies a module's
+    five device tensors into a pinned staging slot on a side stream (behind an event that marks them complete); the
+    slots live in shared memory and a separate PROCESS copies them out and runs torch.save.  Why a process:
+    torch.save holds the interpreter lock for much of its 0.7 s per GB and Llama-3-8B leaves 8.7 GB of data.pth
+    behind -- written from a thread of this process, the launches of the next block's forwards stall (+1.2 s of
+    15.5 s; three writer threads: worse); why pinned slots: fresh pageable host tensors cost the copy thread 6-9 s
+    in page faults.  GQ_SAVE_MODE=thread keeps everything in-process; `sync=True` (CPU tensors, or GQ_SYNC_SAVE=1)
+    writes in line like the reference."""
 
     def __init__(self, save_dir: str, sync: bool):
         self.save_dir, self.sync = save_dir, sync
@@ -45,38 +133,90 @@ class _Saver:
         self.err: Optional[BaseException] = None
         self.busy_s = 0.0
         self.thread = None
-        self.stream = None
+        self.proc = self.inbox = self.outbox = self.freeq = None
+        self.slots: List[torch.Tensor] = []
+        self.use_process = os.environ.get("GQ_SAVE_MODE", "process") == "process"
+        self.slot_bytes = int(os.environ.get("GQ_SAVE_SLOT_MB", 704)) << 20  # embed_tokens of Llama-3 in Q4_K: 657 MB
 
-    def _write(self, name, q_type, tensors):
-        t0 = time.perf_counter()
-        qweight, d, s, dmin, m = [t.cpu() for t in tensors]
-        os.makedirs(os.path.join(self.save_dir, name), exist_ok=True)
-        torch.save({"q_type": int(q_type), "qweight": qweight, "super_group_scale": d, "super_group_zero": dmin,
-                    "group_scale_quant": s, "group_zero_quant": m}, os.path.join(self.save_dir, name, "data.pth"))
-        self.busy_s += time.perf_counter() - t0
+    def _start_process(self):
+        import torch.multiprocessing as tmp
+        ctx = tmp.get_context("spawn")
+        self.slots = [torch.empty(self.slot_bytes, dtype=torch.uint8).share_memory_() for _ in range(2)]
+        self._registered = []
+        for t in self.slots:  # pin the shared pages: device-to-host copies into them are plain DMA
+            try:
+                if int(torch.cuda.cudart().cudaHostRegister(t.data_ptr(), t.numel(), 0)) == 0:
+                    self._registered.append(t)
+            except Exception:
+                pass
+        self.inbox, self.outbox, self.freeq = ctx.Queue(), ctx.Queue(), ctx.Queue()
+        for sid in range(len(self.slots)):
+            self.freeq.put(sid)
+        self.proc = ctx.Process(target=_writer_process, args=(self.save_dir, self.slots, self.inbox, self.freeq, self.outbox),
+                                daemon=True)
+        self.proc.start()
 
     def _loop(self):
+        stream = None
         while True:
             item = self.q.get()
             if item is None:
                 return
             name, q_type, tensors, ev, dev = item
             try:
-                if self.stream is None:
-                    self.stream = torch.cuda.Stream(dev)
-                with torch.cuda.stream(self.stream):
-                    self.stream.wait_event(ev)
-                    self._write(name, q_type, tensors)
+                t0 = time.perf_counter()
+                if stream is None:
+                    stream = torch.cuda.Stream(dev)
+                layout, off = [], 0
+                for t in tensors:
+                    n = t.numel() * t.element_size()
+                    layout.append((off, n, t.dtype, tuple(t.shape)))
+                    off += (n + 255) & ~255
+                with torch.cuda.stream(stream):
+                    stream.wait_event(ev)
+                    if self.proc is not None and off <= self.slot_bytes:
+                        sid = self.freeq.get()
+                        for v, t in zip(_slot_views(self.slots[sid], layout), tensors):
+                            v.copy_(t.contiguous(), non_blocking=True)
+                        stream.synchronize()
+                        self.inbox.put(("slot", sid, name, int(q_type), layout))
+                    else:
+                        host = [t.cpu() for t in tensors]
+                        if self.proc is not None:
+                            self.inbox.put(("host", name, int(q_type), host))
+                        else:
+                            _write_data_pth(self.save_dir, name, q_type, *host)
+                del tensors, item
+                self.busy_s += time.perf_counter() - t0
             except BaseException as e:  # surfaced by close()
                 self.err = self.err or e
 
+    def warm_up(self, device) -> None:
+        """Start the writer process and pin its slots now (0.3 s), in the background of the capture forward."""
+        if self.sync or self.thread is not None or torch.device(device).type != "cuda":
+            return
+        ready = threading.Event()
+
+        def boot():
+            try:
+                if self.use_process:
+                    self._start_process()
+            except BaseException as e:
+                self.err = self.err or e
+            ready.set()
+            self._loop()
+
+        self.thread = threading.Thread(target=boot, name="gq-data-pth-copier", daemon=True)
+        self.thread.start()
+
     def put(self, name, q_type, tensors):
         if self.sync or not tensors[0].is_cuda:
-            self._write(name, q_type, tensors)
+            t0 = time.perf_counter()
+            _write_data_pth(self.save_dir, name, q_type, *[t.cpu() for t in tensors])
+            self.busy_s += time.perf_counter() - t0
             return
         if self.thread is None:
-            self.thread = threading.Thread(target=self._loop, name="gq-data-pth-writer", daemon=True)
-            self.thread.start()
+            self.warm_up(tensors[0].device)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(tensors[0].device))
         self.q.put((name, q_type, tensors, ev, tensors[0].device))
@@ -86,6 +226,24 @@ class _Saver:
             self.q.put(None)
             self.thread.join()
             self.thread = None
+        if self.proc is not None:
+            self.inbox.put(None)
+            try:
+                status, info = self.outbox.get(timeout=600)
+            except Exception as e:
+                status, info = "error", f"writer process did not answer: {e!r}"
+            self.proc.join(timeout=60)
+            for t in getattr(self, "_registered", []):
+                try:
+                    torch.cuda.cudart().cudaHostUnregister(t.data_ptr())
+                except Exception:
+                    pass
+            self.proc = self.inbox = self.outbox = self.freeq = None
+            self.slots = []
+            if status == "ok":
+                self.writer_busy_s = float(info)
+            else:
+                self.err = self.err or RuntimeError(f"data.pth writer process failed: {info}")
         if self.err is not None:
             raise self.err
 
@@ -138,7 +296,8 @@ class Quantizer:
                  quantizer_kwargs: Dict[str, Any], pre_block_modules: List[str], post_block_modules: List[str],
                  block_modules: str, save_dir: str, quant_non_block_modules: bool = False,
                  device: Optional[torch.device] = None, cpu_offload_modules: bool = False,
-                 cpu_offload_activations: bool = False, verbose: bool = False, non_block_fp32: bool = False) -> None:
+                 cpu_offload_activations: bool = False, verbose: bool = False, non_block_fp32: bool = False,
+                 calibration_batch: int = 1) -> None:
         self.model = model
         self.data_loader = data_loader
         self.quantizable_modules = quantizable_modules
@@ -153,6 +312,10 @@ class Quantizer:
         self.verbose = verbose
         self.save_dir = save_dir
         self.non_block_fp32 = non_block_fp32
+        # beyond the reference (which runs one calibration sample per block forward, quantizer.py:150-151): samples
+        # per block forward.  Same Hessians in exact arithmetic (GPTQ.update weighs a batch by its size,
+        # gptq.py:86-112); one Llama-3-8B layer forward takes 0.91 instead of 1.16 ms per sequence at 4.
+        self.calibration_batch = max(1, int(calibration_batch))
 
     # ------------------------------------------------------------------ walk
     @torch.no_grad()
@@ -160,6 +323,8 @@ class Quantizer:
         device = self.device or next(self.model.parameters()).device
         self._save_index = -1
         self._saver = _Saver(self.save_dir, sync=os.environ.get("GQ_SYNC_SAVE") == "1")
+        if os.environ.get("GQ_SAVE_SKIP") != "1":
+            self._saver.warm_up(device)
         try:
             self._quantize(quant_config, device)
         finally:
@@ -169,7 +334,8 @@ class Quantizer:
             if getattr(self, "_phases", None) is not None:
                 self._phases.host["save_tail"] = time.perf_counter() - t0
                 self.timing = self._phases.result()
-                self.timing["saver_thread_s"] = round(self._saver.busy_s, 4)
+                self.timing["saver_copy_thread_busy_s"] = round(self._saver.busy_s, 4)
+                self.timing["saver_writer_process_busy_s"] = round(getattr(self._saver, "writer_busy_s", 0.0), 4)
 
     def _quantize(self, quant_config: Dict[str, GGMLQuantizationType], device) -> None:
         ph = self._phases = _Phases(device)
@@ -191,6 +357,8 @@ class Quantizer:
                 pass
         input_args, input_kwargs = blocks[0].input_args, blocks[0].input_kwargs
         blocks[0] = blocks[0].module
+        if self.calibration_batch > 1:
+            input_args, input_kwargs = _batch_block_inputs(input_args, input_kwargs, self.calibration_batch)
         dist_utils.barrier()
         ph.mark("capture")
 
@@ -263,8 +431,8 @@ class Quantizer:
         # copies and the zip/CRC work of torch.save -- ~1 GB/s per writer, 8.7 GB for Llama-3-8B -- scale with
         # the ranks instead of serialising on rank 0 next to an 8x shorter compute phase
         self._save_index = getattr(self, "_save_index", -1) + 1
-        if self._save_index % dist_utils.get_world_size() != dist_utils.get_rank():
-            return
+        if self._save_index % dist_utils.get_world_size() != dist_utils.get_rank() or os.environ.get("GQ_SAVE_SKIP") == "1":
+            return  # (GQ_SAVE_SKIP: measurement knob -- how much of the wall time the writer costs)
         self._saver.put(name, q_type, (qweight, d, s, dmin, m))
 
     def _quant_group(self, handles: Dict[str, GPTQ], quant_config: Dict[str, GGMLQuantizationType]):

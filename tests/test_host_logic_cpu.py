@@ -607,3 +607,44 @@ def test_packer_metadata_order_rope_freqs_and_experts(tmp_path, monkeypatch):
     (hf / "tokenizer.model").unlink()
     with pytest.raises(FileNotFoundError):
         convert(hf, qdir, tmp_path / "m5.gguf", "f16")
+
+
+def test_calibration_batch_merges_block_inputs(tmp_path):
+    """calibration_batch (beyond the reference): 4 samples per block forward give the same tree and -- the Hessians
+    being the same sums -- the same integers up to the tolerance-class rate; inputs that differ in anything but the
+    hidden states are never merged."""
+    import fake_ops
+    from make_golden_shim import MIXED, tiny_calib, tiny_llama
+    from gptq_gguf_toolkit_amd.quant_utils import GGMLQuantizationType as T
+    from gptq_gguf_toolkit_amd.quantizer import Quantizer, _batch_block_inputs
+    fake_ops.install()
+    outs = []
+    for b in (1, 4):
+        d = str(tmp_path / f"b{b}")
+        os.makedirs(d)
+        model = tiny_llama()
+        data = [([], {"input_ids": ids}) for ids in tiny_calib()]
+        drv = Quantizer(model, data_loader=data, quantizable_modules=r".*layers.*((q|k|v|o|gate|up|down)_proj)$",
+                        quantizer_kwargs=dict(rel_damp=0.01, block_size=128), pre_block_modules=["model.embed_tokens"],
+                        block_modules="model.layers", post_block_modules=["lm_head"], quant_non_block_modules=True,
+                        device="cpu", save_dir=d, calibration_batch=b)
+        fake_ops.calls["h_accumulate"] = 0
+        drv.quantize({k: T[v] for k, v in MIXED.items()})
+        outs.append(d)
+    tot = diff = 0
+    for n in sorted(os.listdir(outs[0])):
+        a = torch.load(os.path.join(outs[0], n, "data.pth"), weights_only=True)["qweight"]
+        b = torch.load(os.path.join(outs[1], n, "data.pth"), weights_only=True)["qweight"]
+        tot += a.numel()
+        diff += int((a != b).sum())
+    assert sorted(os.listdir(outs[0])) == sorted(os.listdir(outs[1])) and diff / tot < 0.02, diff / tot
+    h = [torch.randn(1, 8, 4) for _ in range(5)]
+    pos = torch.arange(8).unsqueeze(0)
+    args = [(x,) for x in h]
+    kws = [{"position_ids": pos.clone(), "use_cache": False} for _ in h]
+    kws[3]["position_ids"] = pos + 1  # sample 3 differs from both neighbours: runs [0, 1, 2], [3], [4]
+    a2, k2 = _batch_block_inputs(args, kws, 4)
+    assert [a[0].shape[0] for a in a2] == [3, 1, 1] and torch.equal(a2[0][0], torch.cat(h[:3]))
+    assert torch.equal(k2[1]["position_ids"], pos + 1) and a2[2][0] is h[4]
+    a3, _ = _batch_block_inputs(args[:3], kws[:3], 2)
+    assert [a[0].shape[0] for a in a3] == [2, 1]
