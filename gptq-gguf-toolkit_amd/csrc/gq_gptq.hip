@@ -234,7 +234,7 @@ int gptq_quantize(float* W, const float* U, int64_t R, int64_t C, int q_type, in
     // one device word shared by all scale-search launches of this call (each leaves it at zero)
     unsigned* panel = reinterpret_cast<unsigned*>(
         (reinterpret_cast<uintptr_t>(Wblk + ((B > SEG) ? (size_t)R * B : 0)) + 255) & ~(uintptr_t)255);
-    if (ti.k_search && static_groups != 2) GQ_HIP(hipMemsetAsync(panel, 0, 4, st));
+    if (ti.k_search && static_groups != 2) GQ_HIP(hipMemsetAsync(panel, 0, 8, st));
     const int64_t ng = C / ti.group, nsg = C / 256;
     const int gps = 256 / ti.group;
     int rc;

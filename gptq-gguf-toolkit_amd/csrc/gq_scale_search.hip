@@ -134,11 +134,12 @@ struct SearchParams {
 };
 
 // quant_utils.py:199-274 for one group spread over LPG lanes; NS = G/LPG values per lane.
-// `skip`: iterations the WHOLE panel skips (bit i), `valid`: bit i set when this group has D > eps in iteration i --
-// the two halves of the panel-wide `if not valid.any(): continue` of :250-252, see panel_fixup_kernel.
+// `skip`: iterations the WHOLE panel skips (bit i); `valid`: bit i set when this group has D > eps in iteration i;
+// `accepted`: bit i set when this group took the candidate of iteration i -- what panel_fixup_kernel needs to follow
+// the panel-wide `if not valid.any(): continue` of :250-252.
 template <int NS, int BITS, int RM, int LPG>
 __device__ __forceinline__ void k_search(const float (&x)[NS], const SearchParams& sp, float& scale_out,
-                                         float& zero_out, unsigned skip, unsigned& valid) {
+                                         float& zero_out, unsigned skip, unsigned& valid, unsigned& accepted) {
     constexpr float maxq = (float)((1 << BITS) - 1);
     constexpr float G = (float)(NS * LPG);
     constexpr int NA = 8 / LPG;
@@ -239,6 +240,7 @@ __device__ __forceinline__ void k_search(const float (&x)[NS], const SearchParam
             // valid in this iteration (NaN / inf candidates lose the comparison); when NONE is, the reference skips
             // the iteration for everyone -- detected through `valid`, redone by panel_fixup_kernel.
             if (cand_err < best_err) {  // :266-271 (NaN compares false)
+                accepted |= 1u << i;
                 best_err = cand_err;
                 best_scale = this_scale;
                 x_min = this_min;
@@ -279,12 +281,18 @@ __device__ __forceinline__ float load_x(const void* x, int64_t idx) {
     else return bf2f(reinterpret_cast<const uint16_t*>(x)[idx]);
 }
 
-// OR of the lanes' per-iteration valid bits into the panel word (one atomic per wave, skipped when nothing is new)
-__device__ __forceinline__ void publish_valid(unsigned* panel_valid, unsigned v) {
+// OR of the lanes' per-iteration bits into the panel words: [0] valid, [1] accepted (one atomic per wave and word,
+// skipped when nothing is new)
+__device__ __forceinline__ void publish_valid(unsigned* panel, unsigned v, unsigned a) {
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v |= (unsigned)__shfl_xor((int)v, o);
-    if ((threadIdx.x & 63) == 0 && (__hip_atomic_load(panel_valid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & v) != v)
-        atomicOr(panel_valid, v);
+    for (int o = 32; o >= 1; o >>= 1) {
+        v |= (unsigned)__shfl_xor((int)v, o);
+        a |= (unsigned)__shfl_xor((int)a, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if ((__hip_atomic_load(panel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & v) != v) atomicOr(panel, v);
+        if ((__hip_atomic_load(panel + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & a) != a) atomicOr(panel + 1, a);
+    }
 }
 
 // One workgroup = 256 threads = 256/(NG*8) row-panels.  NG = 256/G groups per row.
@@ -314,9 +322,9 @@ __global__ __launch_bounds__(256) void scale_search_kernel(
 
     float gscale, gzero;
     if constexpr (KSEARCH) {
-        unsigned valid = 0;
-        k_search<NS, BITS, RM, 8>(xv, sp, gscale, gzero, 0u, valid);
-        if (panel_valid) publish_valid(panel_valid, valid);
+        unsigned valid = 0, accepted = 0;
+        k_search<NS, BITS, RM, 8>(xv, sp, gscale, gzero, 0u, valid, accepted);
+        if (panel_valid) publish_valid(panel_valid, valid, live ? accepted : 0u);
     } else {
         absmax_search<NS, BITS, RM, 8>(xv, gscale, gzero);
     }
@@ -399,9 +407,9 @@ __global__ __launch_bounds__(64) void scale_search_lane_kernel(
 
     float gscale, gzero;
     if constexpr (KSEARCH) {
-        unsigned valid = 0;
-        k_search<NS, BITS, RM, LPG>(xv, sp, gscale, gzero, 0u, valid);
-        if (panel_valid) publish_valid(panel_valid, valid);
+        unsigned valid = 0, accepted = 0;
+        k_search<NS, BITS, RM, LPG>(xv, sp, gscale, gzero, 0u, valid, accepted);
+        if (panel_valid) publish_valid(panel_valid, valid, live ? accepted : 0u);
     } else {
         absmax_search<NS, BITS, RM, LPG>(xv, gscale, gzero);
     }
@@ -437,9 +445,10 @@ __global__ __launch_bounds__(64) void scale_search_lane_kernel(
 // kernel follows every search launch: if every iteration had a valid group (any panel with an entry above ~1e-6) it
 // returns at once.  Otherwise the reference skipped iterations the kernels ran: with S = the set of skipped
 // iterations (initially empty), the first iteration outside S without a valid group is one the reference skips --
-// everything before it ran on the right state -- so it joins S and the whole panel is searched again with S, until
-// no such iteration is left (at most nstep + 1 rounds; a panel of denormals or of constant groups, never a weight
-// matrix).  One lane per group, plain loads: the slow path only has to be right.  Leaves the panel word at 0.
+// everything before it ran on the right state -- so it joins S; if some group had TAKEN that iteration's candidate
+// the whole panel is searched again with S (its state differs from there on), else nothing changes downstream.
+// Repeated until no such iteration is left (at most nstep + 1 searches; a panel of ~1e-8 values or of constant
+// groups, never a weight matrix -- Q5_K panels take the no-search branch every time).  One lane per group, plain loads: the slow path only has to be right.  Leaves the panel word at 0.
 template <int GSZ, int BITS, bool SIGNED, int SMQ, int RM>
 __global__ __launch_bounds__(256) void panel_fixup_kernel(
     const void* __restrict__ x, int64_t rows, int64_t ld, SearchParams sp,
@@ -448,16 +457,24 @@ __global__ __launch_bounds__(256) void panel_fixup_kernel(
     float* __restrict__ gs_out, float* __restrict__ gz_out, unsigned* panel_valid) {
     constexpr int NG = 256 / GSZ;
     constexpr int RPB = 256 / NG;  // rows per pass of the workgroup
-    __shared__ unsigned sh_valid;
+    __shared__ unsigned sh_valid, sh_acc;
     const unsigned full = (2u << sp.nstep) - 1u;
-    unsigned V = *panel_valid & full;
+    unsigned V = panel_valid[0] & full, A = panel_valid[1] & full;
     unsigned skip = 0;
     const int tid = threadIdx.x, g = tid % NG, row_l = tid / NG;
     while (true) {
         const unsigned missing = full & ~(V | skip);
-        if (missing == 0) break;              // uniform: V and skip are the same in every thread
-        skip |= missing & (0u - missing);     // the lowest iteration nobody was valid in
-        if (tid == 0) sh_valid = 0;
+        if (missing == 0) break;              // uniform: V, A and skip are the same in every thread
+        const unsigned i0 = missing & (0u - missing);  // the lowest iteration nobody was valid in: the reference skips it
+        skip |= i0;
+        // nobody TOOK its candidate either (the usual case: Q5_K's uint8-wrapped squares make D negative for every
+        // group of ordinary weights, and such candidates never win): skipping it changes no state, the bits of the
+        // later iterations stand
+        if ((A & i0) == 0) continue;
+        if (tid == 0) {
+            sh_valid = 0;
+            sh_acc = 0;
+        }
         __syncthreads();
         for (int64_t r0 = 0; r0 < rows; r0 += RPB) {
             const int64_t row = r0 + row_l;
@@ -467,9 +484,10 @@ __global__ __launch_bounds__(256) void panel_fixup_kernel(
 #pragma unroll
             for (int k = 0; k < GSZ; ++k) xv[k] = load_x<RM>(x, base + k);
             float gscale, gzero;
-            unsigned valid = 0;
-            k_search<GSZ, BITS, RM, 1>(xv, sp, gscale, gzero, skip, valid);
+            unsigned valid = 0, accepted = 0;
+            k_search<GSZ, BITS, RM, 1>(xv, sp, gscale, gzero, skip, valid, accepted);
             if (live && valid) atomicOr(&sh_valid, valid);
+            if (live && accepted) atomicOr(&sh_acc, accepted);
             if (gs_out && live) {
                 gs_out[row * NG + g] = gscale;
                 gz_out[row * NG + g] = gzero;
@@ -497,9 +515,13 @@ __global__ __launch_bounds__(256) void panel_fixup_kernel(
         }
         __syncthreads();
         V = sh_valid & full;
+        A = sh_acc & full;
         __syncthreads();
     }
-    if (tid == 0) *panel_valid = 0;
+    if (tid == 0) {
+        panel_valid[0] = 0;
+        panel_valid[1] = 0;
+    }
 }
 
 template <int RM>
@@ -514,7 +536,7 @@ static int launch_ss(const void* x, int64_t rows, int64_t ld, int q_type, const 
     void* own = nullptr;
     if (ti.k_search && !panel && (!p || p->nstep >= 1)) {
         GQ_HIP(hipMallocAsync(&own, 256, st));
-        GQ_HIP(hipMemsetAsync(own, 0, 4, st));
+        GQ_HIP(hipMemsetAsync(own, 0, 8, st));
         panel = reinterpret_cast<unsigned*>(own);
     }
     SearchParams sp;
