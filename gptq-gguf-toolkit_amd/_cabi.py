@@ -31,7 +31,8 @@ class TypeInfo(ctypes.Structure):
 
 
 class Search(ctypes.Structure):
-    _fields_ = [("rmin", ctypes.c_double), ("rdelta", ctypes.c_double), ("nstep", ctypes.c_int)]
+    _fields_ = [("rmin", ctypes.c_double), ("rdelta", ctypes.c_double), ("nstep", ctypes.c_int),
+                ("quant_scale", ctypes.c_int), ("grid", ctypes.c_int), ("maxshrink", ctypes.c_double)]
 
 
 def build(force: bool = False) -> str:

@@ -131,6 +131,8 @@ __device__ __forceinline__ float R(float v) {
 struct SearchParams {
     float num[24];  // fp32(rmin + rdelta*i + maxq), evaluated in double on the host
     int nstep;
+    int mse_n;       // quant_scale == "mse": candidates of the grid search, int(maxshrink * grid) + 1; 0: absmax
+    double mse_den;  // maxshrink * grid
 };
 
 // quant_utils.py:199-274 for one group spread over LPG lanes; NS = G/LPG values per lane.
@@ -251,9 +253,12 @@ __device__ __forceinline__ void k_search(const float (&x)[NS], const SearchParam
     zero_out = -x_min;  // :273
 }
 
-// quant_utils.py:147-197 (absmax branch)
+// quant_utils.py:147-197: absmax, and with sp.mse_n > 0 the "mse" grid search of :164-191 -- verbatim, i.e. with the
+// .round() that lands on the SCALE (:180: for scales <= 0.5 the divisor is 0, every candidate gives q_int = 0 and the
+// first one, the absmax scale, is kept) and with the un-rounded q_int.
 template <int NS, int BITS, int RM, int LPG>
-__device__ __forceinline__ void absmax_search(const float (&x)[NS], float& scale_out, float& zero_out) {
+__device__ __forceinline__ void absmax_search(const float (&x)[NS], const SearchParams& sp, float& scale_out,
+                                              float& zero_out) {
     constexpr float maxq = (float)((1 << BITS) - 1);
     float mn = x[0], mx = x[0];
 #pragma unroll
@@ -272,6 +277,38 @@ __device__ __forceinline__ void absmax_search(const float (&x)[NS], float& scale
     }
     scale_out = R<RM>(R<RM>(mx - mn) / maxq);  // :161
     zero_out = 0.0f;                           // :195
+    if (sp.mse_n > 0) {
+        constexpr int NA = 8 / LPG;
+        const float zq = R<RM>((maxq + 1.0f) / 2.0f);  // :162
+        const float eps = R<RM>(1e-9f);
+        float amax = fabsf(mn);
+        amax = mx > amax ? mx : amax;  // :171
+        float min_loss = __builtin_inff(), best = 0.0f;
+        for (int i = 0; i < sp.mse_n; ++i) {
+            const float alpha = R<RM>((float)(1.0 - (double)i / sp.mse_den));  // :170
+            const float cand = R<RM>(amax * alpha);
+            const float xmax1 = mx < cand ? mx : cand;       // :173
+            const float xmin1 = mn > -cand ? mn : -cand;     // :174
+            const float scale1 = R<RM>(R<RM>(xmax1 - xmin1) / maxq);  // :176
+            float c = scale1 < eps ? eps : scale1;
+            if (scale1 != scale1) c = scale1;
+            const float dv = rintf(c);  // :180
+            float a0[NA];
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const float q = clampf(R<RM>(R<RM>(x[k] - zq) / dv), 0.0f, maxq);  // :179-181 (NaN stays NaN)
+                const float y = R<RM>(R<RM>(q * scale1) + zq);                      // :182
+                const float df = R<RM>(y - x[k]);
+                GQ_ACC(a0, k, R<RM>(df * df));                                      // :183
+            }
+            const float loss = R<RM>(group_sum<LPG, NA>(a0));
+            if (loss < min_loss) {  // :185-189
+                min_loss = loss;
+                best = scale1;
+            }
+        }
+        scale_out = best;  // :190
+    }
 }
 
 template <int RM>
@@ -326,7 +363,7 @@ __global__ __launch_bounds__(256) void scale_search_kernel(
         k_search<NS, BITS, RM, 8>(xv, sp, gscale, gzero, 0u, valid, accepted);
         if (panel_valid) publish_valid(panel_valid, valid, live ? accepted : 0u);
     } else {
-        absmax_search<NS, BITS, RM, 8>(xv, gscale, gzero);
+        absmax_search<NS, BITS, RM, 8>(xv, sp, gscale, gzero);
     }
     if (l8 == 0) {
         sh_scale[row_l][g] = gscale;
@@ -411,7 +448,7 @@ __global__ __launch_bounds__(64) void scale_search_lane_kernel(
         k_search<NS, BITS, RM, LPG>(xv, sp, gscale, gzero, 0u, valid, accepted);
         if (panel_valid) publish_valid(panel_valid, valid, live ? accepted : 0u);
     } else {
-        absmax_search<NS, BITS, RM, LPG>(xv, gscale, gzero);
+        absmax_search<NS, BITS, RM, LPG>(xv, sp, gscale, gzero);
     }
     if (gs_out && live && h == 0) {  // make_k_quants / make_quants outputs (gq_group_search)
         gs_out[row * NG + g] = gscale;
@@ -545,6 +582,16 @@ static int launch_ss(const void* x, int64_t rows, int64_t ld, int q_type, const 
     const double rmin = p ? p->rmin : -1.0, rdelta = p ? p->rdelta : 0.1;
     const double maxq = (double)((1 << ti.bits) - 1);
     for (int i = 0; i < 24; ++i) sp.num[i] = (float)(rmin + rdelta * (double)i + maxq);
+    sp.mse_n = 0;
+    sp.mse_den = 1.0;
+    if (p && p->quant_scale == 1 && !ti.k_search) {  // make_k_quants ignores quant_scale
+        sp.mse_den = p->maxshrink * (double)p->grid;
+        sp.mse_n = (int)sp.mse_den + 1;
+        if (!(sp.mse_den > 0.0) || sp.mse_n > 100000)
+            GQ_FAIL(GQ_E_UNSUPPORTED, "gq_scale_search: quant_scale=mse with grid=%d maxshrink=%g", p->grid, p->maxshrink);
+    } else if (p && p->quant_scale != 0 && p->quant_scale != 1) {
+        GQ_FAIL(GQ_E_UNSUPPORTED, "gq_scale_search: quant_scale=%d (0: absmax, 1: mse)", p->quant_scale);
+    }
     // Three mappings with identical arithmetic (profiles/ss_probe.py): one lane per group does half the VALU work
     // of the 8-lane kernel but a wave takes ~35 us whatever the size -- used from one wave per SIMD up
     // (rows * groups >= 65536); a lane PAIR per group halves that latency at +12 % work -- the middle range, where the

@@ -18,8 +18,7 @@ from torch.nn.modules.conv import _ConvNd
 
 from . import dist_utils, model_utils
 from . import ops as _ops
-from .quant_utils import (GGML_QUANT_SIZES, GGMLQuantizationType, QuantizationScale, _check_scale,
-                          check_mse_equivalent)
+from .quant_utils import GGML_QUANT_SIZES, GGMLQuantizationType, QuantizationScale, _check_scale
 
 
 class GPTQ:
@@ -257,10 +256,6 @@ class GPTQ:
         if q_type == GGMLQuantizationType.Q3_K:  # reference gptq.py:204-206 mutates the handle
             self.act_order = False
             self.static_groups = False
-        if self.quant_scale is QuantizationScale.MSE:
-            # the lazy scale search sees error-compensated weights: keep a factor 4 between the original weights
-            # and the value at which the reference's MSE branch stops being the absmax search
-            check_mse_equivalent(q_type, float(self.W.max().item()), margin=4.0)
         if self.act_order:
             return self._compute_act_order(q_type)
         U = self._prepare(defer_check, own_U)
@@ -272,7 +267,7 @@ class GPTQ:
                 return tuple(t[:0] for t in self._empty_result(q_type))
             W = self.W[r0:r1]
         return _ops.gptq_quantize(W, U, int(q_type), self.block_size, self.static_groups, self.rmin,
-                                  self.rdelta, self.nstep)
+                                  self.rdelta, self.nstep, quant_scale=self.quant_scale.value, grid=self.grid)
 
     def _row_split_active(self) -> bool:
         return bool(self.row_split) and not self.act_order and dist_utils.get_world_size() > 1
@@ -292,7 +287,8 @@ class GPTQ:
         # torch.argsort is not stable in the reference either; ties only occur between dead channels, whose
         # rows/columns of H and columns of W are identical, so their relative order cannot change a result
         perm = torch.argsort(diag, descending=True, stable=True)
-        _, d, s, dmin, m = _ops.rtn_quantize(self.W, int(q_type), self.rmin, self.rdelta, self.nstep)  # :184-196
+        _, d, s, dmin, m = _ops.rtn_quantize(self.W, int(q_type), self.rmin, self.rdelta, self.nstep,
+                                             quant_scale=self.quant_scale.value, grid=self.grid)  # :184-196
         Wp = self.W[:, perm].contiguous()                  # :213
         Hp = H[perm][:, perm].contiguous()                 # :214 (a copy: shared Hessians stay untouched)
         U, self._flag = _ops.h_prepare(Hp, Wp, self.rel_damp)

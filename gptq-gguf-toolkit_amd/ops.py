@@ -29,8 +29,13 @@ def _need_cuda(*ts):
             raise _cabi.GQError("gptq_gguf_toolkit_amd ops need GPU tensors (no CPU fallback); got a CPU tensor")
 
 
-def _search(rmin=-1.0, rdelta=0.1, nstep=20):
-    return ctypes.byref(Search(float(rmin), float(rdelta), int(nstep)))
+def _search(rmin=-1.0, rdelta=0.1, nstep=20, quant_scale="absmax", grid=100, maxshrink=0.8):
+    """gq_search_t: make_k_quants' (rmin, rdelta, nstep) and make_quants' quant_scale ("absmax" | "mse", with the
+    grid / maxshrink of quant_utils.py:164-191)."""
+    mode = getattr(quant_scale, "value", quant_scale)
+    if mode not in ("absmax", "mse"):
+        raise ValueError(f"quant_scale must be 'absmax' or 'mse', got {quant_scale!r}")
+    return ctypes.byref(Search(float(rmin), float(rdelta), int(nstep), int(mode == "mse"), int(grid), float(maxshrink)))
 
 
 def _idt(q_type):
@@ -165,7 +170,7 @@ def h_unpack_upper(buf: torch.Tensor, H: torch.Tensor) -> torch.Tensor:
     return H
 
 
-def scale_search(x: torch.Tensor, q_type: int, rmin=-1.0, rdelta=0.1, nstep=20):
+def scale_search(x: torch.Tensor, q_type: int, rmin=-1.0, rdelta=0.1, nstep=20, **mq):
     """get_scale_and_zero on x[rows,256] (row stride free).  Returns (d f16[rows], s[rows,ng], dmin f16[rows], m)."""
     _need_cuda(x)
     assert x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] == 256 and x.stride(1) == 1
@@ -176,7 +181,7 @@ def scale_search(x: torch.Tensor, q_type: int, rmin=-1.0, rdelta=0.1, nstep=20):
     dmin = torch.empty(rows, dtype=torch.float16, device=dev)
     s = torch.empty(rows, ng, dtype=torch.uint8, device=dev)
     m = torch.empty(rows, ng, dtype=torch.uint8, device=dev)
-    check(lib().gq_scale_search(_ptr(x), rows, x.stride(0), int(q_type), _search(rmin, rdelta, nstep), _ptr(d), 1,
+    check(lib().gq_scale_search(_ptr(x), rows, x.stride(0), int(q_type), _search(rmin, rdelta, nstep, **mq), _ptr(d), 1,
                                 _ptr(s), ng, _ptr(dmin), 1, _ptr(m), ng, _stream(x)), "gq_scale_search")
     t = _idt(q_type)
     return d, s.view(t), dmin, m.view(t)
@@ -201,7 +206,7 @@ def _streams(device, n):
 
 
 def gptq_quantize(W: torch.Tensor, U: torch.Tensor, q_type: int, block_size=128, static_groups=False, rmin=-1.0,
-                  rdelta=0.1, nstep=20, ws: Optional[torch.Tensor] = None, row_chunks: Optional[int] = None):
+                  rdelta=0.1, nstep=20, ws: Optional[torch.Tensor] = None, row_chunks: Optional[int] = None, **mq):
     """GPTQ.step body.  W (fp32, contiguous) is updated IN PLACE to the dequantized matrix.
     Returns (qweight, d, s, dmin, m).
 
@@ -226,7 +231,7 @@ def gptq_quantize(W: torch.Tensor, U: torch.Tensor, q_type: int, block_size=128,
         if wsbuf is None or wsbuf.numel() < need:
             wsbuf = _ws(need, W.device)
         check(lib().gq_gptq_quantize(_ptr(W[r0:r1]), _ptr(U), n, C, int(q_type), bs, int(bool(static_groups)),
-                                     _search(rmin, rdelta, nstep), _ptr(q[r0:r1]), _ptr(d[r0:r1]), _ptr(s[r0:r1]),
+                                     _search(rmin, rdelta, nstep, **mq), _ptr(q[r0:r1]), _ptr(d[r0:r1]), _ptr(s[r0:r1]),
                                      _ptr(dmin[r0:r1]), _ptr(m[r0:r1]), _ptr(wsbuf), wsbuf.numel(), _stream(W)),
               "gq_gptq_quantize")
         return wsbuf
@@ -272,12 +277,12 @@ def gptq_quantize_perm(W: torch.Tensor, U: torch.Tensor, q_type: int, perm: torc
     return q.view(_idt(q_type))
 
 
-def rtn_quantize(W: torch.Tensor, q_type: int, rmin=-1.0, rdelta=0.1, nstep=20):
+def rtn_quantize(W: torch.Tensor, q_type: int, rmin=-1.0, rdelta=0.1, nstep=20, **mq):
     _need_cuda(W)
     assert W.is_contiguous() and W.dim() == 2 and W.dtype in _DT
     R, C = W.shape
     q, d, s, dmin, m = _alloc_outs(R, C, q_type, W.device)
-    check(lib().gq_rtn_quantize(_ptr(W), _DT[W.dtype], R, C, int(q_type), _search(rmin, rdelta, nstep), _ptr(q),
+    check(lib().gq_rtn_quantize(_ptr(W), _DT[W.dtype], R, C, int(q_type), _search(rmin, rdelta, nstep, **mq), _ptr(q),
                                 _ptr(d), _ptr(s), _ptr(dmin), _ptr(m), _stream(W)), "gq_rtn_quantize")
     t = _idt(q_type)
     return q.view(t), d, s.view(t), dmin, m.view(t)
@@ -316,7 +321,7 @@ def trailing_update(Cm: torch.Tensor, A: torch.Tensor, B: torch.Tensor):
     return Cm
 
 
-def group_search(x: torch.Tensor, q_type: int, rmin=-1.0, rdelta=0.1, nstep=20):
+def group_search(x: torch.Tensor, q_type: int, rmin=-1.0, rdelta=0.1, nstep=20, **mq):
     """make_k_quants / make_quants on a [rows,256] panel (fp32, or fp16/bf16 with per-op rounding).
     Returns (group_scale f32[rows,ng], group_zero f32[rows,ng], d, s, dmin, m)."""
     _need_cuda(x)
@@ -330,7 +335,7 @@ def group_search(x: torch.Tensor, q_type: int, rmin=-1.0, rdelta=0.1, nstep=20):
     dmin = torch.empty(rows, dtype=torch.float16, device=dev)
     s = torch.empty(rows, ng, dtype=torch.uint8, device=dev)
     m = torch.empty(rows, ng, dtype=torch.uint8, device=dev)
-    check(lib().gq_group_search(_ptr(x), _DT[x.dtype], rows, x.stride(0), int(q_type), _search(rmin, rdelta, nstep),
+    check(lib().gq_group_search(_ptr(x), _DT[x.dtype], rows, x.stride(0), int(q_type), _search(rmin, rdelta, nstep, **mq),
                                 _ptr(gs), _ptr(gz), _ptr(d), _ptr(s), _ptr(dmin), _ptr(m), _stream(x)),
           "gq_group_search")
     t = _idt(q_type)

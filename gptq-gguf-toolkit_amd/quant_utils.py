@@ -47,28 +47,6 @@ def _check_scale(quant_scale):
     return QuantizationScale(quant_scale)
 
 
-def mse_equals_absmax_bound(q_type) -> float:
-    """quant_scale="mse" only touches make_quants (Q3_K / Q6_K, reference quant_utils.py:164-191), and there the grid
-    search computes q_int = clamp((x - zero) / round(max(scale1, 1e-9)), 0, maxq) with zero = (maxq + 1) / 2 (:162,:180):
-    whenever every value of a group is BELOW zero (4 for Q3_K, 32 for Q6_K -- any LLM weight) all 81 candidates give
-    q_int = 0 and the same loss, the first one (alpha = 1) is kept, and the branch returns exactly the absmax scale.
-    Pinned by tests/golden G12 (reference runs in both modes).  Returns that bound; values at or above it make the
-    reference's branch depend on the misplaced .round() and are not reproduced here."""
-    bits = GGML_QUANT_SIZES[GGMLQuantizationType(q_type)][0]
-    return float(2 ** bits) / 2.0
-
-
-def check_mse_equivalent(q_type, max_value: float, margin: float = 1.0) -> None:
-    if GGMLQuantizationType(q_type) not in (GGMLQuantizationType.Q3_K, GGMLQuantizationType.Q6_K):
-        return  # make_k_quants never looks at quant_scale
-    bound = mse_equals_absmax_bound(q_type) / margin
-    if not max_value < bound:
-        raise NotImplementedError(
-            f"quant_scale='mse': a value of {max_value:g} >= {bound:g} makes the reference's grid search "
-            "(quant_utils.py:164-191, misplaced .round() at :180) differ from absmax; only the regime where both "
-            "agree exactly is implemented")
-
-
 class Quantizer:
     """Scale/min search configuration + get_scale_and_zero (reference quant_utils.py:49-145)."""
 
@@ -94,16 +72,17 @@ class Quantizer:
         assert x.ndim == 2 and x.shape[1] == QK_K, f"expected (rows, {QK_K})"
         if x.stride(1) != 1:
             x = x.contiguous()
-        if self.quant_scale is QuantizationScale.MSE:
-            check_mse_equivalent(q_type, float(x.max().item()))
+        mq = dict(quant_scale=self.quant_scale.value, grid=self.grid, maxshrink=self.maxshrink)  # :164-191 (Q3_K / Q6_K)
+        if self.norm != 2.0:
+            raise NotImplementedError("norm other than the reference default 2.0 is compiled into the kernels")
         if x.dtype in (torch.float16, torch.bfloat16):
             # the reference runs make_*quants in the panel's dtype (quantizer.py:109,195 pass model-dtype weights):
             # gq_group_search rounds after every op the way ATen's CPU fp16 / bf16 kernels do
-            _, _, d, s, dmin, m = _ops.group_search(x, int(q_type), self.rmin, self.rdelta, self.nstep)
+            _, _, d, s, dmin, m = _ops.group_search(x, int(q_type), self.rmin, self.rdelta, self.nstep, **mq)
             return d, s, dmin, m
         if x.dtype != torch.float32:
             x = x.float()
-        d, s, dmin, m = _ops.scale_search(x, int(q_type), self.rmin, self.rdelta, self.nstep)
+        d, s, dmin, m = _ops.scale_search(x, int(q_type), self.rmin, self.rdelta, self.nstep, **mq)
         return d, s, dmin, m
 
 

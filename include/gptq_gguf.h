@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define GQ_ABI_VERSION 1
+#define GQ_ABI_VERSION 2
 
 /* ggml type ids (quant_utils.py:11-16) */
 enum { GQ_Q2_K = 10, GQ_Q3_K = 11, GQ_Q4_K = 12, GQ_Q5_K = 13, GQ_Q6_K = 14 };
@@ -65,11 +65,15 @@ typedef struct {
     int type_size;  /* bytes per 256-value GGUF block: 84/110/144/176/210 */
 } gq_type_info_t;
 
-/* scale-search hyper-parameters (quant.py:94-111; python floats -> double) */
+/* scale-search hyper-parameters (quant.py:94-111; python floats -> double).  ABI version 2 added the last three:
+   make_quants' quant_scale (quant_utils.py:147-197, Q3_K / Q6_K only -- make_k_quants ignores it). */
 typedef struct {
-    double rmin;   /* -1.0 */
-    double rdelta; /*  0.1 */
-    int nstep;     /*  20  */
+    double rmin;      /* -1.0 */
+    double rdelta;    /*  0.1 */
+    int nstep;        /*  20  */
+    int quant_scale;  /* 0: "absmax" (default), 1: "mse" = the grid search of quant_utils.py:164-191, verbatim */
+    int grid;         /* 100 (gptq.py:41) */
+    double maxshrink; /* 0.80 (quant_utils.py:64) */
 } gq_search_t;
 
 int gq_abi_version(void);

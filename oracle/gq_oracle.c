@@ -270,6 +270,15 @@ void gqo_make_k_quants(const float* x, int64_t n_groups, int G, int bits,
 
 /* ---------------------------------------------------------- make_quants */
 
+/* quant_scale == "mse" (quant_utils.py:164-191): set through gqo_set_quant_scale (test infrastructure: one global). */
+static int g_mse = 0, g_grid = 100;
+static double g_maxshrink = 0.8;
+void gqo_set_quant_scale(int mse, int grid, double maxshrink) {
+    g_mse = mse;
+    g_grid = grid;
+    g_maxshrink = maxshrink;
+}
+
 static void make_quants_r(const float* x, int64_t n_groups, int G, int bits, int rmode, float* scale, float* zero) {
     const float maxq = (float)((1 << bits) - 1); /* quant_utils.py:74 */
 #pragma omp parallel for schedule(static)
@@ -289,6 +298,37 @@ static void make_quants_r(const float* x, int64_t n_groups, int G, int bits, int
         }
         scale[g] = R(R(mx - mn) / maxq); /* :161 */
         zero[g] = 0.0f;                  /* :195 */
+        if (g_mse) { /* :164-191, verbatim incl. the .round() that lands on the SCALE (:180) and the un-rounded q_int */
+            const float zq = R((maxq + 1.0f) / 2.0f); /* :162 */
+            const double den = g_maxshrink * (double)g_grid;
+            const int n = (int)den + 1; /* :169 */
+            float min_loss = INFINITY, best = 0.0f;
+            float amax = fabsf(mn);
+            amax = mx > amax ? mx : amax; /* :171 torch.max(xmax, |xmin|) */
+            for (int i = 0; i < n; ++i) {
+                const float alpha = R((float)(1.0 - (double)i / den)); /* :170, python double -> tensor dtype */
+                const float cand = R(amax * alpha);
+                const float xmax1 = mx < cand ? mx : cand;     /* :173 */
+                const float xmin1 = mn > -cand ? mn : -cand;   /* :174 */
+                const float scale1 = R(R(xmax1 - xmin1) / maxq); /* :176 */
+                float c = scale1 < R(1e-9f) ? R(1e-9f) : scale1;
+                if (scale1 != scale1) c = scale1;
+                const float dv = rintf(c); /* :180 clamp_min(1e-9).round() */
+                float terms[32];
+                for (int j = 0; j < G; ++j) {
+                    float q = clampf(R(R(xg[j] - zq) / dv), 0.0f, maxq); /* :179-181 */
+                    float y = R(R(q * scale1) + zq);                      /* :182 */
+                    float df = R(y - xg[j]);
+                    terms[j] = R(df * df);                                /* :183 pow(2.0) == x * x */
+                }
+                const float loss = R(gqo_aten_sum(terms, G));
+                if (loss < min_loss) { /* :185-189 */
+                    min_loss = loss;
+                    best = scale1;
+                }
+            }
+            scale[g] = best; /* :190 */
+        }
     }
 }
 

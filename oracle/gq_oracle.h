@@ -58,6 +58,8 @@ void gqo_make_k_quants(const float* x, int64_t n_groups, int G, int bits,
                        double rmin, double rdelta, int nstep, float* scale, float* zero);
 
 /* reference quant_utils.py:147-197 make_quants, absmax branch. */
+/* quant_scale == "mse" for make_quants (quant_utils.py:164-191): 1 / grid / maxshrink; 0 = absmax (default) */
+void gqo_set_quant_scale(int mse, int grid, double maxshrink);
 void gqo_make_quants(const float* x, int64_t n_groups, int G, int bits, float* scale, float* zero);
 
 /* reference quant_utils.py:90-145 get_scale_and_zero on a [rows,256] panel with

@@ -99,6 +99,14 @@ def make_k_quants(x, bits, rmin=-1.0, rdelta=0.1, nstep=20):
     return sc, ze
 
 
+def set_quant_scale(mode="absmax", grid=100, maxshrink=0.8):
+    """make_quants' quant_scale (quant_utils.py:164-191) for every later call of this module: "absmax" or "mse"."""
+    L = lib()
+    L.gqo_set_quant_scale.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_double]
+    L.gqo_set_quant_scale.restype = None
+    L.gqo_set_quant_scale(int(mode == "mse"), int(grid), float(maxshrink))
+
+
 def make_quants(x, bits):
     x = np.ascontiguousarray(x, np.float32)
     n, G = x.shape

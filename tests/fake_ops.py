@@ -59,9 +59,15 @@ def w_prepare(cf, W):
     return torch.tensor([int(not torch.equal(mine, zc))], dtype=torch.int32)
 
 
-def gptq_quantize(W, U, q_type, block_size=128, static_groups=False, rmin=-1.0, rdelta=0.1, nstep=20, ws=None):
+def _mode(mq):
+    O.set_quant_scale(mq.get("quant_scale", "absmax"), mq.get("grid", 100), mq.get("maxshrink", 0.8))
+
+
+def gptq_quantize(W, U, q_type, block_size=128, static_groups=False, rmin=-1.0, rdelta=0.1, nstep=20, ws=None, **mq):
     calls["gptq_quantize"] += 1
+    _mode(mq)
     Wd, q, d, s, dmin, m = O.gptq_step(W.numpy(), U.numpy(), q_type, block_size, static_groups, rmin, rdelta, nstep)
+    _mode({})
     W.copy_(torch.from_numpy(Wd))
     return torch.from_numpy(q), _f16(d), torch.from_numpy(s), _f16(dmin), torch.from_numpy(m)
 
@@ -73,8 +79,10 @@ def gptq_quantize_perm(W, U, q_type, perm, d, s, dmin, m, block_size=128, ws=Non
     return torch.from_numpy(q)
 
 
-def rtn_quantize(W, q_type, rmin=-1.0, rdelta=0.1, nstep=20):
+def rtn_quantize(W, q_type, rmin=-1.0, rdelta=0.1, nstep=20, **mq):
+    _mode(mq)
     q, d, s, dmin, m = O.rtn_quantize(W.float().numpy(), q_type, rmin, rdelta, nstep)
+    _mode({})
     return torch.from_numpy(q), _f16(d), torch.from_numpy(s), _f16(dmin), torch.from_numpy(m)
 
 
@@ -88,8 +96,10 @@ def pack(q_type, q, d, s, dmin=None, m=None):
                                    None if m is None else m.numpy()))
 
 
-def scale_search(x, q_type, rmin=-1.0, rdelta=0.1, nstep=20):
+def scale_search(x, q_type, rmin=-1.0, rdelta=0.1, nstep=20, **mq):
+    _mode(mq)
     d, s, dmin, m = O.scale_search(x.numpy(), q_type, rmin, rdelta, nstep)
+    _mode({})
     return _f16(d), torch.from_numpy(s), _f16(dmin), torch.from_numpy(m)
 
 

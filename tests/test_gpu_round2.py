@@ -534,3 +534,40 @@ def test_quantizer_get_scale_and_zero_in_the_panel_dtype(ops, tag, dt):
             assert np.array_equal(u16(d), g[f"{pre}{name}_d"][:, sg]) and np.array_equal(u16(dmin), g[f"{pre}{name}_dmin"][:, sg])
             assert np.array_equal(npy(s), g[f"{pre}{name}_s"][:, sg * gps:(sg + 1) * gps])
             assert np.array_equal(npy(m), g[f"{pre}{name}_m"][:, sg * gps:(sg + 1) * gps])
+
+
+# ----------------------------------------------------------------- quant_scale = "mse" (quant_utils.py:164-191)
+@pytest.mark.parametrize("name", ["Q3_K", "Q6_K"])
+def test_mse_quant_scale_golden(ops, oracle, name):
+    """make_quants' MSE grid search on the GPU against the reference's outputs (G12: weight-like, mid and the wide panel
+    where the branch really differs), every kernel mapping; then the whole column loop and the RTN with quant_scale
+    = "mse" on a matrix with large values against the oracle."""
+    g = load_golden("g12_mse_scale")
+    t = TYPES[name]
+    for wide in ("0", "1", "2"):
+        os.environ["GQ_SS_WIDE"] = wide
+        try:
+            for tag in ("w", "mid", "wide"):
+                for mode in ("absmax", "mse"):
+                    d, s, dmin, m = ops.scale_search(dev(g[f"{name}_{tag}_x"]), t, quant_scale=mode)
+                    assert np.array_equal(u16(d), g[f"{name}_{tag}_{mode}_d"]), (wide, tag, mode)
+                    assert np.array_equal(npy(s), g[f"{name}_{tag}_{mode}_s"]), (wide, tag, mode)
+        finally:
+            os.environ.pop("GQ_SS_WIDE", None)
+    rng = np.random.default_rng(t)
+    R, C = 96, 512
+    W = (rng.standard_normal((R, C)) * 20.0).astype(np.float32)
+    U = np.triu(rng.standard_normal((C, C)).astype(np.float32) * 0.01, 1) + np.eye(C, dtype=np.float32)
+    try:
+        oracle.set_quant_scale("mse")
+        Wd, oq, od, os_, odm, om = oracle.gptq_step(W, U, t, block_size=128)
+        rq, rd, rs, rdm, rm = oracle.rtn_quantize(W, t)
+    finally:
+        oracle.set_quant_scale("absmax")
+    Wg = dev(W)
+    q, d, s, dmin, m = ops.gptq_quantize(Wg, dev(U), t, block_size=128, quant_scale="mse")
+    assert np.array_equal(npy(q), oq) and np.array_equal(u16(d), od) and np.array_equal(npy(s), os_) and np.array_equal(npy(Wg), Wd)
+    q, d, s, dmin, m = ops.rtn_quantize(dev(W), t, quant_scale="mse")
+    assert np.array_equal(npy(q), rq) and np.array_equal(u16(d), rd) and np.array_equal(npy(s), rs)
+    qa, da, sa, _, _ = ops.rtn_quantize(dev(W), t)
+    assert not np.array_equal(npy(sa), npy(s))  # the mode matters on this matrix

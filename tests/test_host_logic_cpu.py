@@ -38,27 +38,32 @@ def test_quant_config_rules(tmp_path):
         (1e-2, 128, "Q4_K", -1.0, 0.1, 20, "absmax")
 
 
-def test_quant_scale_mse_is_absmax_in_the_weight_regime(monkeypatch):
+def test_quant_scale_mse_through_the_quantizer_class(monkeypatch):
+    """quant_utils.Quantizer(quant_scale="mse").get_scale_and_zero against the reference's outputs (G12): equal to absmax
+    for weight-like panels, different -- and still the reference's -- for the wide one; make_k_quants ignores it."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import fake_ops
     fake_ops.install()
     from gptq_gguf_toolkit_amd.quant_utils import GGML_QUANT_SIZES, GGMLQuantizationType, Quantizer
-    torch.manual_seed(3)
-    x = torch.randn(32, 256) * 0.05
-    for qt in (GGMLQuantizationType.Q3_K, GGMLQuantizationType.Q6_K, GGMLQuantizationType.Q4_K):
+    g = load_golden("g12_mse_scale")
+    for qt in (GGMLQuantizationType.Q3_K, GGMLQuantizationType.Q6_K):
         bits, _, smq, G, SG, sdt, _ = GGML_QUANT_SIZES[qt]
-        outs = []
-        for mode in ("absmax", "mse"):
-            q = Quantizer()
-            q.configure(bits, smq, G, sdt, SG, quant_scale=mode)
-            outs.append(q.get_scale_and_zero(x.clone(), qt))
-        assert all(torch.equal(a, b) for a, b in zip(*outs))
-    q = Quantizer()
-    bits, _, smq, G, SG, sdt, _ = GGML_QUANT_SIZES[GGMLQuantizationType.Q3_K]
-    q.configure(bits, smq, G, sdt, SG, quant_scale="mse")
-    with pytest.raises(NotImplementedError, match="mse"):
-        q.get_scale_and_zero(x * 100.0, GGMLQuantizationType.Q3_K)   # 4.0 or more: the reference's branch differs
-    q.get_scale_and_zero(x * 100.0, GGMLQuantizationType.Q4_K)        # make_k_quants ignores quant_scale
+        for tag in ("w", "wide"):
+            for mode in ("absmax", "mse"):
+                q = Quantizer()
+                q.configure(bits, smq, G, sdt, SG, quant_scale=mode)
+                d, s, dmin, m = q.get_scale_and_zero(torch.from_numpy(g[f"{qt.name}_{tag}_x"].copy()), qt)
+                assert np.array_equal(d.view(torch.int16).numpy().view(np.uint16), g[f"{qt.name}_{tag}_{mode}_d"])
+                assert np.array_equal(s.numpy(), g[f"{qt.name}_{tag}_{mode}_s"])
+    torch.manual_seed(3)
+    x = torch.randn(32, 256) * 30.0
+    bits, _, smq, G, SG, sdt, _ = GGML_QUANT_SIZES[GGMLQuantizationType.Q4_K]
+    outs = []
+    for mode in ("absmax", "mse"):
+        q = Quantizer()
+        q.configure(bits, smq, G, sdt, SG, quant_scale=mode)
+        outs.append(q.get_scale_and_zero(x.clone(), GGMLQuantizationType.Q4_K))
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
 
 
 def test_sharding_and_owner_assignment():
