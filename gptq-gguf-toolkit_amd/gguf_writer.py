@@ -109,8 +109,9 @@ class GGUFWriter:
                 f.write(b"\x00" * ((-data.nbytes) % ALIGNMENT))
 
 
-def read_gguf(path: str):
-    """Tiny reader (tests / verification): -> (kv dict, {name: (shape, ggml_type, raw bytes as np.uint8)})."""
+def parse_gguf(path: str):
+    """-> (kv {key: (value, [value type ids])}, [(name, logical shape (outermost first), ggml type, absolute data
+    offset, n_bytes)], file bytes).  Spec-level reader for this package's tests and the GGUF splitter."""
     buf = open(path, "rb").read()
     pos = 0
 
@@ -129,11 +130,11 @@ def read_gguf(path: str):
 
     def rv(t):
         if t == GGUFValueType.STRING:
-            return rs()
+            return rs(), [t]
         if t == GGUFValueType.ARRAY:
             sub, n = rd("<I"), rd("<Q")
-            return [rv(sub) for _ in range(n)]
-        return rd(_SCALAR_FMT[t])
+            return [rv(sub)[0] for _ in range(n)], [t, sub]
+        return rd(_SCALAR_FMT[t]), [t]
 
     assert buf[:4] == GGUF_MAGIC
     pos = 4
@@ -142,8 +143,7 @@ def read_gguf(path: str):
     kv = {}
     for _ in range(nkv):
         k = rs()
-        t = rd("<I")
-        kv[k] = rv(t)
+        kv[k] = rv(rd("<I"))
     infos = []
     for _ in range(nt):
         name = rs()
@@ -151,10 +151,17 @@ def read_gguf(path: str):
         dims = [rd("<Q") for _ in range(nd)]
         gt, off = rd("<I"), rd("<Q")
         infos.append((name, tuple(reversed(dims)), gt, off))
-    data0 = (pos + ALIGNMENT - 1) // ALIGNMENT * ALIGNMENT
-    tensors = {}
+    align = int(kv["general.alignment"][0]) if "general.alignment" in kv else ALIGNMENT
+    data0 = (pos + align - 1) // align * align
+    tensors = []
     for name, shape, gt, off in infos:
         bs, ts = GGML_QUANT_SIZES[gt]
-        n = int(np.prod(shape)) // bs * ts
-        tensors[name] = (shape, gt, np.frombuffer(buf, np.uint8, n, data0 + off))
-    return kv, tensors
+        tensors.append((name, shape, gt, data0 + off, int(np.prod(shape)) // bs * ts))
+    return kv, tensors, buf
+
+
+def read_gguf(path: str):
+    """Tiny reader (tests / verification): -> (kv dict, {name: (shape, ggml_type, raw bytes as np.uint8)})."""
+    kv, tensors, buf = parse_gguf(path)
+    return ({k: v for k, (v, _) in kv.items()},
+            {name: (shape, gt, np.frombuffer(buf, np.uint8, n, off)) for name, shape, gt, off, n in tensors})

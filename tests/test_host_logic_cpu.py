@@ -653,3 +653,39 @@ def test_calibration_batch_merges_block_inputs(tmp_path):
     assert torch.equal(k2[1]["position_ids"], pos + 1) and a2[2][0] is h[4]
     a3, _ = _batch_block_inputs(args[:3], kws[:3], 2)
     assert [a[0].shape[0] for a in a3] == [2, 1]
+
+
+def test_gguf_splitter_database(tmp_path):
+    """f4: the EvoPress database producer (mapper/gguf_splitter.py:291-446) on a GGUF written by this package: raw tensor
+    bytes as "<bpw>-<type>.pth", per-tensor metadata, manifest with the file's KV metadata, layer database."""
+    from gptq_gguf_toolkit_amd.gguf_splitter import GGUFSplitter, main
+    from gptq_gguf_toolkit_amd.gguf_writer import GGMLType, GGUFWriter
+    rng = np.random.default_rng(1)
+    q4 = rng.integers(0, 256, (6, 2 * 144), dtype=np.uint8)
+    q3 = rng.integers(0, 256, (4, 110), dtype=np.uint8)
+    nrm = rng.standard_normal(8).astype(np.float32)
+    w = GGUFWriter(str(tmp_path / "m.gguf"), "llama")
+    w.add_uint32("llama.block_count", 1)
+    w.add_array("tokenizer.ggml.token_type", [1, 3], 5)
+    w.add_tensor("blk.0.attn_q.weight", q4, raw_dtype=GGMLType.Q4_K)
+    w.add_tensor("blk.0.ffn_down.weight", q3, raw_dtype=GGMLType.Q3_K)
+    w.add_tensor("output_norm.weight", nrm)
+    w.write()
+    main([str(tmp_path / "m.gguf"), str(tmp_path / "db"), "--exact"])
+    db = tmp_path / "db"
+    assert (db / "blk.0.attn_q.weight" / "4.5-Q4_K.pth").read_bytes() == q4.tobytes()
+    assert (db / "blk.0.ffn_down.weight" / "3.4375-Q3_K.pth").read_bytes() == q3.tobytes()
+    assert (db / "output_norm.weight" / "32-F32.pth").read_bytes() == nrm.tobytes()
+    meta = json.loads((db / "blk.0.attn_q.weight" / "4.5-Q4_K-metadata.json").read_text())["tensor_info"]
+    assert meta["shape"] == [512, 6] and meta["np_shape"] == [6, 288] and meta["np_dtype"] == "uint8" and meta["type"] == 12
+    man = json.loads((db / "manifest.json").read_text())
+    assert man["metadata"]["llama.block_count"] == {"types": [4], "value": 1}
+    assert man["metadata"]["tokenizer.ggml.token_type"] == {"types": [9, 5], "value": [1, 3]}
+    assert man["layers"]["blk.0.ffn_down.weight"]["bitwidths"]["3.4375"]["quantization"] == "Q3_K"
+    ldb = json.loads((db / "gguf_layer_database.json").read_text())
+    raw = open(tmp_path / "m.gguf", "rb").read()
+    o = ldb["blk.0.attn_q.weight"]["data_offset"]
+    assert raw[o:o + q4.nbytes] == q4.tobytes() and ldb["output_norm.weight"]["exact_bitwidth"] == 32.0
+    s2 = GGUFSplitter(str(tmp_path / "m.gguf"), str(tmp_path / "db2"))
+    s2.split_gguf_model()
+    assert (tmp_path / "db2" / "blk.0.attn_q.weight" / "4.pth").exists() and (tmp_path / "db2" / "output_norm.weight" / "32.pth").exists()
