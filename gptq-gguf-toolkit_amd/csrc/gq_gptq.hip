@@ -29,7 +29,16 @@ int launch_scale_search(const float* x, int64_t rows, int64_t ld, int q_type, co
 constexpr int SEG = 128;
 constexpr int SB = 16;  // register sub-block
 constexpr int SEG_WAVES = 8;  // wave 0 walks the dependent chain, all waves share the rank-1 tile updates
-constexpr int SEG_LDS_BYTES = (SEG * 64 + SEG * SEG + SB * 64) * 4;
+constexpr int SEG_LDS_BYTES = (SEG * 64 + SEG * SEG + 2 * SB * 64) * 4 + SEG * 8;
+
+// Correctly rounded fp32 division through an fp64 reciprocal: fl32(fl64(n * fl64(1 / d))) == fl32(n / d) for all
+// finite fp32 n, d != 0.  The exact quotient of two 24-bit significands is either representable or at least 2^-49
+// (relative) away from every fp32 rounding boundary (a boundary has 25 significant bits, so n - m d is a non-zero
+// multiple of the unit of a 49-bit product), while the two fp64 roundings move the product by at most 2^-52: the
+// final rounding sees the same side of every boundary as the exact quotient does.  Three VALU ops in the dependent
+// chain (cvt, mul_f64, cvt) instead of the 11-instruction v_div_scale / v_rcp / fma / v_div_fixup sequence -- the
+// column loop performs two divisions per column and is bound by exactly that chain.
+__device__ __forceinline__ float div_rcp64(float n, double rd) { return (float)((double)n * rd); }
 
 template <bool PERM>
 __global__ __launch_bounds__(SEG_WAVES * 64) void gptq_segment_kernel(
@@ -40,53 +49,98 @@ __global__ __launch_bounds__(SEG_WAVES * 64) void gptq_segment_kernel(
     uint8_t* __restrict__ qweight, float* __restrict__ Err, int64_t ld_err, int64_t err_col0,
     const int32_t* __restrict__ perm) {  // PERM (act_order, gptq.py:211-216): column j takes the parameters of
                                          // the group of its ORIGINAL column perm[j]
-    // One workgroup = 64 rows (lane = row) x SEG_WAVES waves.  Wave 0 walks the columns (the dependent chain);
-    // after every 16-column sub-block all waves share the rank-1 updates of the later columns.
+    // One workgroup = 64 rows (lane = row) x SEG_WAVES waves.  Wave 0 walks the columns (the dependent chain) one
+    // 16-column sub-block ("tile") at a time; the rank-1 updates of the later tiles run UNDER the next chain:
+    //   iteration t:  wave 0: chain(t) -> -err of tile t into ne[t & 1]
+    //                 waves 1..7: apply ne[(t-1) & 1] (the errors of tile t-1) to the tiles t+1.. (deferred one tile)
+    //                 barrier;  all 8 waves: apply ne[t & 1] to tile t+1 only, two columns each;  barrier
+    // Tile u thus receives the errors of tiles 0, 1, .., u-2 (deferred, iterations 1..u-1) and then of tile u-1 (the
+    // split step of iteration u-1), in this order, each as the same (mul, add) pairs in the same k order as the
+    // reference's successive addr_ calls (gptq.py:267): results are unchanged, the update time leaves the critical
+    // path (41 -> see DESIGN.md K5).
     extern __shared__ __attribute__((aligned(16))) float seg_smem[];
     float* wl = seg_smem;                   // wl[j*64 + lane]: working copy, column-major (32 KiB)
     float* Us = seg_smem + SEG * 64;        // Us[i*SEG + j] = U[a+i, a+j]: diagonal block (64 KiB), read back
                                             // with wave-uniform (broadcast) 16-byte LDS loads
-    float* ne = Us + SEG * SEG;             // ne[k*64 + lane]: -err of the current sub-block (4 KiB)
+    float* ne = Us + SEG * SEG;             // ne[(t & 1)*SB*64 + k*64 + lane]: -err of tile t, double-buffered (8 KiB)
+    double* rdiag = reinterpret_cast<double*>(ne + 2 * SB * 64);  // rdiag[i] = 1 / U[a+i, a+i] in fp64 (1 KiB)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    for (int idx = tid; idx < len * (SEG / 4); idx += SEG_WAVES * 64) {
-        const int i = idx / (SEG / 4), j4 = (idx % (SEG / 4)) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (j4 < len) v = *reinterpret_cast<const float4*>(U + (a + i) * C + a + j4);
-        *reinterpret_cast<float4*>(Us + i * SEG + j4) = v;
-    }
     const int64_t row = (int64_t)blockIdx.x * 64 + lane;
     const bool live = row < R;
     const int64_t r = live ? row : 0;
-
-    // gptq.py:225 w_blk = w[:, c1:c2].clone()  (each wave brings in a quarter of the columns)
-    {
+    // Two-step prologue: everything the FIRST tile's chain needs (U rows 0..15, the tile's 16 columns of W, its
+    // reciprocal diagonal) is brought in by all waves, then the chain starts while waves 1..7 -- idle in
+    // iteration 0 -- bring in the other 7/8 (gptq.py:225 w_blk = w[:, c1:c2].clone()).
+    auto load_u_rows = [&](int i_lo, int i_hi, int t0, int nthr) {
+        for (int idx = t0; idx < (i_hi - i_lo) * (SEG / 4); idx += nthr) {
+            const int i = i_lo + idx / (SEG / 4), j4 = (idx % (SEG / 4)) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j4 < len) v = *reinterpret_cast<const float4*>(U + (a + i) * C + a + j4);
+            *reinterpret_cast<float4*>(Us + i * SEG + j4) = v;
+        }
+    };
+    auto load_w_cols = [&](int j_lo, int j_hi, int w0, int nw) {
         const float* sp = src + r * ld_src;
-        for (int j = wid * 4; j < len; j += 4 * SEG_WAVES) {
+        for (int j = j_lo + w0 * 4; j < j_hi; j += 4 * nw) {
             float4 v = *reinterpret_cast<const float4*>(sp + j);
             wl[(j + 0) * 64 + lane] = v.x;
             wl[(j + 1) * 64 + lane] = v.y;
             wl[(j + 2) * 64 + lane] = v.z;
             wl[(j + 3) * 64 + lane] = v.w;
         }
-    }
+    };
+    const int first = len < SB ? len : SB;
+    if (tid < first) rdiag[tid] = 1.0 / (double)U[(a + tid) * C + a + tid];
+    load_u_rows(0, first, tid, SEG_WAVES * 64);
+    load_w_cols(0, first, wid, SEG_WAVES);
     const int64_t nsg = C / 256, ng = C / G;
+    // group parameters of every tile of the segment, fetched before the chain starts (they do not depend on it): a
+    // tile lies inside one group (16 | G), ds = f32(d) * s, dm = f32(dmin) * m, and 1 / max(ds, 1e-9) in fp64
+    constexpr int NT = SEG / SB;
+    float dst[PERM ? 1 : NT], dmt[PERM ? 1 : NT];
+    double rdt[PERM ? 1 : NT];
+    if constexpr (!PERM) {
+        if (wid == 0) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int64_t col0 = a + t * SB < a + len ? a + t * SB : a;
+                dst[t] = h2f(d[r * nsg + col0 / 256]) * ival(s[r * ng + col0 / G], is_signed);
+                dmt[t] = h2f(dmin[r * nsg + col0 / 256]) * ival(m[r * ng + col0 / G], is_signed);
+                rdt[t] = 1.0 / (double)(dst[t] < 1e-9f ? 1e-9f : dst[t]);  // quant_utils.py:37 clamp_min(eps)
+            }
+        }
+    }
     __syncthreads();
+    if (wid != 0) {  // under the first chain
+        const int ht = tid - 64;
+        if (ht >= first && ht < len) rdiag[ht] = 1.0 / (double)U[(a + ht) * C + a + ht];
+        load_u_rows(first, len, ht, (SEG_WAVES - 1) * 64);
+        load_w_cols(first, len, wid - 1, SEG_WAVES - 1);
+    }
 
-    for (int i0 = 0; i0 < len; i0 += SB) {
+    const int ntile = len / SB;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (t >= ntile) break;
+        const int i0 = t * SB;
+        float* net = ne + (t & 1) * (SB * 64);
+#ifndef GQ_SEG_NOCHAIN  // (timing probes only: profiles/seg_ab.sh)
         if (wid == 0) {
             const int64_t col0 = a + i0;
-            // group parameters are constant over a 16-aligned run of 16 columns
             float ds = 0.f, dm = 0.f, dsv[PERM ? SB : 1], dmv[PERM ? SB : 1];
+            double rden = 0.0, rdenv[PERM ? SB : 1];
             if constexpr (PERM) {
 #pragma unroll
                 for (int k = 0; k < SB; ++k) {
                     const int64_t pc = perm[col0 + k];
                     dsv[k] = h2f(d[r * nsg + pc / 256]) * ival(s[r * ng + pc / G], is_signed);
                     dmv[k] = h2f(dmin[r * nsg + pc / 256]) * ival(m[r * ng + pc / G], is_signed);
+                    rdenv[k] = 1.0 / (double)(dsv[k] < 1e-9f ? 1e-9f : dsv[k]);
                 }
             } else {
-                ds = h2f(d[r * nsg + col0 / 256]) * ival(s[r * ng + col0 / G], is_signed);
-                dm = h2f(dmin[r * nsg + col0 / 256]) * ival(m[r * ng + col0 / G], is_signed);
+                ds = dst[t];
+                dm = dmt[t];
+                rden = rdt[t];
             }
             float wr[SB], nerr[SB], wq[SB];
             uint32_t qpack[4] = {0, 0, 0, 0};
@@ -95,20 +149,22 @@ __global__ __launch_bounds__(SEG_WAVES * 64) void gptq_segment_kernel(
 #pragma unroll
             for (int k = 0; k < SB; ++k) {
                 const float* urow = Us + (i0 + k) * SEG + i0;  // wave-uniform LDS address (broadcast)
-                const float dii = urow[k];
-                if constexpr (PERM) { ds = dsv[k]; dm = dmv[k]; }
-                const float q = quantize1(wr[k], ds, dm, qmin, qmax);  // gptq.py:247-254
-                wq[k] = dequantize1(q, ds, dm);                        // :255-261
-                const float err = (wr[k] - wq[k]) / dii;               // :264
+                if constexpr (PERM) { ds = dsv[k]; dm = dmv[k]; rden = rdenv[k]; }
+                const float q = clampf(rintf(div_rcp64(wr[k] + dm, rden)), qmin, qmax);  // gptq.py:247-254
+                wq[k] = dequantize1(q, ds, dm);                                            // :255-261
+                const float err = div_rcp64(wr[k] - wq[k], rdiag[i0 + k]);                 // :264
                 const uint8_t qb = is_signed ? (uint8_t)(int8_t)q : (uint8_t)q;
                 qpack[k >> 2] |= (uint32_t)qb << (8 * (k & 3));
                 // :267 addr_(err, U[i, i:], alpha=-1): self + (alpha*err)*u, two roundings
                 const float nk = -err;
                 nerr[k] = nk;
-                ne[k * 64 + lane] = nk;
 #pragma unroll
                 for (int kk = k; kk < SB; ++kk) wr[kk] = wr[kk] + nk * urow[kk];
             }
+            // published after the chain: an LDS store inside it would order every later LDS read of U behind it
+            // (the compiler cannot tell that `ne` and `Us` never overlap)
+#pragma unroll
+            for (int k = 0; k < SB; ++k) net[k * 64 + lane] = nerr[k];
             if (live) {
                 *reinterpret_cast<uint4*>(qweight + row * C + col0) =
                     make_uint4(qpack[0], qpack[1], qpack[2], qpack[3]);
@@ -122,28 +178,51 @@ __global__ __launch_bounds__(SEG_WAVES * 64) void gptq_segment_kernel(
                 }
             }
         }
-        __syncthreads();
-        // rank-1 updates of the later columns of this segment, 16 columns per tile, tiles dealt round-robin
-        // to the four waves; each element sees the same sequence of (mul, add) pairs, in the same order of
-        // i, as the reference's 16 successive addr_ calls.
+#endif
+#ifndef GQ_SEG_NOUPDATE
+        // deferred: the errors of tile t-1 go into the tiles t+1.., 16 columns per helper wave and turn; each element
+        // sees the same sequence of (mul, add) pairs, in the same order of i, as 16 successive addr_ calls
         // (packed v_pk_mul_f32 / v_pk_add_f32 were measured 35 % SLOWER here)
-        int t = 0;
-        for (int j0 = i0 + SB; j0 < len; j0 += SB, ++t) {
-            if ((t % SEG_WAVES) != wid) continue;
-            float wt[SB], nk[SB];
+        if (wid != 0 && t > 0) {
+            const float* nep = ne + ((t - 1) & 1) * (SB * 64);
+            int turn = 0;
+            for (int j0 = i0 + SB; j0 < len; j0 += SB, ++turn) {
+                if ((turn % (SEG_WAVES - 1)) + 1 != wid) continue;
+                float wt[SB], nk[SB];
 #pragma unroll
-            for (int jj = 0; jj < SB; ++jj) wt[jj] = wl[(j0 + jj) * 64 + lane];
+                for (int jj = 0; jj < SB; ++jj) wt[jj] = wl[(j0 + jj) * 64 + lane];
 #pragma unroll
-            for (int k = 0; k < SB; ++k) nk[k] = ne[k * 64 + lane];
+                for (int k = 0; k < SB; ++k) nk[k] = nep[k * 64 + lane];
+#pragma unroll
+                for (int k = 0; k < SB; ++k) {
+                    const float* urow = Us + (i0 - SB + k) * SEG + j0;
+#pragma unroll
+                    for (int jj = 0; jj < SB; ++jj) wt[jj] = wt[jj] + nk[k] * urow[jj];
+                }
+#pragma unroll
+                for (int jj = 0; jj < SB; ++jj) wl[(j0 + jj) * 64 + lane] = wt[jj];
+            }
+        }
+#endif
+        __syncthreads();
+#ifndef GQ_SEG_NOUPDATE
+        // the next tile needs this tile's errors NOW: all eight waves, two of its columns each
+        if (i0 + SB < len) {
+            constexpr int CPW = SB / SEG_WAVES;
+            const int j0 = i0 + SB + wid * CPW;
+            float wt[CPW];
+#pragma unroll
+            for (int jj = 0; jj < CPW; ++jj) wt[jj] = wl[(j0 + jj) * 64 + lane];
 #pragma unroll
             for (int k = 0; k < SB; ++k) {
-                const float* urow = Us + (i0 + k) * SEG + j0;
+                const float nk = net[k * 64 + lane];
 #pragma unroll
-                for (int jj = 0; jj < SB; ++jj) wt[jj] = wt[jj] + nk[k] * urow[jj];
+                for (int jj = 0; jj < CPW; ++jj) wt[jj] = wt[jj] + nk * Us[(i0 + k) * SEG + j0 + jj];
             }
 #pragma unroll
-            for (int jj = 0; jj < SB; ++jj) wl[(j0 + jj) * 64 + lane] = wt[jj];
+            for (int jj = 0; jj < CPW; ++jj) wl[(j0 + jj) * 64 + lane] = wt[jj];
         }
+#endif
         __syncthreads();
     }
 }
