@@ -627,6 +627,9 @@ size_t h_prepare_workspace_bytes(int64_t R, int64_t C) {
 //                  X21 = -X22 (L21 X11)                              (two GEMMs, triangular k-range skips)
 // L21 lives in Tmp (the factor itself is not an output: only X = L^-1 is), the product L21 X11
 // reuses the dead A21 block.  Leaves are 128x128 (diag_potrf_inv_kernel, writes X_kk directly).
+// (Measured and dropped, r02: L21 X11 of the large nodes on helper streams -- one per recursion depth -- under the
+// recursion into A22, which it does not depend on: h_prepare(14336) alone 24.3 -> 23.5 ms, but inside a block's
+// four-chain schedule the three extra hardware queues cost far more than that: 102 -> 113 ms per step.)
 static int chol_inv_rec(float* A, float* X, float* Tmp, int* flag, int64_t n, int64_t lo, int64_t hi, size_t diag_lds,
                         hipStream_t st) {
     if (hi - lo == 1) {
