@@ -287,10 +287,19 @@ class BlockSchedule:
         lanes = []
         trace = os.environ.get("GQ_SCHED_TRACE")
         t_host = time.perf_counter()
+        # lanes: longest-processing-time-first over all lanes; the costliest chain comes first and lands on lane 0 = the
+        # caller's stream (a dense block: one chain per lane; a Mixtral block: 20 chains over 4 lanes)
+        cost = [sum(float(handles[n].d_row) * handles[n].d_col ** 2 + float(handles[n].d_col) ** 3 / 3 for n in names)
+                for names in order]
+        lane_of, load = [0] * len(order), [0.0] * max(len(streams), 1)
+        for k in range(len(order)):
+            lane_of[k] = min(range(len(streams)), key=lambda i: (load[i], i)) if streams else 0
+            load[lane_of[k]] += cost[k]
         for k, names in enumerate(order):
             if trace:
-                print(f"  [sched] +{1e3 * (time.perf_counter() - t_host):7.2f} ms: enqueue chain {k} {names}", file=sys.stderr)
-            lane = _Lane(streams[k % len(streams)] if streams else None, main)
+                print(f"  [sched] +{1e3 * (time.perf_counter() - t_host):7.2f} ms: enqueue chain {k} {names} on lane {lane_of[k]}",
+                      file=sys.stderr)
+            lane = _Lane(streams[lane_of[k]] if streams else None, main)
             lead = handles[names[0]].shared_H_with or handles[names[0]]
             lane.wait(ready.get(id(lead), start))
             born = []
