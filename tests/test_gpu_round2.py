@@ -198,7 +198,6 @@ def test_end_to_end_rates_vs_fp64_chain(ops, oracle):
     Wo = npy(W0)
     u_err = float(np.abs(npy(U).astype(np.float64) - Uo).max() / np.abs(Uo).max())
     rows = slice(0, 1024)  # the oracle walks 1024 of the 4096 independent rows
-    Uo[np.abs(Uo) < 1e-25] = 0.0  # their products are fp32 denormals (host column loop 20x slower) and cannot change a weight
     U32 = Uo.astype(np.float32)
     Wd, oq, od, os_, odm, om = oracle.gptq_step(Wo[rows], U32, 12, block_size=128)
 
