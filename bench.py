@@ -168,8 +168,7 @@ def block_step(wl, layers, W16, X, keep=None):
     def extra(name, h, res):
         packed = ops.pack(int(qtypes[name]), *res)
         if keep is not None:
-            lead = h.shared_H_with or h
-            keep[name] = (res, packed, lead._U_cache[0] if lead._U_cache is not None else None)
+            keep[name] = (res, packed, h._last_U)
         return packed
 
     t_fed = time.perf_counter()
@@ -310,12 +309,12 @@ def tolerance_parity(wl, W16, X, n_seq=8):
 
 
 def cpu_baseline(wl, W16, keep):
-    """Oracle (C restatement of the reference, OpenMP) on the host cores: GPTQ.step of the Linears fed by the
-    attention input (q/k/v: 25.2 M params at 8B sizes, one shared U -- the U the GPU used).  ~10-30 s of CPU."""
+    """Oracle (C restatement of the reference, OpenMP) on the host cores: GPTQ.step of the attention Linears
+    (q/k/v/o: 41.9 M params at 8B sizes, with the U the GPU used for each).  ~5-15 s of CPU."""
     try:
         from oracle import oracle as O
         shapes = wl["shapes"]
-        names = [n for n in ("q_proj", "k_proj", "v_proj") if n in shapes and n in keep and keep[n][2] is not None]
+        names = [n for n in ("q_proj", "k_proj", "v_proj", "o_proj") if n in shapes and n in keep and keep[n][2] is not None]
         if shapes["q_proj"][1] > 4096:
             names = [n for n in names if n != "q_proj"]
         threads = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
@@ -333,7 +332,7 @@ def cpu_baseline(wl, W16, keep):
         return {"value": round(tot / dt / 1e6, 3), "unit": "Mparams/s", "cores": threads, "kind": "port",
                 "sample": f"GPTQ.step only (scale search + column loop + trailing update, given the GPU's U; the "
                           f"Hessian accumulation, the Cholesky chain, dequantize and pack of the GPU step are NOT in "
-                          f"this figure) of the {len(names)} Linears fed by the attention input ({'/'.join(names)}, "
+                          f"this figure) of the {len(names)} attention Linears ({'/'.join(names)}, "
                           f"{tot / 1e6:.1f} M params), {dt:.1f} s; ints equal to the GPU's: {same / cnt:.6f}"}
     except Exception as e:  # the bench line must still print
         return {"value": None, "unit": "Mparams/s", "cores": 0, "kind": "port", "sample": f"failed: {e!r}"}

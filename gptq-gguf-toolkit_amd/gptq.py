@@ -66,6 +66,7 @@ class GPTQ:
         self._zero_copy = os.environ.get("GQ_STAGE_COPY") != "1"
         self._buf_b = 0
         self._U_cache = None
+        self._last_U = None
 
     # ------------------------------------------------------------------ Hessian
     @torch.no_grad()
@@ -170,6 +171,7 @@ class GPTQ:
         self.shared_H_with = None
         self._has_followers = False
         self._U_cache = None
+        self._last_U = None
         self._pending_mismatch = None
         self._flag = None
         self.no_samples = False
@@ -259,6 +261,7 @@ class GPTQ:
         if self.act_order:
             return self._compute_act_order(q_type)
         U = self._prepare(defer_check, own_U)
+        self._last_U = U  # for inspection (bench.py's cpu_baseline runs the oracle on the same U); dropped by reset()
         W = self.W
         if self._row_split_active():
             # every rank factorises (same reduced H => the same U, bit for bit) and walks its own rows
