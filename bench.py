@@ -309,14 +309,17 @@ def tolerance_parity(wl, W16, X, n_seq=8):
 
 
 def cpu_baseline(wl, W16, keep):
-    """Oracle (C restatement of the reference, OpenMP) on the host cores: GPTQ.step of the attention Linears
-    (q/k/v/o: 41.9 M params at 8B sizes, with the U the GPU used for each).  ~5-15 s of CPU."""
+    """Oracle (C restatement of the reference, OpenMP) on the host cores: GPTQ.step of every Linear of the block (218 M
+    params at 8B sizes) with the U the GPU used for each.  ~10 s of CPU on 8 cores."""
     try:
         from oracle import oracle as O
         shapes = wl["shapes"]
-        names = [n for n in ("q_proj", "k_proj", "v_proj", "o_proj") if n in shapes and n in keep and keep[n][2] is not None]
-        if shapes["q_proj"][1] > 4096:
-            names = [n for n in names if n != "q_proj"]
+        names, budget = [], 2.0e12  # bounded: sum of R C^2 (one Llama-3-8B block: 1.6e12, ~10 s on 8 cores)
+        for n in shapes:
+            cost = float(shapes[n][0]) * shapes[n][1] ** 2
+            if n in keep and keep[n][2] is not None and cost <= budget:
+                names.append(n)
+                budget -= cost
         threads = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
         tot, same, cnt, dt = 0, 0.0, 0, 0.0
         for n in names:
@@ -332,7 +335,7 @@ def cpu_baseline(wl, W16, keep):
         return {"value": round(tot / dt / 1e6, 3), "unit": "Mparams/s", "cores": threads, "kind": "port",
                 "sample": f"GPTQ.step only (scale search + column loop + trailing update, given the GPU's U; the "
                           f"Hessian accumulation, the Cholesky chain, dequantize and pack of the GPU step are NOT in "
-                          f"this figure) of the {len(names)} attention Linears ({'/'.join(names)}, "
+                          f"this figure) of {len(names)} of the block's {len(shapes)} Linears ({'/'.join(names)}, "
                           f"{tot / 1e6:.1f} M params), {dt:.1f} s; ints equal to the GPU's: {same / cnt:.6f}"}
     except Exception as e:  # the bench line must still print
         return {"value": None, "unit": "Mparams/s", "cores": 0, "kind": "port", "sample": f"failed: {e!r}"}
