@@ -392,7 +392,10 @@ int gptq_quantize(float* W, const float* U, int64_t R, int64_t C, int q_type, in
         if (c2 < S1) {  // rest of the super-block, this block's errors only
             // (measured and dropped: applying the blocks in pairs -- an even block updates its partner only, the odd
             // block the rest with both in one chained K = 256 launch -- gives 4 tiny + 3 deeper launches instead of 7
-            // thin ones, bit-identical, but no faster: 1.79 vs 1.71 ms for 4096 x 14336; every launch is latency)
+            // thin ones, bit-identical, but no faster: 1.79 vs 1.71 ms for 4096 x 14336; every launch is latency.
+            // Also dropped: a dedicated K = 128 kernel, one workgroup per CU with the whole K of both operands in LDS
+            // (23.5 vs 17.3 us per launch).  A rank-128 update moves 16 B of operands L2 -> LDS per output element for
+            // 256 flops at 64 x 64 tiles: it is L2-bandwidth-bound near 50 TFLOP/s whatever the schedule.)
             if ((rc = launch_trailing_update(W + c2, C, Err + pos * B, ldE, U + c1 * C + c2, C, R, S1 - c2, ncols, st)))
                 return rc;
             continue;
