@@ -13,6 +13,7 @@
 //           LDS and also inverts it; panel  A21 <- A21 * L11^-T  and the trailing
 //           symmetric update  A22 -= L21 L21^T  run on the fp32 matrix cores.
 //   trtri : recursive halving, X21 = -X22 * (M21 * X11), two GEMMs per node.
+#include <atomic>
 #include <stdlib.h>
 
 #include "gq_common.hpp"
@@ -712,7 +713,7 @@ int h_prepare(float* H, float* W, int64_t R, int64_t C, float rel_damp, float* U
     GQ_LAUNCH_CHECK();
     GQ_HIP(hipMemsetAsync(X, 0, (size_t)n * n * sizeof(float), st));
     }
-    static bool attr_set = false;
+    static std::atomic<bool> attr_set{false};  // guards an idempotent call: a race sets the same value twice
     static const bool use_ref = getenv("GQ_DIAG_REF") != nullptr;  // A/B: the column-by-column kernel
     const size_t diag_lds = use_ref ? (2 * NB * LDP + NB) * sizeof(float) : DIAG_BLK_LDS;
     if (!attr_set) {

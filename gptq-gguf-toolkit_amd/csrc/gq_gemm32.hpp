@@ -23,6 +23,7 @@
 // the C tile and runs 8 waves (2x4, wave tile 64x32); the GPTQ far update on whole tiles has its own kernel,
 // gemm32_chain_full_kernel below.
 #pragma once
+#include <atomic>
 #include <stdlib.h>
 
 #include <type_traits>
@@ -416,7 +417,7 @@ template <int CHAIN>
 inline int launch_gemm32_chain_full(float* Cmat, int64_t ldc, const float* A, int64_t lda, const float* B, int64_t ldb,
                                     int64_t M, int64_t N, int64_t K, hipStream_t st) {
     constexpr int LDS = 3 * G32<128>::STAGE_FLOATS * 4;
-    static bool attr_set = false;
+    static std::atomic<bool> attr_set{false};  // guards an idempotent call: a race sets the same value twice
     if (!attr_set) {
         GQ_HIP(hipFuncSetAttribute((const void*)gemm32_chain_full_kernel<CHAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr_set = true;
@@ -431,7 +432,7 @@ template <bool TRANS_B, int MODE, bool LOWER, int KR, int CHAIN, int TS, bool FU
 inline int launch_gemm32_full(float* Cmat, int64_t ldc, const float* A, int64_t lda, const float* B, int64_t ldb, int64_t M,
                             int64_t N, int64_t K, hipStream_t st) {
     constexpr int NW = (CHAIN != 0 && TS == 128) ? 8 : 4;  // the chained kernel also holds the C tile: 8 waves
-    static bool attr_set = false;
+    static std::atomic<bool> attr_set{false};  // guards an idempotent call: a race sets the same value twice
     if (!attr_set) {
         GQ_HIP(hipFuncSetAttribute((const void*)gemm32_kernel<TRANS_B, MODE, LOWER, KR, CHAIN, TS, FULL, NW>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, G32<TS>::LDS_BYTES));

@@ -7,6 +7,7 @@
 // GEMM W[:, c2:] -= Err[R,B] @ U[c1:c2, c2:] on the fp32 matrix cores
 // (v_mfma_f32_32x32x2_f32 == a k-ordered fmaf chain, which is what the reference's
 // sgemm computes per element -- verified bit-for-bit in tests/golden G6).
+#include <atomic>
 #include "gq_common.hpp"
 #include "gq_gemm32.hpp"
 #include <stdlib.h>
@@ -325,7 +326,7 @@ int gptq_quantize(float* W, const float* U, int64_t R, int64_t C, int q_type, in
                 return rc;
     }
     const dim3 seg_grid((unsigned)((R + 63) / 64)), seg_block(SEG_WAVES * 64);
-    static bool seg_attr = false;
+    static std::atomic<bool> seg_attr{false};  // guards an idempotent call: a race sets the same value twice
     if (!seg_attr) {
         GQ_HIP(hipFuncSetAttribute((const void*)gptq_segment_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    SEG_LDS_BYTES));

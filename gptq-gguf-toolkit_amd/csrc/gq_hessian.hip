@@ -13,6 +13,7 @@
 // 16-bit path: X[T,C] is first re-laid out (transpose16_kernel) into per-(panel, stage) blocks
 // that ARE the LDS image of an operand stage, so both MFMA operands are 16-byte K-contiguous
 // fragments and the operand stream is perfectly sequential in HBM.
+#include <atomic>
 #include <stdlib.h>
 
 #include "gq_common.hpp"
@@ -1305,7 +1306,7 @@ int h_accumulate_grouped(int n, float* const* H, const void* const* X, const int
         }
     }
     if (!ws || ws_bytes < need) GQ_FAIL(GQ_E_WORKSPACE, "gq_h_accumulate: workspace %zu < %zu bytes", ws_bytes, need);
-    static bool attr_set = false;
+    static std::atomic<bool> attr_set{false};  // guards an idempotent call: a race sets the same value twice
     if (!attr_set) {
         GQ_HIP(hipFuncSetAttribute((const void*)syrk16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * H_STAGE_BYTES));
         GQ_HIP(hipFuncSetAttribute((const void*)syrk16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * H_STAGE_BYTES));
