@@ -261,7 +261,7 @@ class GPTQ:
         if self.act_order:
             return self._compute_act_order(q_type)
         U = self._prepare(defer_check, own_U)
-        self._last_U = U  # for inspection (bench.py's cpu_baseline runs the oracle on the same U); dropped by reset()
+        self._last_U = U  # for inspection (bench.py's cpu_baseline leg re-runs the column loop on the same U); dropped by reset()
         W = self.W
         if self._row_split_active():
             # every rank factorises (same reduced H => the same U, bit for bit) and walks its own rows
