@@ -26,7 +26,9 @@ int h_accumulate(float*, const void*, int, int64_t, int64_t, float, float, void*
 int h_accumulate_grouped(int, float* const*, const void* const*, const int64_t*, const int64_t*, const float*, const float*,
                          int, void*, size_t, hipStream_t, const void* const* const*, const int64_t*);
 size_t h_prepare_workspace_bytes(int64_t, int64_t);
-int h_prepare(float*, float*, int64_t, int64_t, float, float*, int*, uint8_t*, void*, size_t, hipStream_t);
+int h_prepare(float*, float*, int64_t, int64_t, float, float*, int*, uint8_t*, void*, size_t, hipStream_t, bool);
+int obq_quantize(float*, const float*, int64_t, int64_t, int, int, int, int, uint8_t*, float*, float*, void*, size_t,
+                 hipStream_t);
 int w_prepare(const uint8_t*, float*, int64_t, int64_t, int*, hipStream_t);
 int h_pack_upper(const float*, int64_t, float*, hipStream_t);
 int h_unpack_upper(const float*, int64_t, float*, hipStream_t);
@@ -121,7 +123,18 @@ int gq_h_accumulate_segments(int n, float* const* H_host, const void* const* con
 
 int gq_h_prepare(float* H, float* W, int64_t R, int64_t C, float rel_damp, float* U, int* not_invertible,
                  uint8_t* col_flags_out, void* ws, size_t ws_bytes, void* stream) {
-    return h_prepare(H, W, R, C, rel_damp, U, not_invertible, col_flags_out, ws, ws_bytes, (hipStream_t)stream);
+    return h_prepare(H, W, R, C, rel_damp, U, not_invertible, col_flags_out, ws, ws_bytes, (hipStream_t)stream, false);
+}
+
+int gq_obq_h_prepare(float* H, float* W, int64_t R, int64_t C, float rel_damp, float* U, int* not_invertible,
+                     uint8_t* col_flags_out, void* ws, size_t ws_bytes, void* stream) {
+    return h_prepare(H, W, R, C, rel_damp, U, not_invertible, col_flags_out, ws, ws_bytes, (hipStream_t)stream, true);
+}
+
+int gq_obq_quantize(float* W, const float* U, int64_t R, int64_t C, int bits, int group_size, int sym, int block_size,
+                    uint8_t* qweight, float* scale, float* zero, void* ws, size_t ws_bytes, void* stream) {
+    return obq_quantize(W, U, R, C, bits, group_size, sym, block_size, qweight, scale, zero, ws, ws_bytes,
+                        (hipStream_t)stream);
 }
 
 int gq_w_prepare(const uint8_t* col_flags, float* W, int64_t R, int64_t C, int* mismatch, void* stream) {

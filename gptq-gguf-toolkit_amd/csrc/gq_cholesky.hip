@@ -164,6 +164,12 @@ __global__ __launch_bounds__(256) void mask_h_kernel(float* __restrict__ H, int6
     }
 }
 
+// H[dead, dead] = 1 alone (evopress/src/fast_obq.py:134-135: the damping there comes BEFORE the zero-column mask)
+__global__ __launch_bounds__(256) void dead_diag_kernel(float* __restrict__ H, int64_t C, const uint8_t* __restrict__ dead) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < C && dead[j]) H[j * C + j] = 1.0f;
+}
+
 // damp = rel_damp * mean(diag H); H_ii += damp  (gptq.py:315-316).  One workgroup.
 __global__ __launch_bounds__(1024) void damp_kernel(float* __restrict__ H, int64_t C, float rel_damp) {
     __shared__ double part[1024];
@@ -681,8 +687,10 @@ int w_prepare(const uint8_t* flags, float* W, int64_t R, int64_t C, int* mismatc
     return GQ_OK;
 }
 
+// obq_order: EvoPress FastOBQ (evopress/src/fast_obq.py:133-141, 221-228) fixes the dead diagonal and damps FIRST,
+// then masks the zero columns of W with an undamped 1 on the diagonal; GPTQ (gptq.py:308-316) masks, then damps.
 int h_prepare(float* H, float* W, int64_t R, int64_t C, float rel_damp, float* U, int* not_invertible,
-              uint8_t* col_flags_out, void* ws, size_t ws_bytes, hipStream_t st) {
+              uint8_t* col_flags_out, void* ws, size_t ws_bytes, hipStream_t st, bool obq_order) {
     if (!H || !W || !U || !not_invertible) GQ_FAIL(GQ_E_NULL, "gq_h_prepare: null pointer");
     if (R <= 0 || C <= 0 || C % NB) GQ_FAIL(GQ_E_BAD_SHAPE, "gq_h_prepare: R=%ld C=%ld (C %% 128 != 0)", (long)R, (long)C);
     const size_t need = h_prepare_workspace_bytes(R, C);
@@ -705,9 +713,14 @@ int h_prepare(float* H, float* W, int64_t R, int64_t C, float rel_damp, float* U
     hipLaunchKernelGGL(zero_dead_cols_kernel, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, st, W, R, C, dead);
     GQ_LAUNCH_CHECK();
     if (col_flags_out) GQ_HIP(hipMemcpyAsync(col_flags_out, dead, 2 * (size_t)C, hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL(mask_h_kernel, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, st, H, C, zc);
-    GQ_LAUNCH_CHECK();
-    hipLaunchKernelGGL(damp_kernel, dim3(1), dim3(1024), 0, st, H, C, rel_damp);
+    if (obq_order) {
+        hipLaunchKernelGGL(dead_diag_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, H, C, dead);
+        hipLaunchKernelGGL(damp_kernel, dim3(1), dim3(1024), 0, st, H, C, rel_damp);
+        hipLaunchKernelGGL(mask_h_kernel, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, st, H, C, zc);
+    } else {
+        hipLaunchKernelGGL(mask_h_kernel, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, st, H, C, zc);
+        hipLaunchKernelGGL(damp_kernel, dim3(1), dim3(1024), 0, st, H, C, rel_damp);
+    }
     GQ_LAUNCH_CHECK();
     hipLaunchKernelGGL(reverse_copy_kernel, dim3(4096), dim3(256), 0, st, A, H, n);
     GQ_LAUNCH_CHECK();

@@ -41,14 +41,18 @@ constexpr int SEG_LDS_BYTES = (SEG * 64 + SEG * SEG + 2 * SB * 64) * 4 + SEG * 8
 // column loop performs two divisions per column and is bound by exactly that chain.
 __device__ __forceinline__ float div_rcp64(float n, double rd) { return (float)((double)n * rd); }
 
-template <bool PERM>
+// UNI: the uniform grid of EvoPress' FastOBQ (evopress/src/quant_utils.py:23-29) instead of a K-quant:
+//   q = clamp(round(w / max(scale, 1e-9) + zero), 0, maxq),  w_hat = scale * (q - zero)
+// with scale / zero fp32 [R, C / G] (uscale / uzero; d, s, dmin, m unused).
+template <bool PERM, bool UNI = false>
 __global__ __launch_bounds__(SEG_WAVES * 64) void gptq_segment_kernel(
     float* W, int64_t C, const float* src, int64_t ld_src,  // may alias (single-segment blocks)
     const float* __restrict__ U, int64_t a, int len, int64_t R,
     const uint16_t* __restrict__ d, const uint8_t* __restrict__ s, const uint16_t* __restrict__ dmin,
     const uint8_t* __restrict__ m, int G, int is_signed, float qmin, float qmax,
     uint8_t* __restrict__ qweight, float* __restrict__ Err, int64_t ld_err, int64_t err_col0,
-    const int32_t* __restrict__ perm) {  // PERM (act_order, gptq.py:211-216): column j takes the parameters of
+    const int32_t* __restrict__ perm, const float* __restrict__ uscale = nullptr,
+    const float* __restrict__ uzero = nullptr) {  // PERM (act_order, gptq.py:211-216): column j takes the parameters of
                                          // the group of its ORIGINAL column perm[j]
     // One workgroup = 64 rows (lane = row) x SEG_WAVES waves.  Wave 0 walks the columns (the dependent chain) one
     // 16-column sub-block ("tile") at a time; the rank-1 updates of the later tiles run UNDER the next chain:
@@ -105,8 +109,13 @@ __global__ __launch_bounds__(SEG_WAVES * 64) void gptq_segment_kernel(
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int64_t col0 = a + t * SB < a + len ? a + t * SB : a;
-                dst[t] = h2f(d[r * nsg + col0 / 256]) * ival(s[r * ng + col0 / G], is_signed);
-                dmt[t] = h2f(dmin[r * nsg + col0 / 256]) * ival(m[r * ng + col0 / G], is_signed);
+                if constexpr (UNI) {
+                    dst[t] = uscale[r * ng + col0 / G];
+                    dmt[t] = uzero[r * ng + col0 / G];
+                } else {
+                    dst[t] = h2f(d[r * nsg + col0 / 256]) * ival(s[r * ng + col0 / G], is_signed);
+                    dmt[t] = h2f(dmin[r * nsg + col0 / 256]) * ival(m[r * ng + col0 / G], is_signed);
+                }
                 rdt[t] = 1.0 / (double)(dst[t] < 1e-9f ? 1e-9f : dst[t]);  // quant_utils.py:37 clamp_min(eps)
             }
         }
@@ -151,8 +160,14 @@ __global__ __launch_bounds__(SEG_WAVES * 64) void gptq_segment_kernel(
             for (int k = 0; k < SB; ++k) {
                 const float* urow = Us + (i0 + k) * SEG + i0;  // wave-uniform LDS address (broadcast)
                 if constexpr (PERM) { ds = dsv[k]; dm = dmv[k]; rden = rdenv[k]; }
-                const float q = clampf(rintf(div_rcp64(wr[k] + dm, rden)), qmin, qmax);  // gptq.py:247-254
-                wq[k] = dequantize1(q, ds, dm);                                            // :255-261
+                float q;
+                if constexpr (UNI) {
+                    q = clampf(rintf(div_rcp64(wr[k], rden) + dm), qmin, qmax);  // fast_obq.py:173, quant_utils.py:23-25
+                    wq[k] = ds * (q - dm);                                       // :174, quant_utils.py:28-29
+                } else {
+                    q = clampf(rintf(div_rcp64(wr[k] + dm, rden)), qmin, qmax);  // gptq.py:247-254
+                    wq[k] = dequantize1(q, ds, dm);                              // :255-261
+                }
                 const float err = div_rcp64(wr[k] - wq[k], rdiag[i0 + k]);                 // :264
                 const uint8_t qb = is_signed ? (uint8_t)(int8_t)q : (uint8_t)q;
                 qpack[k >> 2] |= (uint32_t)qb << (8 * (k & 3));
@@ -228,6 +243,41 @@ __global__ __launch_bounds__(SEG_WAVES * 64) void gptq_segment_kernel(
     }
 }
 
+// evopress/src/quant_utils.py:57-106 Quantizer.find_params(x, weight=True), perchannel: one wave per row of the
+// [R, G] panel at x (row stride ld): min / max over the group, the symmetric range, (-1, +1) for a constant row,
+// scale = (max - min) / maxq, zero = round(-min / scale) or (maxq + 1) / 2.  G % 4 == 0, x 16-byte aligned.
+__global__ __launch_bounds__(256) void uniform_params_kernel(const float* __restrict__ x, int64_t R, int64_t ld, int G,
+                                                             float maxq, int sym, float* __restrict__ scale,
+                                                             float* __restrict__ zero, int64_t ng) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    const float* xr = x + row * ld;
+    float mn = xr[0], mx = mn;
+    for (int j = lane * 4; j < G; j += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(xr + j);
+        mn = fminf(fminf(mn, v.x), fminf(v.y, fminf(v.z, v.w)));
+        mx = fmaxf(fmaxf(mx, v.x), fmaxf(v.y, fmaxf(v.z, v.w)));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mn = fminf(mn, __shfl_xor(mn, o));
+        mx = fmaxf(mx, __shfl_xor(mx, o));
+    }
+    if (lane) return;
+    if (sym) {
+        mx = fmaxf(fabsf(mn), mx);
+        if (mn < 0.0f) mn = -mx;
+    }
+    if (mn == mx) {
+        mn = -1.0f;
+        mx = 1.0f;
+    }
+    const float sc = (mx - mn) / maxq;
+    scale[row * ng] = sc;
+    zero[row * ng] = sym ? (maxq + 1.0f) / 2.0f : rintf(-mn / sc);
+}
+
 // Block scratch maintenance for block_size > 128 (generic path, VALU):
 //   Wblk[r, j] = Wblk[r, j] + (-Err[r, e0+i]) * U[a+i, cj0+j]   for i = 0..n_i-1, in order.
 __global__ __launch_bounds__(256) void block_far_update_kernel(float* __restrict__ Wblk, int64_t ld_blk,
@@ -282,11 +332,30 @@ size_t gptq_workspace_bytes(int64_t R, int64_t C, int block_size) {
 // perm != nullptr: act_order (gptq.py:208-216, 233-235, 272-276).  W and U are already in permuted
 // order, d/s/dmin/m are INPUTS (the static scales of the original column groups, gptq.py:184-196) and
 // qweight comes back in permuted positions; the caller un-permutes it.
-int gptq_quantize(float* W, const float* U, int64_t R, int64_t C, int q_type, int block_size, int static_groups,
-                  const gq_search_t* p, uint8_t* qweight, uint16_t* d, uint8_t* s, uint16_t* dmin, uint8_t* m,
-                  void* ws, size_t ws_bytes, hipStream_t st, const int32_t* perm) {
+//
+// uni != nullptr: the uniform grids of EvoPress' FastOBQ (evopress/src/fast_obq.py:146-200) instead of a K-quant --
+// the same column loop and trailing updates; the grid of a group is found from W as it is when the block holding
+// the group's first column starts (fast_obq.py:168-171 reads w, which the in-block feedback never touches).
+struct UniformSpec {
+    int bits, group, sym;  // group == 0: one grid per row, from the original W (fast_obq.py:153-154)
+    float *scale, *zero;   // [R, C / group]
+};
+
+static int column_loop(float* W, const float* U, int64_t R, int64_t C, int q_type, int block_size, int static_groups,
+                       const gq_search_t* p, uint8_t* qweight, uint16_t* d, uint8_t* s, uint16_t* dmin, uint8_t* m,
+                       void* ws, size_t ws_bytes, hipStream_t st, const int32_t* perm, const UniformSpec* uni) {
     TypeInfo ti;
-    if (!type_info(q_type, ti)) GQ_FAIL(GQ_E_BAD_TYPE, "gq_gptq_quantize: unknown q_type %d", q_type);
+    if (uni) {
+        ti = TypeInfo{};
+        ti.group = uni->group > 0 ? uni->group : (int)C;
+        ti.is_signed = 0;
+        ti.qmin = 0;
+        ti.qmax = (1 << uni->bits) - 1;
+        ti.k_search = false;
+        static_groups = 2;  // no K-quant scale search
+        d = dmin = reinterpret_cast<uint16_t*>(qweight);  // unused by the UNI kernel; keeps the null check below simple
+        s = m = qweight;
+    } else if (!type_info(q_type, ti)) GQ_FAIL(GQ_E_BAD_TYPE, "gq_gptq_quantize: unknown q_type %d", q_type);
     if (R <= 0 || C <= 0 || C % 256) GQ_FAIL(GQ_E_BAD_SHAPE, "gq_gptq_quantize: R=%ld C=%ld (C %% 256 != 0)", (long)R, (long)C);
     if (!W || !U || !qweight || !d || !s || !dmin || !m) GQ_FAIL(GQ_E_NULL, "gq_gptq_quantize: null pointer");
     const int64_t B = block_size <= 0 || block_size > C ? C : block_size;  // gptq.py:54
@@ -304,10 +373,13 @@ int gptq_quantize(float* W, const float* U, int64_t R, int64_t C, int q_type, in
     // (Deferring the far part to a helper stream, to overlap it with the next super-block's column loop,
     // measured no gain alone and -8 % inside a block's multi-stream schedule: its long K = 1024 tiles keep
     // the column-loop workgroups, which need a whole CU's LDS, waiting.)
-    const bool lookahead = (B == LA_B) && getenv("GQ_NO_LOOKAHEAD") == nullptr;
     int la = LA;
     // tuning knob; even only: a 256-column scale-search group must not straddle two super-blocks
     if (const char* e = getenv("GQ_LA")) la = (atoi(e) >= 2 && atoi(e) <= LA && atoi(e) % 2 == 0) ? atoi(e) : LA;
+    // a uniform group must lie inside one super-block as well: its grid is found from columns that every earlier
+    // block has already updated
+    const bool lookahead = (B == LA_B) && getenv("GQ_NO_LOOKAHEAD") == nullptr &&
+                           (!uni || uni->group <= 0 || (la * B) % uni->group == 0);
     const int64_t ldE = lookahead ? (int64_t)LA * B : B;
     float* Err = reinterpret_cast<float*>(((uintptr_t)ws + 255) & ~(uintptr_t)255);
     float* Wblk = Err + (size_t)R * B * (lookahead ? LA : 1);
@@ -316,8 +388,16 @@ int gptq_quantize(float* W, const float* U, int64_t R, int64_t C, int q_type, in
         (reinterpret_cast<uintptr_t>(Wblk + ((B > SEG) ? (size_t)R * B : 0)) + 255) & ~(uintptr_t)255);
     if (ti.k_search && static_groups != 2) GQ_HIP(hipMemsetAsync(panel, 0, 8, st));
     const int64_t ng = C / ti.group, nsg = C / 256;
-    const int gps = 256 / ti.group;
+    const int gps = uni ? 1 : 256 / ti.group;
     int rc;
+    auto uniform_params = [&](int64_t col, int G, int64_t g) {
+        hipLaunchKernelGGL(uniform_params_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, W + col, R, C, G,
+                           (float)ti.qmax, uni->sym, uni->scale + g, uni->zero + g, ng);
+    };
+    if (uni && uni->group <= 0) {
+        uniform_params(0, (int)C, 0);
+        GQ_LAUNCH_CHECK();
+    }
 
     if (static_groups == 1) {  // gptq.py:184-196: all scales from the ORIGINAL W
         for (int64_t c = 0; c < C; c += 256)
@@ -332,6 +412,8 @@ int gptq_quantize(float* W, const float* U, int64_t R, int64_t C, int q_type, in
                                    SEG_LDS_BYTES));
         GQ_HIP(hipFuncSetAttribute((const void*)gptq_segment_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    SEG_LDS_BYTES));
+        GQ_HIP(hipFuncSetAttribute((const void*)gptq_segment_kernel<false, true>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, SEG_LDS_BYTES));
         seg_attr = true;
     }
     for (int64_t c1 = 0; c1 < C; c1 += B) {  // gptq.py:222
@@ -340,6 +422,11 @@ int gptq_quantize(float* W, const float* U, int64_t R, int64_t C, int q_type, in
         const bool single = (c2 - c1) <= SEG && (c1 / 256 == (c2 - 1) / 256);
         const int64_t ncols = c2 - c1;
         const int64_t bi = c1 / B, sb = bi / la, pos = lookahead ? bi % la : 0;  // block, super-block, slot
+        if (uni && uni->group > 0) {  // fast_obq.py:168-171 for every group that starts inside this block
+            ProfScope ps(PT_SCALE_SEARCH, st);
+            for (int64_t g = (c1 + uni->group - 1) / uni->group; g * uni->group < c2; ++g) uniform_params(g * uni->group, uni->group, g);
+            GQ_LAUNCH_CHECK();
+        }
         if (!single) {  // w_blk lives in scratch
             ProfScope ps(PT_BLOCK_FAR, st);
             hipLaunchKernelGGL(copy2d_kernel, dim3(2048), dim3(256), 0, st, Wblk, B, W + c1, C, R, ncols);
@@ -365,14 +452,18 @@ int gptq_quantize(float* W, const float* U, int64_t R, int64_t C, int q_type, in
             const int64_t ld_src = single ? C : B;
             {
                 ProfScope ps(PT_GPTQ_SEGMENT, st);
-                if (perm)
+                if (uni)
+                    hipLaunchKernelGGL((gptq_segment_kernel<false, true>), seg_grid, seg_block, SEG_LDS_BYTES, st, W, C, srcp,
+                                       ld_src, U, a, len, R, d, s, dmin, m, ti.group, 0, 0.0f, (float)ti.qmax, qweight, Err,
+                                       ldE, pos * B + (a - c1), perm, uni->scale, uni->zero);
+                else if (perm)
                     hipLaunchKernelGGL(gptq_segment_kernel<true>, seg_grid, seg_block, SEG_LDS_BYTES, st, W, C, srcp, ld_src, U, a,
                                        len, R, d, s, dmin, m, ti.group, ti.is_signed, (float)ti.qmin, (float)ti.qmax, qweight, Err,
-                                       ldE, pos * B + (a - c1), perm);
+                                       ldE, pos * B + (a - c1), perm, nullptr, nullptr);
                 else
                     hipLaunchKernelGGL(gptq_segment_kernel<false>, seg_grid, seg_block, SEG_LDS_BYTES, st, W, C, srcp, ld_src, U, a,
                                        len, R, d, s, dmin, m, ti.group, ti.is_signed, (float)ti.qmin, (float)ti.qmax, qweight, Err,
-                                       ldE, pos * B + (a - c1), perm);
+                                       ldE, pos * B + (a - c1), perm, nullptr, nullptr);
                 GQ_LAUNCH_CHECK();
             }
             if (e < c2) {  // push this segment's rank-1 updates into the rest of the block
@@ -409,6 +500,25 @@ int gptq_quantize(float* W, const float* U, int64_t R, int64_t C, int q_type, in
         }
     }
     return GQ_OK;
+}
+
+int gptq_quantize(float* W, const float* U, int64_t R, int64_t C, int q_type, int block_size, int static_groups,
+                  const gq_search_t* p, uint8_t* qweight, uint16_t* d, uint8_t* s, uint16_t* dmin, uint8_t* m,
+                  void* ws, size_t ws_bytes, hipStream_t st, const int32_t* perm) {
+    return column_loop(W, U, R, C, q_type, block_size, static_groups, p, qweight, d, s, dmin, m, ws, ws_bytes, st, perm,
+                       nullptr);
+}
+
+// EvoPress FastOBQ.step for one bit width (evopress/src/fast_obq.py:146-200) given U.
+int obq_quantize(float* W, const float* U, int64_t R, int64_t C, int bits, int group_size, int sym, int block_size,
+                 uint8_t* qweight, float* scale, float* zero, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (bits < 1 || bits > 8) GQ_FAIL(GQ_E_UNSUPPORTED, "gq_obq_quantize: bits=%d (1..8: qweight is uint8)", bits);
+    if (!scale || !zero) GQ_FAIL(GQ_E_NULL, "gq_obq_quantize: null pointer");
+    if (group_size < 0 || (group_size > 0 && (group_size % SB || C % group_size)))
+        GQ_FAIL(GQ_E_UNSUPPORTED, "gq_obq_quantize: group_size %d must be 0 or a multiple of 16 that divides C=%ld", group_size, (long)C);
+    UniformSpec u{bits, group_size, sym ? 1 : 0, scale, zero};
+    return column_loop(W, U, R, C, -1, block_size, 2, nullptr, qweight, nullptr, nullptr, nullptr, nullptr, ws, ws_bytes,
+                       st, nullptr, &u);
 }
 
 }  // namespace gq

@@ -125,9 +125,10 @@ def h_stage(buf: torch.Tensor, fill: int, x: torch.Tensor):
           "gq_h_stage")
 
 
-def h_prepare(H: torch.Tensor, W: torch.Tensor, rel_damp: float, want_flags: bool = False):
+def h_prepare(H: torch.Tensor, W: torch.Tensor, rel_damp: float, want_flags: bool = False, obq_order: bool = False):
     """In-place dead-channel fix / masking / damping of (H, W); returns (U, not_invertible[int32 tensor])
-    (+ col_flags uint8[2*C] if want_flags: the dead / zero-column sets U depends on)."""
+    (+ col_flags uint8[2*C] if want_flags: the dead / zero-column sets U depends on).  obq_order: damping before
+    the zero-column mask (EvoPress FastOBQ, evopress/src/fast_obq.py:133-141, 221-228)."""
     _need_cuda(H, W)
     assert H.dtype == torch.float32 and W.dtype == torch.float32 and H.is_contiguous() and W.is_contiguous()
     R, C = W.shape
@@ -135,8 +136,9 @@ def h_prepare(H: torch.Tensor, W: torch.Tensor, rel_damp: float, want_flags: boo
     flag = torch.zeros(1, dtype=torch.int32, device=H.device)
     cf = torch.empty(2 * C, dtype=torch.uint8, device=H.device) if want_flags else None
     ws = _ws(workspace_bytes(_cabi.WS_H_PREPARE, R, C), H.device)
-    check(lib().gq_h_prepare(_ptr(H), _ptr(W), R, C, rel_damp, _ptr(U), _ptr(flag), _ptr(cf), _ptr(ws), ws.numel(),
-                             _stream(H)), "gq_h_prepare")
+    fn = lib().gq_obq_h_prepare if obq_order else lib().gq_h_prepare
+    check(fn(_ptr(H), _ptr(W), R, C, rel_damp, _ptr(U), _ptr(flag), _ptr(cf), _ptr(ws), ws.numel(), _stream(H)),
+          "gq_obq_h_prepare" if obq_order else "gq_h_prepare")
     return (U, flag, cf) if want_flags else (U, flag)
 
 
@@ -275,6 +277,26 @@ def gptq_quantize_perm(W: torch.Tensor, U: torch.Tensor, q_type: int, perm: torc
                                       _ptr(s.contiguous()), _ptr(dmin.contiguous()), _ptr(m.contiguous()), _ptr(q),
                                       _ptr(ws), ws.numel(), _stream(W)), "gq_gptq_quantize_perm")
     return q.view(_idt(q_type))
+
+
+def obq_quantize(W: torch.Tensor, U: torch.Tensor, bits: int, group_size: int = 0, sym: bool = False, block_size=128,
+                 ws: Optional[torch.Tensor] = None):
+    """EvoPress FastOBQ.step for one bit width (evopress/src/fast_obq.py:146-200).  W (fp32, contiguous) becomes
+    the dequantized matrix.  Returns (qweight u8 [R, C], scale f32 [R, C/G], zero f32 [R, C/G])."""
+    _need_cuda(W, U)
+    assert W.dtype == torch.float32 and U.dtype == torch.float32 and W.is_contiguous() and U.is_contiguous()
+    R, C = W.shape
+    ng = C // group_size if group_size else 1
+    q = torch.empty(R, C, dtype=torch.uint8, device=W.device)
+    scale = torch.empty(R, ng, dtype=torch.float32, device=W.device)
+    zero = torch.empty(R, ng, dtype=torch.float32, device=W.device)
+    bs = int(block_size or 0)
+    need = workspace_bytes(_cabi.WS_GPTQ_QUANTIZE, R, C, 0, bs)
+    if ws is None or ws.numel() < need:
+        ws = _ws(need, W.device)
+    check(lib().gq_obq_quantize(_ptr(W), _ptr(U), R, C, int(bits), int(group_size or 0), int(bool(sym)), bs, _ptr(q),
+                                _ptr(scale), _ptr(zero), _ptr(ws), ws.numel(), _stream(W)), "gq_obq_quantize")
+    return q, scale, zero
 
 
 def rtn_quantize(W: torch.Tensor, q_type: int, rmin=-1.0, rdelta=0.1, nstep=20, **mq):

@@ -172,6 +172,22 @@ int gq_gptq_quantize_perm(float* W, const float* U, int64_t R, int64_t C, int q_
                           const int32_t* perm, const uint16_t* d, const uint8_t* s, const uint16_t* dmin,
                           const uint8_t* m, uint8_t* qweight, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- EvoPress' FastOBQ (evopress/src/fast_obq.py): the same column loop on uniform min/max grids ----
+   replaces fast_obq.py:133-141 (dead diagonal, damping, W[:, dead] = 0) + :219-232 (_prepare: zero-column mask,
+   U = chol_upper(inv(H))): as gq_h_prepare, but damping comes BEFORE the mask and masked diagonals stay exactly 1.
+   A non-positive-definite H sets *not_invertible (the reference raises from torch.linalg.cholesky). */
+int gq_obq_h_prepare(float* H, float* W, int64_t R, int64_t C, float rel_damp, float* U, int* not_invertible,
+                     uint8_t* col_flags_out, void* ws, size_t ws_bytes, void* stream);
+
+/* replaces fast_obq.py:146-200 for ONE bit width (1..8) given U: q = clamp(round(w / max(scale, 1e-9) + zero), 0,
+   2^bits - 1), w_hat = scale (q - zero) (quant_utils.py:23-29), the grid of a group found from W when its first
+   column is reached (quant_utils.py:57-106, fast_obq.py:168-171).  group_size 0: one grid per row from the original
+   W (:153-154; returned in scale/zero [R, 1], which the reference leaves uninitialised).  group_size % 16 == 0,
+   C % group_size == 0, C % 256 == 0, block_size % 16 == 0.  qweight u8 [R, C]; scale / zero fp32 [R, C/group_size];
+   W becomes the dequantized matrix.  Workspace: GQ_WS_GPTQ_QUANTIZE. */
+int gq_obq_quantize(float* W, const float* U, int64_t R, int64_t C, int bits, int group_size, int sym, int block_size,
+                    uint8_t* qweight, float* scale, float* zero, void* ws, size_t ws_bytes, void* stream);
+
 /* replaces quantizer.py:278-330 (_quant_non_block_module, RTN for embed/lm_head).
    W in w_dtype; GQ_F32 follows the fp32 arithmetic of the reference run with
    --dtype float32. */

@@ -416,6 +416,99 @@ float gqo_dequantize1(float q, uint16_t d, int s, uint16_t dmin, int m) {
     return ds * q - dm;
 }
 
+/* --------------------------------------------------- EvoPress FastOBQ step (uniform grids) */
+
+/* evopress/src/quant_utils.py:57-106 Quantizer.find_params(x, weight=True) with perchannel=True on a [R, G] panel
+   (row stride ld): per row xmin / xmax, sym: symmetric range; equal -> (-1, +1); scale = (xmax - xmin) / maxq;
+   zero = (maxq + 1) / 2 (sym) or round(-xmin / scale). */
+void gqo_uniform_params(const float* x, int64_t rows, int64_t ld, int G, int bits, int sym, float* scale, int64_t s_ld,
+                        float* zero, int64_t z_ld) {
+    const float maxq = (float)((1 << bits) - 1);
+    for (int64_t r = 0; r < rows; ++r) {
+        const float* xr = x + r * ld;
+        float mn = xr[0], mx = xr[0];
+        for (int j = 1; j < G; ++j) {
+            mn = xr[j] < mn ? xr[j] : mn;
+            mx = xr[j] > mx ? xr[j] : mx;
+        }
+        if (sym) {
+            float a = fabsf(mn);
+            mx = a > mx ? a : mx;
+            if (mn < 0.0f) mn = -mx;
+        }
+        if (mn == mx) {
+            mn = -1.0f;
+            mx = 1.0f;
+        }
+        const float sc = (mx - mn) / maxq;
+        scale[r * s_ld] = sc;
+        zero[r * z_ld] = sym ? (maxq + 1.0f) / 2.0f : rintf(-mn / sc);
+    }
+}
+
+/* evopress/src/fast_obq.py:131-200 for ONE bit width, given U = chol_upper(H^-1): the GPTQ column loop with
+   q = clamp(round(w / max(scale, 1e-9) + zero), 0, maxq), w_hat = scale * (q - zero) (quant_utils.py:23-29) and the
+   grid of a group found lazily from the current w at the group's first column (:168-171).  group_size == 0: one
+   grid per row from the ORIGINAL w (:153-154); the reference leaves its scale / zero OUTPUTS uninitialised then
+   (:157-159 only keep them on the handle) -- here they are returned in column 0.  W becomes the dequantized matrix. */
+void gqo_obq_step(float* W, const float* U, int64_t R, int64_t C, int bits, int group_size, int sym, int block_size,
+                  uint8_t* qweight, float* scale, float* zero) {
+    const float maxq = (float)((1 << bits) - 1);
+    const int64_t G = group_size > 0 ? group_size : C, ng = C / G;
+    if (block_size <= 0) block_size = (int)C;
+    if (group_size <= 0) gqo_uniform_params(W, R, C, (int)C, bits, sym, scale, ng, zero, ng);
+    float* w_blk = (float*)malloc(sizeof(float) * (size_t)R * block_size);
+    float* errs = (float*)malloc(sizeof(float) * (size_t)R * block_size);
+    for (int64_t c1 = 0; c1 < C; c1 += block_size) {
+        int64_t c2 = c1 + block_size < C ? c1 + block_size : C;
+        int ncols = (int)(c2 - c1);
+        for (int64_t r = 0; r < R; ++r) memcpy(w_blk + r * ncols, W + r * C + c1, sizeof(float) * ncols);
+        for (int i = 0; i < ncols; ++i) {
+            const int64_t col = c1 + i, g = col / G;
+            if (group_size > 0 && col % G == 0) /* :168-171 reads w, not w_blk */
+                gqo_uniform_params(W + col, R, C, (int)G, bits, sym, scale + g, ng, zero + g, ng);
+            const float dii = U[col * C + col];
+            const float* urow = U + col * C + c1;
+#pragma omp parallel for schedule(static)
+            for (int64_t r = 0; r < R; ++r) {
+                float* wb = w_blk + r * ncols;
+                const float sc = scale[r * ng + g], zp = zero[r * ng + g];
+                const float wci = wb[i];
+                const float q = clampf(rintf(wci / (sc < 1e-9f ? 1e-9f : sc) + zp), 0.0f, maxq);
+                const float wq = sc * (q - zp);
+                qweight[r * C + col] = (uint8_t)q;
+                const float err = (wci - wq) / dii;
+                W[r * C + col] = wq;
+                const float nerr = -1.0f * err;
+                for (int j = i; j < ncols; ++j) wb[j] = wb[j] + nerr * urow[j];
+                errs[r * ncols + i] = err;
+            }
+        }
+        if (c2 < C) { /* :197 addmm_(errs, H_inv_cho[c1:c2, c2:], alpha=-1): k-ordered fma chain, one subtraction */
+#pragma omp parallel
+            {
+                float* acc = (float*)malloc(sizeof(float) * (size_t)(C - c2));
+#pragma omp for schedule(static)
+                for (int64_t r = 0; r < R; ++r) {
+                    const float* e = errs + r * ncols;
+                    float* wr = W + r * C + c2;
+                    const int64_t n = C - c2;
+                    for (int64_t j = 0; j < n; ++j) acc[j] = 0.0f;
+                    for (int k = 0; k < ncols; ++k) {
+                        const float ek = e[k];
+                        const float* ur = U + (c1 + k) * C + c2;
+                        for (int64_t j = 0; j < n; ++j) acc[j] = fmaf(ek, ur[j], acc[j]);
+                    }
+                    for (int64_t j = 0; j < n; ++j) wr[j] = wr[j] - acc[j];
+                }
+                free(acc);
+            }
+        }
+    }
+    free(w_blk);
+    free(errs);
+}
+
 /* ------------------------------------------------------------ GPTQ step */
 
 /* perm != NULL: act_order (gptq.py:208-216): W/U are in permuted order, d/s/dmin/m hold the static scales of
@@ -708,13 +801,23 @@ void gqo_h_accumulate(float* H, const float* X, int64_t T, int64_t C, float beta
         }
 }
 
-int gqo_h_prepare(float* H, float* W, int64_t R, int64_t C, float rel_damp, float* U) {
+static void damp_diag(float* H, int64_t C, float rel_damp) {
+    /* gptq.py:315-316 damping: mean of the diagonal in fp32 (ATen sums in its own order; tolerance-class) */
+    double tr = 0.0;
+    for (int64_t i = 0; i < C; ++i) tr += H[i * C + i];
+    float damp = rel_damp * (float)(tr / (double)C);
+    for (int64_t i = 0; i < C; ++i) H[i * C + i] += damp;
+}
+
+/* obq: EvoPress FastOBQ order (evopress/src/fast_obq.py:133-141 damp first, :221-228 then mask with an undamped 1) */
+static int h_prepare_impl(float* H, float* W, int64_t R, int64_t C, float rel_damp, float* U, int obq) {
     /* gptq.py:134-135,141 */
     for (int64_t i = 0; i < C; ++i)
         if (H[i * C + i] == 0.0f) {
             H[i * C + i] = 1.0f;
             for (int64_t r = 0; r < R; ++r) W[r * C + i] = 0.0f;
         }
+    if (obq) damp_diag(H, C, rel_damp);
     /* gptq.py:307-313 zero columns of W */
     for (int64_t j = 0; j < C; ++j) {
         int allz = 1;
@@ -724,12 +827,7 @@ int gqo_h_prepare(float* H, float* W, int64_t R, int64_t C, float rel_damp, floa
             H[j * C + j] = 1.0f;
         }
     }
-    /* :315-316 damping: mean of the diagonal in fp32 (ATen sums in its own order;
-       tolerance-class) */
-    double tr = 0.0;
-    for (int64_t i = 0; i < C; ++i) tr += H[i * C + i];
-    float damp = rel_damp * (float)(tr / (double)C);
-    for (int64_t i = 0; i < C; ++i) H[i * C + i] += damp;
+    if (!obq) damp_diag(H, C, rel_damp);
 
     /* :318-320  U = chol_upper(inv(H)) in double, via H = L L^T, Hinv = L^-T L^-1 */
     double* A = (double*)malloc(sizeof(double) * (size_t)C * C);
@@ -790,6 +888,13 @@ int gqo_h_prepare(float* H, float* W, int64_t R, int64_t C, float rel_damp, floa
     free(A);
     free(Li);
     return bad;
+}
+
+int gqo_h_prepare(float* H, float* W, int64_t R, int64_t C, float rel_damp, float* U) {
+    return h_prepare_impl(H, W, R, C, rel_damp, U, 0);
+}
+int gqo_obq_h_prepare(float* H, float* W, int64_t R, int64_t C, float rel_damp, float* U) {
+    return h_prepare_impl(H, W, R, C, rel_damp, U, 1);
 }
 
 /* make_k_quants / make_quants in fp16 (rmode 1) / bf16 (rmode 2): exposed for tests */

@@ -58,6 +58,11 @@ void gqo_make_k_quants(const float* x, int64_t n_groups, int G, int bits,
                        double rmin, double rdelta, int nstep, float* scale, float* zero);
 
 /* reference quant_utils.py:147-197 make_quants, absmax branch. */
+/* EvoPress FastOBQ (evopress/src/fast_obq.py:131-200, quant_utils.py:57-106): uniform grids */
+void gqo_uniform_params(const float* x, int64_t rows, int64_t ld, int G, int bits, int sym, float* scale, int64_t s_ld,
+                        float* zero, int64_t z_ld);
+void gqo_obq_step(float* W, const float* U, int64_t R, int64_t C, int bits, int group_size, int sym, int block_size,
+                  uint8_t* qweight, float* scale, float* zero);
 /* quant_scale == "mse" for make_quants (quant_utils.py:164-191): 1 / grid / maxshrink; 0 = absmax (default) */
 void gqo_set_quant_scale(int mse, int grid, double maxshrink);
 void gqo_make_quants(const float* x, int64_t n_groups, int G, int bits, float* scale, float* zero);
@@ -120,6 +125,8 @@ void gqo_h_accumulate(float* H, const float* X, int64_t T, int64_t C, float beta
    damping, U = chol_upper(inv(H)).  Returns 0, or 1 if the identity fallback
    was taken (H not positive definite).  H is mutated like the reference. */
 int gqo_h_prepare(float* H, float* W, int64_t R, int64_t C, float rel_damp, float* U);
+/* EvoPress FastOBQ order: damping before the zero-column mask (evopress/src/fast_obq.py:133-141, 221-228) */
+int gqo_obq_h_prepare(float* H, float* W, int64_t R, int64_t C, float rel_damp, float* U);
 
 #ifdef __cplusplus
 }

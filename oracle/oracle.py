@@ -99,6 +99,23 @@ def make_k_quants(x, bits, rmin=-1.0, rdelta=0.1, nstep=20):
     return sc, ze
 
 
+def obq_step(W, U, bits, group_size=128, sym=False, block_size=128):
+    """EvoPress FastOBQ.step for one bit width (evopress/src/fast_obq.py:131-200) given U.
+    Returns (W_dequantized, qweight u8 [R, C], scale f32 [R, C/G], zero f32 [R, C/G])."""
+    L = lib()
+    vp, i64, ci = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
+    L.gqo_obq_step.argtypes = [vp, vp, i64, i64, ci, ci, ci, ci, vp, vp, vp]
+    L.gqo_obq_step.restype = None
+    W = np.array(W, np.float32, order="C", copy=True)
+    U = np.ascontiguousarray(U, np.float32)
+    R, C = W.shape
+    ng = C // group_size if group_size else 1
+    q = np.empty((R, C), np.uint8)
+    sc, ze = np.empty((R, ng), np.float32), np.empty((R, ng), np.float32)
+    L.gqo_obq_step(_p(W), _p(U), R, C, bits, group_size or 0, int(sym), block_size or 0, _p(q), _p(sc), _p(ze))
+    return W, q, sc, ze
+
+
 def set_quant_scale(mode="absmax", grid=100, maxshrink=0.8):
     """make_quants' quant_scale (quant_utils.py:164-191) for every later call of this module: "absmax" or "mse"."""
     L = lib()
@@ -216,13 +233,16 @@ def h_accumulate(H, X, beta, alpha):
     return H
 
 
-def h_prepare(H, W, rel_damp=0.01):
-    """Returns (U, H_mutated, W_mutated, not_invertible)."""
+def h_prepare(H, W, rel_damp=0.01, obq_order=False):
+    """Returns (U, H_mutated, W_mutated, not_invertible).  obq_order: EvoPress FastOBQ's damp-then-mask."""
     H = np.array(H, np.float32, order="C", copy=True)
     W = np.array(W, np.float32, order="C", copy=True)
     R, C = W.shape
     U = np.empty((C, C), np.float32)
-    bad = lib().gqo_h_prepare(_p(H), _p(W), R, C, rel_damp, _p(U))
+    fn = lib().gqo_obq_h_prepare if obq_order else lib().gqo_h_prepare
+    fn.argtypes = lib().gqo_h_prepare.argtypes
+    fn.restype = ctypes.c_int
+    bad = fn(_p(H), _p(W), R, C, rel_damp, _p(U))
     return U, H, W, bool(bad)
 
 

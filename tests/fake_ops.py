@@ -36,11 +36,11 @@ def h_accumulate_grouped(Hs, Xs, betas, alphas, ws=None):
     return Hs
 
 
-def h_prepare(H, W, rel_damp, want_flags=False):
+def h_prepare(H, W, rel_damp, want_flags=False, obq_order=False):
     calls["h_prepare"] += 1
     H0 = H.numpy().copy()
     dead = (np.diag(H0) == 0)
-    U, H2, W2, bad = O.h_prepare(H0, W.numpy(), rel_damp)
+    U, H2, W2, bad = O.h_prepare(H0, W.numpy(), rel_damp, obq_order=obq_order)
     H.copy_(torch.from_numpy(H2))
     W.copy_(torch.from_numpy(W2))
     flag = torch.tensor([int(bad)], dtype=torch.int32)
@@ -79,6 +79,12 @@ def gptq_quantize_perm(W, U, q_type, perm, d, s, dmin, m, block_size=128, ws=Non
     return torch.from_numpy(q)
 
 
+def obq_quantize(W, U, bits, group_size=0, sym=False, block_size=128, ws=None):
+    Wd, q, sc, ze = O.obq_step(W.numpy(), U.numpy(), bits, group_size or 0, sym, block_size or 0)
+    W.copy_(torch.from_numpy(Wd))
+    return torch.from_numpy(q), torch.from_numpy(sc), torch.from_numpy(ze)
+
+
 def rtn_quantize(W, q_type, rmin=-1.0, rdelta=0.1, nstep=20, **mq):
     _mode(mq)
     q, d, s, dmin, m = O.rtn_quantize(W.float().numpy(), q_type, rmin, rdelta, nstep)
@@ -110,8 +116,9 @@ def install(monkeypatch=None):
     import gptq_gguf_toolkit_amd.quant_utils as qu
     import gptq_gguf_toolkit_amd.quantizer as qz
     import gptq_gguf_toolkit_amd.block_schedule as bs
+    import gptq_gguf_toolkit_amd.fast_obq as fo
     me = sys.modules[__name__]
-    for mod in (g, qu, qz, bs):
+    for mod in (g, qu, qz, bs, fo):
         if monkeypatch is not None:
             monkeypatch.setattr(mod, "_ops", me)
         else:

@@ -689,3 +689,69 @@ def test_gguf_splitter_database(tmp_path):
     s2 = GGUFSplitter(str(tmp_path / "m.gguf"), str(tmp_path / "db2"))
     s2.split_gguf_model()
     assert (tmp_path / "db2" / "blk.0.attn_q.weight" / "4.pth").exists() and (tmp_path / "db2" / "output_norm.weight" / "32.pth").exists()
+
+
+def test_fast_obq_handle_against_reference_run():
+    """f4: the FastOBQ handle (EvoPress' uniform-grid GPTQ, evopress/src/fast_obq.py) fed the seeded inputs of G14
+    through update() -> quantize([2, 3, 4, 8]) against the reference's own run.  The first group's grid has no
+    Hessian in it and must be exact; U comes from the fp64 oracle here and from fp32 LAPACK there, so later ints are
+    held to a rate."""
+    import fake_ops
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from make_golden_shim import OBQ_CASES, obq_inputs
+    from gptq_gguf_toolkit_amd.fast_obq import FastOBQ
+    fake_ops.install()
+    g = load_golden("g14_fast_obq")
+    for tag, R, C, gs, sym, block in OBQ_CASES:
+        W, xs = obq_inputs(R, C)
+        layer = torch.nn.Linear(C, R, bias=False)
+        layer.weight.data = W.clone()
+        h = FastOBQ(layer, bitwidth_options=[2, 3, 4, 8], group_size=gs, sym=sym, rel_damp=0.01, block_size=block)
+        for x in xs:
+            h.update(x)
+        q, s, z, perm = h.quantize([2, 3, 4, 8])
+        assert perm is None and torch.equal(layer.weight.data, W)  # the handle never writes the layer
+        assert np.array_equal(h.W.numpy(), g[f"{tag}_W0"])
+        for b in (2, 3, 4, 8):
+            assert q[b].dtype == torch.uint8 and s[b].shape == (R, C // gs) and z[b].dtype == W.dtype
+            assert np.array_equal(s[b][:, 0].numpy(), g[f"{tag}_b{b}_scale"][:, 0])
+            assert np.array_equal(z[b][:, 0].numpy(), g[f"{tag}_b{b}_zero"][:, 0])
+            assert np.array_equal(q[b][:, 0].numpy(), g[f"{tag}_b{b}_q"][:, 0])
+            mism = float((q[b].numpy() != g[f"{tag}_b{b}_q"]).mean())
+            assert mism < 0.01, f"{tag} {b} bits: {mism:.3%} ints differ from the reference run"
+        h.reset()
+        assert h.H is None and h.num_samples == 0
+    with pytest.raises(ValueError):
+        FastOBQ(torch.nn.Linear(256, 8, bias=False), bitwidth_options=[9])
+    with pytest.raises(NotImplementedError):
+        FastOBQ(torch.nn.Linear(256, 8, bias=False), bitwidth_options=[4], perchannel=False)
+
+
+def test_fast_obq_act_order_and_layer_dtype():
+    """act_order (fast_obq.py:146-149): columns walked in descending order of the damped diagonal, results in
+    permuted positions with `perm` returned; scale / zero come back in the layer's dtype (:150-151)."""
+    import fake_ops
+    from oracle import oracle as O
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from make_golden_shim import obq_inputs
+    from gptq_gguf_toolkit_amd.fast_obq import FastOBQ
+    fake_ops.install()
+    R, C = 16, 256
+    W, xs = obq_inputs(R, C)
+    layer = torch.nn.Linear(C, R, bias=False).half()
+    layer.weight.data = W.half()
+    h = FastOBQ(layer, bitwidth_options=[4], group_size=128, rel_damp=0.01, block_size=128, act_order=True)
+    for x in xs:
+        h.update(x)
+    h.flush()
+    H0 = h.H.numpy().copy()
+    q, s, z, perm = h.quantize([4])
+    d = np.diag(H0).copy()
+    d[d == 0] = 1.0
+    want = np.argsort(-(d + np.float32(0.01) * d.mean(dtype=np.float32)), kind="stable")
+    assert np.array_equal(perm.numpy(), want) and s[4].dtype == torch.float16
+    Wp = W.numpy()[:, want].copy()
+    Wp[:, want == 3] = 0
+    U, *_ = O.h_prepare(H0[want][:, want], Wp, 0.01, obq_order=True)
+    _, q_ref, s_ref, z_ref = O.obq_step(h.W.numpy(), U, 4, 128, False, 128)
+    assert np.array_equal(q[4].numpy(), q_ref) and np.array_equal(s[4].numpy(), s_ref.astype(np.float16))

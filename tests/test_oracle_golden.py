@@ -248,3 +248,60 @@ def test_g9_rtn_model_dtype(oracle, tag, rmode, name):
     if name == "Q4_K":
         q32, *_ = oracle.rtn_quantize(g[f"W_{tag}"], TYPES[name])
         assert (q32 != q).mean() > 0.01
+
+
+# ---------------------------------------------------------------- G14: EvoPress FastOBQ (uniform grids)
+G14_TAGS = ("g128", "g64sym", "g128b64")
+
+
+@pytest.mark.parametrize("tag", G14_TAGS)
+def test_g14_fast_obq_step(oracle, tag):
+    """evopress/src/fast_obq.py:146-200 given (W, U) as the reference's own _prepare produced them: ints, scales and
+    zero points of every bit width are bit-exact."""
+    g = load_golden("g14_fast_obq")
+    R, C, gs, sym, block = (int(v) for v in g[f"{tag}_cfg"])
+    U = triu_unpack(g[f"{tag}_U_triu"], C)
+    for b in (2, 3, 4, 8):
+        Wd, q, sc, ze = oracle.obq_step(g[f"{tag}_W0"], U, b, gs, bool(sym), block)
+        assert np.array_equal(q, g[f"{tag}_b{b}_q"])
+        assert np.array_equal(sc.view(np.uint32), g[f"{tag}_b{b}_scale"].view(np.uint32))
+        assert np.array_equal(ze, g[f"{tag}_b{b}_zero"])
+        grp = np.repeat(np.arange(C // gs), gs)
+        assert np.array_equal(Wd, sc[:, grp] * (q.astype(np.float32) - ze[:, grp]))  # quant_utils.py:28-29
+
+
+@pytest.mark.parametrize("tag", ("g64sym", "g128b64"))
+def test_g14_obq_prepare(oracle, tag):
+    """fast_obq.py:133-141 + 219-232: dead diagonal -> 1, damping, THEN the zero-column mask with an undamped 1."""
+    g = load_golden("g14_fast_obq")
+    R, C, *_ = (int(v) for v in g[f"{tag}_cfg"])
+    U, H2, W2, bad = oracle.h_prepare(g[f"{tag}_H_in"], g[f"{tag}_W_in"], 0.01, obq_order=True)
+    assert not bad and np.array_equal(W2, g[f"{tag}_W0"])  # dead channel 3 zeroed
+    assert np.allclose(np.diag(H2), g[f"{tag}_H_after_diag"], rtol=1e-6)
+    assert H2[3, 3] == 1.0 and H2[7, 7] == 1.0  # masked AFTER the damping
+    for r in (3, 7):
+        assert np.array_equal(H2[r], g[f"{tag}_H_after_row{r}"])
+    Uref = triu_unpack(g[f"{tag}_U_triu"], C)
+    assert np.abs(U - Uref).max() <= 1e-4 * np.abs(Uref).max()
+
+
+def test_obq_step_per_row_grid(oracle):
+    """group_size None (fast_obq.py:153-154): one grid per row from the original W; the first block checked against a direct
+    numpy restatement of the column loop (the reference leaves scale / zero outputs uninitialised here)."""
+    rng = np.random.default_rng(5)
+    R, C = 8, 256
+    W = (rng.standard_normal((R, C)) * 0.05).astype(np.float32)
+    X = rng.standard_normal((512, C)).astype(np.float32)
+    U, *_ = oracle.h_prepare((2.0 / 512 * X.T @ X).astype(np.float32), W, 0.01, obq_order=True)
+    Wd, q, sc, ze = oracle.obq_step(W, U, 3, 0, False, 128)
+    mn, mx = W.min(1), W.max(1)
+    s_ref = ((mx - mn) / np.float32(7)).astype(np.float32)
+    z_ref = np.round(-mn / s_ref)
+    assert np.array_equal(sc[:, 0], s_ref) and np.array_equal(ze[:, 0], z_ref)
+    blk = W[:, :128].copy()  # the first block: no trailing update has touched it, so numpy restates it bit for bit
+    for i in range(128):
+        qq = np.clip(np.round(blk[:, i] / np.maximum(s_ref, np.float32(1e-9)) + z_ref), 0, 7).astype(np.float32)
+        wq = s_ref * (qq - z_ref)
+        assert np.array_equal(q[:, i], qq.astype(np.uint8)) and np.array_equal(Wd[:, i], wq)
+        err = ((blk[:, i] - wq) / U[i, i]).astype(np.float32)
+        blk[:, i:] = blk[:, i:] + (-err)[:, None] * U[i, i:128][None]
