@@ -9,9 +9,14 @@ schedules kernels:
                tensor (q/k/v, gate/up) are detected and share one Hessian.  Activations are buffered by the
                handles; `sample_done()` (after every calibration sample) folds the buffers of ALL distinct
                inputs into their Hessians with grouped SYRK launches once they hold `flush_tokens` tokens:
-               the narrow inputs in one grid, then the widest input alone on the chip.
-  quantize()   phase 0  the remaining tokens are folded in; [N>1] ONE all-reduce per distinct Hessian, widest
-                        first (gptq.py:131-132 does one per handle);
+               the narrow inputs in one grid, then the widest input alone on the chip.  [N=1] Only the WIDEST
+               input is folded as the samples arrive; the narrow ones (zero-copy references, a few GB) are
+               kept and folded -- in the very same portions -- at quantize() time on a side stream, UNDER the
+               widest input's factorisation and column loop, which are chains of small dependent launches
+               that leave the matrix cores idle.
+  quantize()   phase 0  the remaining tokens are folded in (the postponed narrow inputs on a side stream);
+                        [N>1] ONE all-reduce per distinct Hessian, widest first (gptq.py:131-132 does one per
+                        handle);
                phase 1  every input group is an independent chain (h_prepare -> per Linear: working copy,
                         column loop, dequantize) and runs on its own HIP stream, widest chain first: the
                         single-workgroup leaves of one factorisation and the 64-CU column-loop kernels overlap
@@ -98,6 +103,9 @@ class BlockSchedule:
         self.verbose = verbose
         self.stats = {"syrk_launches": 0, "allreduce_bytes": 0, "reused_U": 0, "own_U": 0, "refactorised": 0}
         self.owners: Dict[str, Any] = {}  # name -> owner rank or "rows/<world>" of the last quantize()
+        # postponed folds of the narrow inputs (single rank): on / off, and the bytes of activations it may keep
+        self.defer_narrow = os.environ.get("GQ_DEFER_NARROW", "1") == "1"
+        self.defer_bytes = int(float(os.environ.get("GQ_DEFER_GB", 48)) * 2 ** 30)
 
     # ------------------------------------------------------------------ hook side
     def hook(self, name: str):
@@ -127,8 +135,8 @@ class BlockSchedule:
         self._seen.clear()
         if self._sharing is None:
             self._publish_sharing()
-        if any(h._fill >= h.flush_tokens for h in self.handles.values()):
-            self.flush()
+        if any(h._fill - h._marked >= h.flush_tokens for h in self.handles.values()):
+            self.flush(postpone=True)
 
     def _publish_sharing(self) -> None:
         """After the block's first sample: for every follower, "its weight's all-zero columns differ from its
@@ -167,14 +175,73 @@ class BlockSchedule:
     def leaders(self) -> List[GPTQ]:
         return [h for h in self.handles.values() if h.shared_H_with is None]
 
-    def flush(self) -> None:
+    def _postponable(self, todo: List[GPTQ]) -> List[GPTQ]:
+        """The narrow inputs whose fold may wait for quantize(): single rank, a strictly widest input exists,
+        everything pending is a kept reference (nothing staged), and the kept bytes fit the budget."""
+        if not self.defer_narrow or len(todo) < 2 or dist_utils.get_world_size() > 1:
+            return []
+        if todo[0].d_col <= todo[1].d_col or torch.device(todo[0].W_device).type != "cuda" or self.n_streams < 2:
+            return []
+        rest = todo[1:]
+        if any(h._staged or not h._segs for h in rest):
+            return []
+        kept = sum(x.numel() * x.element_size() for h in rest for x, _, _ in h._segs)
+        return rest if kept <= self.defer_bytes else []
+
+    def _fold(self, grids: List[List[GPTQ]], upto: Optional[Dict[int, int]] = None) -> List[Any]:
+        """One grouped SYRK launch per grid (on the current stream); returns the activation blocks it reads."""
+        read = []
+        for grp in grids:
+            args = [h._flush_args(None if upto is None else upto[id(h)]) for h in grp]
+            _ops.h_accumulate_grouped([a[0] for a in args], [a[1] for a in args], [a[2] for a in args],
+                                      [a[3] for a in args])
+            self.stats["syrk_launches"] += 1
+            read += [a[1] for a in args]
+            for h in grp:
+                h._flush_done(None if upto is None else upto[id(h)])
+        return read
+
+    def _fold_postponed(self) -> List[Any]:
+        """The postponed folds of the narrow inputs, portion by portion exactly as sample_done() would have issued
+        them (same launches, same order per Hessian: bit-identical H), on the current stream."""
+        read = []
+        while True:
+            todo = [h for h in self.leaders() if h._marks]
+            if not todo:
+                return read
+            todo.sort(key=lambda h: (-h.d_col, id(h)))
+            upto = {id(h): h._marks[0] for h in todo}
+            by_kind: Dict[Any, List[GPTQ]] = {}
+            for h in todo:
+                by_kind.setdefault((h._pending_dtype(), h._pending_device()), []).append(h)
+            grids = [grp[i:i + 8] for grp in by_kind.values() for i in range(0, len(grp), 8)]
+            read += self._fold(grids, upto)
+            for h in todo:
+                first = h._marks.pop(0)
+                h._marks = [m - first for m in h._marks]
+
+    def flush(self, postpone: bool = False) -> None:
         """Fold every leader's buffered activations into its Hessian: grouped SYRK launches (<= 8 problems per
         grid, one activation dtype per grid), the narrow inputs first and the widest input alone -- its tiles
-        fill the chip for ~5 ms per 64 Ki tokens, nothing is gained by mixing it with the others."""
+        fill the chip for ~5 ms per 64 Ki tokens, nothing is gained by mixing it with the others.
+        `postpone` (sample_done): the narrow inputs only note where this fold would have ended (_postponable)."""
         todo = [h for h in self.leaders() if h._fill > 0]
         if not todo:
             return
         todo.sort(key=lambda h: (-h.d_col, id(h)))
+        later = self._postponable(todo) if postpone else []
+        if later:
+            for h in later:
+                h._marks.append(len(h._segs))
+                h._marked = h._fill
+            self._fold([[todo[0]]])
+            self.stats["postponed_folds"] = self.stats.get("postponed_folds", 0) + 1
+            return
+        if any(h._marks for h in todo):  # postponed portions first, in their own launches (never merged with newer tokens)
+            self._fold_postponed()
+            todo = [h for h in todo if h._fill > 0]
+            if not todo:
+                return
         grids: List[List[GPTQ]] = []
         if len(todo) > 1 and todo[0].d_col > todo[1].d_col and not os.environ.get("GQ_SYRK_ONE_GRID"):
             rest, grids_tail = todo[1:], [[todo[0]]]
@@ -186,13 +253,7 @@ class BlockSchedule:
         for grp in by_kind.values():
             grids += [grp[i:i + 8] for i in range(0, len(grp), 8)]
         grids += grids_tail
-        for grp in grids:
-            args = [h._flush_args() for h in grp]
-            _ops.h_accumulate_grouped([a[0] for a in args], [a[1] for a in args], [a[2] for a in args],
-                                      [a[3] for a in args])
-            self.stats["syrk_launches"] += 1
-            for h in grp:
-                h._flush_done()
+        self._fold(grids)
 
     # ------------------------------------------------------------------ multi-rank agreement
     def _agree_on_sharing(self) -> None:
@@ -251,8 +312,30 @@ class BlockSchedule:
         main = torch.cuda.current_stream(dev) if on_gpu else None
 
         # ---- phase 0: the rest of the tokens, then one all-reduce per distinct Hessian, widest first
-        self.flush()
         ready: Dict[int, Any] = {}
+        held: List[Any] = []
+        late = [h for h in self.leaders() if h._marks]
+        side = _chain_streams(dev, self.n_streams - 1)[:1] if on_gpu and late else []
+        if side:
+            # the postponed narrow inputs: every portion on the first side stream, next to the widest chain; their
+            # last tokens ride along as one more portion.  The kept activation tensors stay referenced until the
+            # lanes have joined the caller's stream (they were allocated on it).
+            entry = torch.cuda.Event()
+            entry.record(main)
+            wide = [h for h in self.leaders() if h._fill > 0 and not h._marks]
+            for h in late:
+                if len(h._segs) > h._marks[-1]:
+                    h._marks.append(len(h._segs))
+            side[0].wait_event(entry)
+            with torch.cuda.stream(side[0]):
+                held = self._fold_postponed()
+                folded = torch.cuda.Event()
+                folded.record(side[0])
+            for h in late:
+                ready[id(h)] = folded
+            if wide:
+                self._fold([[h] for h in sorted(wide, key=lambda h: -h.d_col)])
+        self.flush()
         for h in sorted(self.leaders(), key=lambda h: -h.d_col):
             h.sync_hessian()
             if world > 1:

@@ -62,7 +62,9 @@ class GPTQ:
         self._buf = None
         self._fill = 0                 # pending tokens (kept blocks + staged rows)
         self._staged = 0               # rows of _buf in use
-        self._segs = []                # zero-copy: (tensor, version at hook time) per pending sample
+        self._segs = []                # zero-copy: (tensor, version at hook time, batch size) per pending sample
+        self._marks = []               # BlockSchedule: numbers of pending samples at which a fold was postponed
+        self._marked = 0               # ... and the pending tokens those postponed folds cover
         self._zero_copy = os.environ.get("GQ_STAGE_COPY") != "1"
         self._buf_b = 0
         self._U_cache = None
@@ -93,7 +95,7 @@ class GPTQ:
         if self._zero_copy and self._staged == 0 and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) \
                 and x.is_contiguous() and t % 128 == 0 and self.d_col % 256 == 0 and x.data_ptr() % 16 == 0 \
                 and (not self._segs or (self._segs[0][0].shape == x.shape and self._segs[0][0].dtype == x.dtype)):
-            self._segs.append((x, x._version))
+            self._segs.append((x, x._version, batch_size))
         else:
             self._stage(x)
         self._fill += t
@@ -105,7 +107,7 @@ class GPTQ:
         """Append x [t, C] to the staging buffer (behind the kept zero-copy blocks, which move into it first)."""
         if self._pending_dtype() not in (None, x.dtype):
             self.flush()  # one activation dtype per fold
-        pend, self._segs = [y for y, _ in self._segs], []
+        pend, self._segs, self._marks, self._marked = [y for y, _, _ in self._segs], [], [], 0
         need = self._staged + sum(y.shape[0] for y in pend) + x.shape[0]
         if self._buf is not None and (self._buf.dtype != x.dtype or need > self._buf.shape[0]):
             if self._staged:  # the staged rows are exactly the samples counted so far (pend is empty in this mode)
@@ -134,25 +136,39 @@ class GPTQ:
         _ops.h_accumulate(H, X, beta, alpha)
         self._flush_done()
 
-    def _flush_args(self):
+    def _flush_args(self, upto: Optional[int] = None):
         """(H, X, beta, alpha) of the pending fold; X is [T, C] or the list of kept [L, C] blocks.  b samples at
-        once are the telescoped form of b single updates of gptq.py:106-112."""
+        once are the telescoped form of b single updates of gptq.py:106-112.  `upto`: only the first `upto` kept
+        blocks (a fold the block schedule postponed; pair with _flush_done(upto))."""
         n, b = self.num_samples, self._buf_b
         if self._segs:
-            for x, v in self._segs:
+            segs = self._segs if upto is None else self._segs[:upto]
+            for x, v, _ in segs:
                 if x._version != v:
                     raise RuntimeError("a Linear input was modified in place after its forward hook ran; set "
                                        "GQ_STAGE_COPY=1 to copy activations at hook time")
-            X = [x for x, _ in self._segs]
+            X = [x for x, _, _ in segs]
+            b = sum(bs for _, _, bs in segs)
         else:
             X = self._buf[:self._staged]
         return self.H, X, n / (n + b), 2.0 / (n + b)
 
-    def _flush_done(self) -> None:
+    def _flush_done(self, upto: Optional[int] = None) -> None:
+        if upto is not None and self._segs:
+            done, self._segs = self._segs[:upto], self._segs[upto:]
+            b = sum(bs for _, _, bs in done)
+            self.num_samples += b
+            self._buf_b -= b
+            t = sum(x.shape[0] for x, _, _ in done)
+            self._fill -= t
+            self._marked = max(0, self._marked - t)
+            return
         self.num_samples += self._buf_b
         self._fill = 0
         self._staged = 0
         self._segs = []
+        self._marks = []
+        self._marked = 0
         self._buf_b = 0
 
     def reset(self) -> None:
@@ -166,6 +182,8 @@ class GPTQ:
         self._fill = 0
         self._staged = 0
         self._segs = []
+        self._marks = []
+        self._marked = 0
         self._buf_b = 0
         self._reduced = False
         self.shared_H_with = None

@@ -238,7 +238,7 @@ def test_cholesky_chain_accuracy_full_size(ops):
 
 # ----------------------------------------------------------------- the package's block scheduler
 def _toy_block(seed=0, dims=((512, 512, "a"), (256, 512, "a"), (256, 512, "a"), (512, 512, "o"), (1024, 512, "m"),
-                             (1024, 512, "m"), (512, 1024, "d"))):
+                             (1024, 512, "m"), (512, 1024, "d")), L=96, n_samples=6):
     names = ["q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj"]
     g = torch.Generator(device="cuda").manual_seed(seed)
     layers, inputs = {}, {}
@@ -248,7 +248,7 @@ def _toy_block(seed=0, dims=((512, 512, "a"), (256, 512, "a"), (256, 512, "a"), 
         layers[n] = lin
         if grp not in inputs:
             sig = torch.exp(torch.randn(C, device="cuda", generator=g) * 0.5)
-            inputs[grp] = [(torch.randn(1, 96, C, device="cuda", generator=g) * sig).half() for _ in range(6)]
+            inputs[grp] = [(torch.randn(1, L, C, device="cuda", generator=g) * sig).half() for _ in range(n_samples)]
     return layers, {n: inputs[grp] for n, (_, _, grp) in zip(names, dims)}
 
 
@@ -285,6 +285,45 @@ def test_block_schedule_equals_per_handle_quantize(ops):
             assert torch.equal(a, b), f"{n}: scheduler result differs from the per-handle path"
         from gptq_gguf_toolkit_amd.quant_utils import dequantize_linear_weight
         assert torch.equal(l.weight.data, dequantize_linear_weight(qt[n], *ref, out_dtype=torch.float16))
+
+
+def test_postponed_narrow_folds_change_nothing(ops):
+    """Single rank: the narrow inputs' SYRK portions are postponed to quantize() and run on a side stream under the
+    widest input's chain (zero-copy references kept meanwhile).  Same portions, same order per Hessian: results
+    are bit-identical to folding as the samples arrive, with and without a tail portion, and when the budget of
+    kept bytes stops the postponement half way."""
+    from gptq_gguf_toolkit_amd.block_schedule import BlockSchedule
+    from gptq_gguf_toolkit_amd.gptq import GPTQ
+    from gptq_gguf_toolkit_amd.quant_utils import GGMLQuantizationType as T
+    qt = {"q_proj": T.Q3_K, "k_proj": T.Q2_K, "v_proj": T.Q4_K, "o_proj": T.Q5_K, "gate_proj": T.Q6_K,
+          "up_proj": T.Q4_K, "down_proj": T.Q4_K}
+    for n_samples, budget in ((6, None), (7, None), (7, 3 * 3 * 128 * 512 * 2)):
+        runs = {}
+        for defer in (False, True):
+            layers, xs = _toy_block(seed=11, L=128, n_samples=n_samples)
+            sched = BlockSchedule(layers, lambda l, n: GPTQ(l, rel_damp=0.01, block_size=128))
+            sched.defer_narrow = defer
+            if budget is not None:
+                sched.defer_bytes = budget  # three samples of the three narrow inputs
+            for h in sched.handles.values():
+                h.flush_tokens = 256  # a fold every two samples
+            for i in range(n_samples):
+                for n in layers:
+                    sched.feed(n, xs[n][i])
+                sched.sample_done()
+            hs = {n: h for n, h in sched.handles.items()}
+            pending = sum(len(h._marks) for h in hs.values())
+            out = sched.quantize(qt, writeback=True)
+            torch.cuda.synchronize()
+            runs[defer] = (out, {n: l.weight.data.clone() for n, l in layers.items()}, sched.stats, pending)
+        assert runs[False][2].get("postponed_folds", 0) == 0 and runs[False][3] == 0
+        # with the budget: postponed after sample 2, over budget at sample 4 (everything folded), postponed again at 6
+        assert runs[True][2]["postponed_folds"] == (3 if budget is None else 2) and runs[True][3] > 0
+        assert runs[True][2]["syrk_launches"] == runs[False][2]["syrk_launches"]
+        for n in qt:
+            for a, b in zip(runs[True][0][n], runs[False][0][n]):
+                assert torch.equal(a, b), f"{n}: postponed folds changed a result"
+            assert torch.equal(runs[True][1][n], runs[False][1][n])
 
 
 def test_block_schedule_follower_with_own_zero_column(ops):
