@@ -401,6 +401,18 @@ def test_bench_two_ranks_hold_identical_results():
     assert set(owners.values()) == {0, 1}, owners  # both ranks own matrices
 
 
+def test_bench_four_ranks_row_split_and_owners():
+    """From 4 ranks up the widest matrix is split by rows (every rank factorises the same reduced H and walks its own
+    rows, all-gather of the row slices) and the other six are dealt to owners: bench.py --gpus 4, RCCL when the box
+    has four GPUs, else four gloo ranks sharing the one GPU; every rank must hold identical results."""
+    backend = "nccl" if torch.cuda.device_count() >= 4 else "gloo"
+    line, err = _spawn_bench(4, backend)
+    assert "verify: all ranks hold identical results" in err
+    assert line["n_gpus"] == 4 and line["ranks_seen"] == 4
+    owners = line["config"]["owners"]
+    assert owners["down_proj"] == "rows/4" and {v for k, v in owners.items() if k != "down_proj"} == {0, 1, 2, 3}, owners
+
+
 def _g13_gpu_worker(rank, world, port, ret, backend):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import test_host_logic_cpu as hl
