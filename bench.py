@@ -308,6 +308,50 @@ def tolerance_parity(wl, W16, X, n_seq=8):
         return {"error": repr(e)}
 
 
+def fast_obq_leg(wl, W16, X, n_seq=32, bits=(2, 3, 4, 8)):
+    """f4: EvoPress' uniform-grid GPTQ (evopress/src/fast_obq.py) on the block's widest Linear through the package's
+    FastOBQ handle -- one Hessian and ONE factorisation, then one column loop per bit width (the layer database the
+    search reads, evopress/src/quantizer.py:146-171) -- timed alone on the GPU, and a 64-row slice of every bit width
+    checked against the oracle's restatement on the same U."""
+    try:
+        from oracle import oracle as O
+        from gptq_gguf_toolkit_amd.fast_obq import FastOBQ
+        shapes = wl["shapes"]
+        name = max(shapes, key=lambda n: shapes[n][0] * shapes[n][1] * shapes[n][1])
+        R, C, inp = shapes[name]
+        lin = torch.nn.Linear(C, R, bias=False, device=W16[name].device, dtype=W16[name].dtype)
+        lin.weight.data = W16[name]
+        out = {}
+        for it in range(2):  # the second pass is the timed one
+            h = FastOBQ(lin, bitwidth_options=list(bits), group_size=128, sym=False, rel_damp=0.01, block_size=128)
+            for x in X[inp][:n_seq]:
+                h.update(x)
+            h.flush()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            q, sc, ze, _ = h.quantize(list(bits))
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        U = h._last_U.cpu().numpy()
+        rows = slice(R // 2 - 32, R // 2 + 32)
+        W0 = h.W[rows].cpu().numpy()
+        same = []
+        for b in bits:
+            _, oq, osc, oze = O.obq_step(W0, U, b, 128, False, 128)
+            same.append(bool(np.array_equal(q[b][rows].cpu().numpy(), oq)
+                             and np.array_equal(sc[b][rows].float().cpu().numpy(), osc.astype(np.float16).astype(np.float32)
+                                                if sc[b].dtype == torch.float16 else osc)))
+        out = {"linear": f"{name} {R}x{C}", "bit_widths": list(bits), "group_size": 128, "tokens": int(n_seq * X[inp][0].numel() // C),
+               "ms_prepare_plus_all_loops": round(dt * 1e3, 2),
+               "Mparams_per_s_per_bit_width": round(R * C * len(bits) / dt / 1e6, 1),
+               "oracle_rows_equal": same,
+               "note": "one factorisation, len(bit_widths) column loops; timed alone on the GPU after the timed region"}
+        h.reset()
+        return out
+    except Exception as e:
+        return {"error": repr(e)}
+
+
 def cpu_baseline(wl, W16, keep):
     """Oracle (C restatement of the reference, OpenMP) on the host cores: GPTQ.step of every Linear of the block (218 M
     params at 8B sizes) with the U the GPU used for each.  ~10 s of CPU on 8 cores."""
@@ -604,6 +648,7 @@ def main():
             "roofline": roof,
             "trailing_update": trailing_update_legs(wl, W16, X, (far[0], far[1], far[2], args.steps)) if side else None,
             "tolerance_parity": tolerance_parity(wl, W16, X) if side else None,
+            "fast_obq": fast_obq_leg(wl, W16, X) if side else None,
             "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline(wl, W16, keep),
         }
     del keep, sched
