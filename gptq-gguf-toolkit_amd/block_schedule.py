@@ -364,7 +364,12 @@ class BlockSchedule:
         order = sorted(chains.values(), key=chain_cost)
         # the costliest chain stays on the caller's stream (it ends last anyway), the others get side streams
         on_main = 1 if os.environ.get("GQ_CHAIN_MAIN", "1") == "1" else 0
-        streams = [None] * on_main + _chain_streams(dev, min(self.n_streams, len(order)) - on_main)
+        # a chain whose column loop keeps its far updates on the library's helper stream brings a hardware queue
+        # of its own: one lane fewer here (five queues cost more than the overlap gains)
+        lent = 1 if on_gpu and self.n_streams > 2 and any(
+            _ops.uses_helper_stream(h.d_row, h.d_col, h.block_size) for h in handles.values()
+            if h.owner_rank == rank and not h._row_split_active()) else 0
+        streams = [None] * on_main + _chain_streams(dev, min(self.n_streams - lent, len(order)) - on_main)
         results: Dict[str, tuple] = {}
         deq: Dict[str, torch.Tensor] = {}
         lanes = []

@@ -29,6 +29,7 @@ size_t h_prepare_workspace_bytes(int64_t, int64_t);
 int h_prepare(float*, float*, int64_t, int64_t, float, float*, int*, uint8_t*, void*, size_t, hipStream_t, bool);
 int obq_quantize(float*, const float*, int64_t, int64_t, int, int, int, int, uint8_t*, float*, float*, void*, size_t,
                  hipStream_t);
+int gptq_uses_helper_stream(int64_t, int64_t, int);
 int w_prepare(const uint8_t*, float*, int64_t, int64_t, int*, hipStream_t);
 int h_pack_upper(const float*, int64_t, float*, hipStream_t);
 int h_unpack_upper(const float*, int64_t, float*, hipStream_t);
@@ -125,6 +126,8 @@ int gq_h_prepare(float* H, float* W, int64_t R, int64_t C, float rel_damp, float
                  uint8_t* col_flags_out, void* ws, size_t ws_bytes, void* stream) {
     return h_prepare(H, W, R, C, rel_damp, U, not_invertible, col_flags_out, ws, ws_bytes, (hipStream_t)stream, false);
 }
+
+int gq_gptq_uses_helper_stream(int64_t R, int64_t C, int block_size) { return gptq_uses_helper_stream(R, C, block_size); }
 
 int gq_obq_h_prepare(float* H, float* W, int64_t R, int64_t C, float rel_damp, float* U, int* not_invertible,
                      uint8_t* col_flags_out, void* ws, size_t ws_bytes, void* stream) {

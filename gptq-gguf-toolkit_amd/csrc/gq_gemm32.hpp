@@ -291,8 +291,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
     asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(fa0[s]), "+v"(fa1[s]), "+v"(fb0[s]), "+v"(fb1[s]) : "n"(N))
 
 template <int CHAIN>
-__global__ __launch_bounds__(512, 2) void gemm32_chain_full_kernel(float* Cmat, int64_t ldc, const float* A, int64_t lda,
-                                                                   const float* B, int64_t ldb, int64_t K) {
+__device__ __forceinline__ void g32_chain_full_tile(float* Cmat, int64_t ldc, const float* A, int64_t lda, const float* B,
+                                                    int64_t ldb, int64_t K, const int64_t m0, const int64_t n0) {
     extern __shared__ __attribute__((aligned(16))) float g32_smem[];
     constexpr int TS = 128, NT = 512, NV = 2, STAGE = G32<TS>::STAGE_FLOATS, AF = G32<TS>::A_FLOATS, LDB = G32<TS>::LDB;
     constexpr int SPC = CHAIN / TK;  // chunks per chain
@@ -300,7 +300,6 @@ __global__ __launch_bounds__(512, 2) void gemm32_chain_full_kernel(float* Cmat, 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 2, wn = wid & 3;
     const int li = lane & 31, lk = lane >> 5;
-    const int64_t m0 = (int64_t)blockIdx.y * TS, n0 = (int64_t)blockIdx.x * TS;
     const int64_t nk = K / TK;
     f32x16 acc[2], cv[2];
     float* cp[2];
@@ -414,16 +413,43 @@ __global__ __launch_bounds__(512, 2) void gemm32_chain_full_kernel(float* Cmat, 
 #undef GQ_C_READS
 
 template <int CHAIN>
+__global__ __launch_bounds__(512, 2) void gemm32_chain_full_kernel(float* Cmat, int64_t ldc, const float* A, int64_t lda,
+                                                                   const float* B, int64_t ldb, int64_t K) {
+    g32_chain_full_tile<CHAIN>(Cmat, ldc, A, lda, B, ldb, K, (int64_t)blockIdx.y * 128, (int64_t)blockIdx.x * 128);
+}
+// The same tiles walked by a FIXED number of workgroups (gridDim.x of them, tile t = blockIdx.x + i gridDim.x, column
+// tile fastest): the launch never holds more CUs than that, whatever its size -- the look-ahead far update of the
+// GPTQ column loop runs next to the loop's own kernels this way (gq_gptq.hip).  Same arithmetic per element.
+template <int CHAIN>
+__global__ __launch_bounds__(512, 2) void gemm32_chain_full_persistent_kernel(float* Cmat, int64_t ldc, const float* A,
+                                                                              int64_t lda, const float* B, int64_t ldb,
+                                                                              int64_t K, int64_t ntx, int64_t ntiles) {
+    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        g32_chain_full_tile<CHAIN>(Cmat, ldc, A, lda, B, ldb, K, (t / ntx) * 128, (t % ntx) * 128);
+        __syncthreads();  // every wave is done with the LDS ring before the next tile's first image is written
+    }
+}
+
+// max_wgs > 0: the persistent form with at most that many workgroups
+template <int CHAIN>
 inline int launch_gemm32_chain_full(float* Cmat, int64_t ldc, const float* A, int64_t lda, const float* B, int64_t ldb,
-                                    int64_t M, int64_t N, int64_t K, hipStream_t st) {
+                                    int64_t M, int64_t N, int64_t K, hipStream_t st, int max_wgs = 0) {
     constexpr int LDS = 3 * G32<128>::STAGE_FLOATS * 4;
     static std::atomic<bool> attr_set{false};  // guards an idempotent call: a race sets the same value twice
     if (!attr_set) {
         GQ_HIP(hipFuncSetAttribute((const void*)gemm32_chain_full_kernel<CHAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        GQ_HIP(hipFuncSetAttribute((const void*)gemm32_chain_full_persistent_kernel<CHAIN>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr_set = true;
     }
-    dim3 grid((unsigned)(N / 128), (unsigned)(M / 128)), block(512);
-    hipLaunchKernelGGL((gemm32_chain_full_kernel<CHAIN>), grid, block, LDS, st, Cmat, ldc, A, lda, B, ldb, K);
+    const int64_t ntx = N / 128, ntiles = ntx * (M / 128);
+    if (max_wgs > 0 && ntiles > max_wgs) {
+        hipLaunchKernelGGL((gemm32_chain_full_persistent_kernel<CHAIN>), dim3((unsigned)max_wgs), dim3(512), LDS, st, Cmat, ldc,
+                           A, lda, B, ldb, K, ntx, ntiles);
+    } else {
+        dim3 grid((unsigned)ntx, (unsigned)(M / 128)), block(512);
+        hipLaunchKernelGGL((gemm32_chain_full_kernel<CHAIN>), grid, block, LDS, st, Cmat, ldc, A, lda, B, ldb, K);
+    }
     GQ_LAUNCH_CHECK();
     return GQ_OK;
 }

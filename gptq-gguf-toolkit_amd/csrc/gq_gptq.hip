@@ -8,6 +8,7 @@
 // (v_mfma_f32_32x32x2_f32 == a k-ordered fmaf chain, which is what the reference's
 // sgemm computes per element -- verified bit-for-bit in tests/golden G6).
 #include <atomic>
+#include <mutex>
 #include "gq_common.hpp"
 #include "gq_gemm32.hpp"
 #include <stdlib.h>
@@ -321,10 +322,59 @@ int launch_trailing_update(float* Cmat, int64_t ldc, const float* A, int64_t lda
 constexpr int LA = 8;
 constexpr int LA_B = 128;  // only this block size takes the look-ahead path (the chain length is a template constant)
 
+// ---- the far update next to the column loop (single-Linear look-ahead pipeline) ----
+// The far update of super-block s (everything beyond it) is one MFMA-bound GEMM; the column loop of super-block s+1
+// is a string of small latency-bound launches that needs the far update on ITS OWN 1024 columns only.  So the far
+// update is cut by column groups (g = 1024-column group index; F_s[g] = super-block s's update of group g):
+//   caller's stream:  loop(s) | F_s[s+1] | loop(s+1) | F_{s+1}[s+2] | ...
+//   helper stream:             F_s[s+2] , F_s[s+3..] | F_{s+1}[s+3] , F_{s+1}[s+4..] | ...
+// F_s[s+1] waits for F_{s-1}[s+1] (an event after that small launch); the helper launches are PERSISTENT with a
+// bounded number of workgroups, so the loop's kernels always find free CUs instead of queueing behind 56-us GEMM
+// tiles.  Every element of W still sees ((w - E_0 U_0) - E_1 U_1) - ... in the same order: results are unchanged.
+// The error buffer is doubled (the helper may still read super-block s's errors while the loop fills s+1's).
+static bool far_async_shape(int64_t R, int64_t C, int64_t B, int la) {
+    // read per call (three getenv per Linear): tests and A/B runs flip them inside one process
+    const bool off = getenv("GQ_FAR_SYNC") != nullptr;
+    const int64_t max_rows = getenv("GQ_FAR_ASYNC_MAX_ROWS") ? atol(getenv("GQ_FAR_ASYNC_MAX_ROWS")) : 8192;
+    const int64_t min_sb = getenv("GQ_FAR_ASYNC_MIN_SB") ? atol(getenv("GQ_FAR_ASYNC_MIN_SB")) : 8;
+    return !off && B == LA_B && R % 128 == 0 && C % 128 == 0 && R <= max_rows && C >= min_sb * (int64_t)la * B;
+}
+struct FarHelper {
+    hipStream_t st = nullptr;
+};
+static int far_helper_stream(hipStream_t* out) {
+    static std::mutex mu;
+    static FarHelper per_dev[64];
+    int dev = 0;
+    GQ_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    FarHelper& h = per_dev[dev & 63];
+    if (!h.st) GQ_HIP(hipStreamCreateWithFlags(&h.st, hipStreamNonBlocking));
+    *out = h.st;
+    return GQ_OK;
+}
+// re-recordable events of the calling host thread (a wait captures the record that precedes it)
+static int far_event(int i, hipEvent_t* out) {
+    thread_local hipEvent_t pool[96] = {};
+    hipEvent_t& e = pool[i % 96];
+    if (!e) GQ_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    *out = e;
+    return GQ_OK;
+}
+
+// does gq_gptq_quantize(R, C, block_size) put its far updates on the library's helper stream?
+int gptq_uses_helper_stream(int64_t R, int64_t C, int block_size) {
+    const int64_t B = block_size <= 0 || block_size > C ? C : block_size;
+    int la = LA;
+    if (const char* e = getenv("GQ_LA")) la = (atoi(e) >= 2 && atoi(e) <= LA && atoi(e) % 2 == 0) ? atoi(e) : LA;
+    return getenv("GQ_NO_LOOKAHEAD") == nullptr && far_async_shape(R, C, B, la);
+}
+
 size_t gptq_workspace_bytes(int64_t R, int64_t C, int block_size) {
     int64_t B = block_size <= 0 || block_size > C ? C : block_size;
     size_t err = (size_t)R * (size_t)B * sizeof(float);
     if (B == LA_B) err *= LA;  // super-block error buffer [R, LA * B]
+    if (B == LA_B) err *= 2;   // ... doubled for the far update next to the loop (far_async_shape)
     size_t blk = B > SEG ? (size_t)R * (size_t)B * sizeof(float) : 0;
     return err + blk + 256 + 256;  // + the panel word of the scale searches (quant_utils.py:250-252)
 }
@@ -359,6 +409,7 @@ static int column_loop(float* W, const float* U, int64_t R, int64_t C, int q_typ
     if (R <= 0 || C <= 0 || C % 256) GQ_FAIL(GQ_E_BAD_SHAPE, "gq_gptq_quantize: R=%ld C=%ld (C %% 256 != 0)", (long)R, (long)C);
     if (!W || !U || !qweight || !d || !s || !dmin || !m) GQ_FAIL(GQ_E_NULL, "gq_gptq_quantize: null pointer");
     const int64_t B = block_size <= 0 || block_size > C ? C : block_size;  // gptq.py:54
+    int rc;
     if (B % SB) GQ_FAIL(GQ_E_UNSUPPORTED, "gq_gptq_quantize: block_size %ld is not a multiple of 16", (long)B);
     if (q_type == GQ_Q3_K && perm) GQ_FAIL(GQ_E_UNSUPPORTED, "gq_gptq_quantize_perm: Q3_K forces act_order off (gptq.py:204-206)");
     if (q_type == GQ_Q3_K) static_groups = 0;  // gptq.py:204-206
@@ -381,15 +432,20 @@ static int column_loop(float* W, const float* U, int64_t R, int64_t C, int q_typ
     const bool lookahead = (B == LA_B) && getenv("GQ_NO_LOOKAHEAD") == nullptr &&
                            (!uni || uni->group <= 0 || (la * B) % uni->group == 0);
     const int64_t ldE = lookahead ? (int64_t)LA * B : B;
-    float* Err = reinterpret_cast<float*>(((uintptr_t)ws + 255) & ~(uintptr_t)255);
-    float* Wblk = Err + (size_t)R * B * (lookahead ? LA : 1);
+    float* Err0 = reinterpret_cast<float*>(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+    float* Wblk = Err0 + (size_t)R * B * (B == LA_B ? 2 * LA : 1);
+    const bool far_async = lookahead && far_async_shape(R, C, B, la);
+    const int far_wgs = getenv("GQ_FAR_WGS") ? atoi(getenv("GQ_FAR_WGS")) : 192;
+    hipStream_t helper = nullptr;
+    hipEvent_t ev_small_prev = nullptr, ev_bulk[2] = {nullptr, nullptr}, ev_last = nullptr;
+    if (far_async && (rc = far_helper_stream(&helper))) return rc;
+    int ev_i = 0;
     // one device word shared by all scale-search launches of this call (each leaves it at zero)
     unsigned* panel = reinterpret_cast<unsigned*>(
         (reinterpret_cast<uintptr_t>(Wblk + ((B > SEG) ? (size_t)R * B : 0)) + 255) & ~(uintptr_t)255);
     if (ti.k_search && static_groups != 2) GQ_HIP(hipMemsetAsync(panel, 0, 8, st));
     const int64_t ng = C / ti.group, nsg = C / 256;
     const int gps = uni ? 1 : 256 / ti.group;
-    int rc;
     auto uniform_params = [&](int64_t col, int G, int64_t g) {
         hipLaunchKernelGGL(uniform_params_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, W + col, R, C, G,
                            (float)ti.qmax, uni->sym, uni->scale + g, uni->zero + g, ng);
@@ -422,6 +478,11 @@ static int column_loop(float* W, const float* U, int64_t R, int64_t C, int q_typ
         const bool single = (c2 - c1) <= SEG && (c1 / 256 == (c2 - 1) / 256);
         const int64_t ncols = c2 - c1;
         const int64_t bi = c1 / B, sb = bi / la, pos = lookahead ? bi % la : 0;  // block, super-block, slot
+        float* Err = far_async ? Err0 + (sb & 1) * (size_t)R * ldE : Err0;
+        if (far_async && pos == 0 && ev_bulk[sb & 1]) {  // this half of the error buffer: the helper is done with it
+            GQ_HIP(hipStreamWaitEvent(st, ev_bulk[sb & 1], 0));
+            ev_bulk[sb & 1] = nullptr;
+        }
         if (uni && uni->group > 0) {  // fast_obq.py:168-171 for every group that starts inside this block
             ProfScope ps(PT_SCALE_SEARCH, st);
             for (int64_t g = (c1 + uni->group - 1) / uni->group; g * uni->group < c2; ++g) uniform_params(g * uni->group, uni->group, g);
@@ -493,12 +554,44 @@ static int column_loop(float* W, const float* U, int64_t R, int64_t C, int q_typ
             continue;
         }
         // end of the super-block: all its blocks at once, every later column
-        {
+        if (!far_async) {
             ProfScope ps(PT_TRAILING_FAR, st);
             if ((rc = launch_gemm32<false, 0, false, 0, LA_B>(W + S1, C, Err, ldE, U + S0 * C + S1, C, R, C - S1, S1 - S0, st)))
                 return rc;
+            continue;
+        }
+        {
+            const int64_t G = (int64_t)la * B, g1 = S1 + G < C ? S1 + G : C, g2 = g1 + G < C ? g1 + G : C;
+            hipEvent_t ready = nullptr, ev = nullptr;
+            if (g1 < C) {  // the helper may start on this super-block's errors
+                if ((rc = far_event(ev_i++, &ready))) return rc;
+                GQ_HIP(hipEventRecord(ready, st));
+            }
+            if (ev_small_prev) GQ_HIP(hipStreamWaitEvent(st, ev_small_prev, 0));  // F_{s-1}[s+1] is in
+            ev_small_prev = nullptr;
+            {
+                ProfScope ps(PT_TRAILING_FAR, st);
+                if ((rc = launch_gemm32_chain_full<LA_B>(W + S1, C, Err, ldE, U + S0 * C + S1, C, R, g1 - S1, S1 - S0, st)))
+                    return rc;
+            }
+            if (g1 < C) {
+                ProfScope ps(PT_TRAILING_FAR, helper);
+                GQ_HIP(hipStreamWaitEvent(helper, ready, 0));
+                if ((rc = launch_gemm32_chain_full<LA_B>(W + g1, C, Err, ldE, U + S0 * C + g1, C, R, g2 - g1, S1 - S0, helper, far_wgs)))
+                    return rc;
+                if ((rc = far_event(ev_i++, &ev))) return rc;
+                GQ_HIP(hipEventRecord(ev, helper));
+                ev_small_prev = ev;
+                if (g2 < C && (rc = launch_gemm32_chain_full<LA_B>(W + g2, C, Err, ldE, U + S0 * C + g2, C, R, C - g2, S1 - S0, helper, far_wgs)))
+                    return rc;
+                if ((rc = far_event(ev_i++, &ev))) return rc;
+                GQ_HIP(hipEventRecord(ev, helper));
+                ev_bulk[sb & 1] = ev;
+                ev_last = ev;
+            }
         }
     }
+    if (ev_last) GQ_HIP(hipStreamWaitEvent(st, ev_last, 0));  // the caller's stream sees the helper's last write
     return GQ_OK;
 }
 

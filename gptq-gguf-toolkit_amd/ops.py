@@ -259,6 +259,11 @@ def gptq_quantize(W: torch.Tensor, U: torch.Tensor, q_type: int, block_size=128,
     return q.view(t), d, s.view(t), dmin, m.view(t)
 
 
+def uses_helper_stream(R: int, C: int, block_size) -> bool:
+    """Will the column loop of an R x C matrix run its far updates on the library's helper stream (gq_gptq_uses_helper_stream)?"""
+    return bool(lib().gq_gptq_uses_helper_stream(int(R), int(C), int(block_size or 0)))
+
+
 def gptq_quantize_perm(W: torch.Tensor, U: torch.Tensor, q_type: int, perm: torch.Tensor, d, s, dmin, m, block_size=128,
                        ws: Optional[torch.Tensor] = None) -> torch.Tensor:
     """GPTQ.step body with act_order (gptq.py:208-216, 233-235).  W (fp32) and U are already permuted by `perm`

@@ -72,6 +72,10 @@ def gptq_quantize(W, U, q_type, block_size=128, static_groups=False, rmin=-1.0, 
     return torch.from_numpy(q), _f16(d), torch.from_numpy(s), _f16(dmin), torch.from_numpy(m)
 
 
+def uses_helper_stream(R, C, block_size):
+    return False
+
+
 def gptq_quantize_perm(W, U, q_type, perm, d, s, dmin, m, block_size=128, ws=None):
     calls["gptq_quantize"] += 1
     Wd, q = O.gptq_step_perm(W.numpy(), U.numpy(), q_type, perm.numpy(), _bits(d), s.numpy(), _bits(dmin), m.numpy(), block_size)

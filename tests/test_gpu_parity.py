@@ -171,6 +171,58 @@ def test_gptq_lookahead_equals_per_block_updates(ops, R):
         assert torch.equal(a.view(torch.uint8), b.view(torch.uint8))
 
 
+def test_far_update_next_to_the_loop_changes_nothing(ops):
+    """Many super-blocks, few rows: the far update of a super-block is cut by 1024-column groups -- the next group on
+    the caller's stream, the rest on the library's helper stream as persistent launches (gq_gptq.hip) -- and runs next
+    to the column loop.  Per element the same subtractions in the same order: bit-identical to the one-stream
+    schedule (GQ_FAR_SYNC=1) and to gptq.py:270 block by block (GQ_NO_LOOKAHEAD=1); C = 9472 = 9.25 super-blocks.
+    Two such calls enqueued back to back on two streams share the helper stream and must not disturb each other."""
+    torch.manual_seed(9)
+    R, C = 384, 9472
+    assert ops.uses_helper_stream(R, C, 128) and not ops.uses_helper_stream(R, 4096, 128)
+    W0 = (torch.randn(R, C, device="cuda") * 0.02).half().float()
+    X = (torch.randn(C + 512, C, device="cuda") * torch.exp(torch.randn(C, device="cuda") * 0.5)).half()
+    H = torch.zeros(C, C, device="cuda")
+    ops.h_accumulate(H, X, 0.0, 2.0 / 4)
+    del X
+    Wp = W0.clone()
+    U, flag = ops.h_prepare(H, Wp, 0.01)
+    assert int(flag.item()) == 0
+    outs = []
+    for env in ({}, {"GQ_FAR_WGS": "24"}, {"GQ_FAR_SYNC": "1"}, {"GQ_NO_LOOKAHEAD": "1"}):
+        os.environ.update(env)
+        try:
+            assert ops.uses_helper_stream(R, C, 128) == (not env or "GQ_FAR_WGS" in env)
+            W = Wp.clone()
+            outs.append((W,) + tuple(ops.gptq_quantize(W, U, 12, 128)))
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+    torch.cuda.synchronize()
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert torch.equal(a.view(torch.uint8), b.view(torch.uint8))
+    # two chains at once
+    Wb = (Wp * 1.5).contiguous()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s1):
+        Wa = Wp.clone()
+        ra = ops.gptq_quantize(Wa, U, 12, 128)
+    with torch.cuda.stream(s2):
+        Wc = Wb.clone()
+        rb = ops.gptq_quantize(Wc, U, 14, 128)
+    torch.cuda.synchronize()
+    os.environ["GQ_FAR_SYNC"] = "1"
+    try:
+        Wd = Wb.clone()
+        rd = ops.gptq_quantize(Wd, U, 14, 128)
+    finally:
+        os.environ.pop("GQ_FAR_SYNC", None)
+    assert torch.equal(Wa, outs[0][0]) and all(torch.equal(a, b) for a, b in zip(ra, outs[0][1:]))
+    assert torch.equal(Wc, Wd) and all(torch.equal(a, b) for a, b in zip(rb, rd))
+
+
 def test_gptq_bad_args(ops):
     from gptq_gguf_toolkit_amd import GQError
     W = torch.zeros(64, 300, device="cuda")
