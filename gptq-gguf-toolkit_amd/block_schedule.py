@@ -328,7 +328,16 @@ class BlockSchedule:
                     h._marks.append(len(h._segs))
             side[0].wait_event(entry)
             with torch.cuda.stream(side[0]):
-                held = self._fold_postponed()
+                # fewer resident SYRK workgroups than CUs: the widest chain's kernels always find free ones
+                prev = os.environ.get("GQ_SYRK_WGS")
+                os.environ["GQ_SYRK_WGS"] = os.environ.get("GQ_DEFER_WGS", "192")
+                try:
+                    held = self._fold_postponed()
+                finally:
+                    if prev is None:
+                        os.environ.pop("GQ_SYRK_WGS", None)
+                    else:
+                        os.environ["GQ_SYRK_WGS"] = prev
                 folded = torch.cuda.Event()
                 folded.record(side[0])
             for h in late:

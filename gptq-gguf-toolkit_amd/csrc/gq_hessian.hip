@@ -1159,7 +1159,11 @@ static int syrk16_launch(int kind, const int* idx, int m, float* const* H, const
     const bool bf = x_dtype == GQ_BF16;
     if (kind == 2) {
         // one tile per workgroup, or (grp.bar) one workgroup per CU walking its XCD's list in rounds
-        const dim3 grid((unsigned)(grp.bar ? 256 : 8 * grp.per_xcd)), blk(512);
+        // (GQ_SYRK_WGS, read per call: fewer resident workgroups for a fold that runs NEXT TO a latency-bound chain --
+        // the block schedule's postponed folds -- so that the chain's kernels always find free CUs)
+        int wgs = 256;
+        if (const char* e = getenv("GQ_SYRK_WGS")) wgs = (atoi(e) >= 8 && atoi(e) <= 256) ? (atoi(e) & ~7) : 256;
+        const dim3 grid((unsigned)(grp.bar ? wgs : 8 * grp.per_xcd)), blk(512);
         if (bf) hipLaunchKernelGGL(syrk16_256n_kernel<true>, grid, blk, S_LDS_BYTES, st, grp);
         else hipLaunchKernelGGL(syrk16_256n_kernel<false>, grid, blk, S_LDS_BYTES, st, grp);
         if (n_reduce > 0) {
