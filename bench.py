@@ -198,6 +198,10 @@ def trailing_update_legs(wl, W16, X, in_region):
     with the U of a real gq_h_prepare on that Linear's Hessian:
       far_alone     the chained far updates (one per 1024-column super-block), alone on the GPU
       whole_alone   near (rest-of-super-block after every 128-column block) + far launches, alone on the GPU
+                    (both with GQ_FAR_SYNC=1: every GEMM has the chip to itself -- the kernels' own efficiency)
+      loop_ms       the Linear's whole column loop, alone: one stream, and as the product runs it (far updates cut
+                    by column groups and moved next to the loop on the library's helper stream, persistent launches
+                    with 192 workgroups: each far GEMM is slower, the loop as a whole shorter)
       far_in_region the far launches as they ran INSIDE the timed region, next to the other chains
     Algorithmic flops: far = sum over super-blocks 2 R (S1-S0)(C-S1); near = sum over blocks 2 R 128 (S1-c2)."""
     try:
@@ -213,18 +217,40 @@ def trailing_update_legs(wl, W16, X, in_region):
         B, sb = 128, 1024
         far = sum(2.0 * R * (min(s0 + sb, C) - s0) * (C - min(s0 + sb, C)) for s0 in range(0, C, sb))
         near = sum(2.0 * R * B * (min((c1 // sb + 1) * sb, C) - (c1 + B)) for c1 in range(0, C, B))
-        best = {}
-        for it in range(2):
-            Wf = W16[name].float()
-            torch.cuda.synchronize()
-            _cabi.prof_enable(["trailing_far_gemm32", "trailing_gemm32"])
-            ops.gptq_quantize(Wf, U, int(q_of(wl, name)), B)
-            torch.cuda.synchronize()
-            got = _cabi.prof_collect(busy=True)
-            _cabi.prof_enable([])
-            for k, v in got.items():
-                if k not in best or v[0] < best[k][0]:
-                    best[k] = v
+        best, loop_ms = {}, {}
+        had = os.environ.get("GQ_FAR_SYNC")
+        try:
+            for mode in ("one_stream", "as_run"):
+                if mode == "one_stream":
+                    os.environ["GQ_FAR_SYNC"] = "1"
+                elif had is None:
+                    os.environ.pop("GQ_FAR_SYNC", None)
+                for it in range(3):  # un-profiled wall time of the whole loop
+                    Wf = W16[name].float()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    ops.gptq_quantize(Wf, U, int(q_of(wl, name)), B)
+                    torch.cuda.synchronize()
+                    dt = (time.perf_counter() - t0) * 1e3
+                    loop_ms[mode] = min(loop_ms.get(mode, dt), dt)
+                if mode != "one_stream":
+                    continue
+                for it in range(2):
+                    Wf = W16[name].float()
+                    torch.cuda.synchronize()
+                    _cabi.prof_enable(["trailing_far_gemm32", "trailing_gemm32"])
+                    ops.gptq_quantize(Wf, U, int(q_of(wl, name)), B)
+                    torch.cuda.synchronize()
+                    got = _cabi.prof_collect(busy=True)
+                    _cabi.prof_enable([])
+                    for k, v in got.items():
+                        if k not in best or v[0] < best[k][0]:
+                            best[k] = v
+        finally:
+            if had is None:
+                os.environ.pop("GQ_FAR_SYNC", None)
+            else:
+                os.environ["GQ_FAR_SYNC"] = had
         fms, fn, _ = best.get("trailing_far_gemm32", (0.0, 0, 0.0))
         nms, nn_, _ = best.get("trailing_gemm32", (0.0, 0, 0.0))
         out = {"bound": "mfma", "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "linear": f"{name} {R}x{C}",
@@ -238,6 +264,8 @@ def trailing_update_legs(wl, W16, X, in_region):
             a = (far + near) / ((fms + nms) * 1e-3) / 1e12
             out["whole_alone"] = {"achieved": round(a, 2), "frac": round(a / PEAK_F32_MFMA_TFLOPS, 4),
                                   "launches": fn + nn_, "ms": round(fms + nms, 3), "near_ms": round(nms, 3)}
+        out["loop_ms"] = {"one_stream": round(loop_ms["one_stream"], 2), "as_run": round(loop_ms["as_run"], 2),
+                          "far_updates_on_helper_stream": bool(ops.uses_helper_stream(R, C, B))}
         if in_region and in_region[1]:
             # launches of EVERY Linear of the block ran under this tag in the region: price them all
             far_all = sum(sum(2.0 * r * (min(s0 + sb, c) - s0) * (c - min(s0 + sb, c)) for s0 in range(0, c, sb))

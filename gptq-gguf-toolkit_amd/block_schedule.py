@@ -9,11 +9,12 @@ schedules kernels:
                tensor (q/k/v, gate/up) are detected and share one Hessian.  Activations are buffered by the
                handles; `sample_done()` (after every calibration sample) folds the buffers of ALL distinct
                inputs into their Hessians with grouped SYRK launches once they hold `flush_tokens` tokens:
-               the narrow inputs in one grid, then the widest input alone on the chip.  [N=1] Only the WIDEST
-               input is folded as the samples arrive; the narrow ones (zero-copy references, a few GB) are
-               kept and folded -- in the very same portions -- at quantize() time on a side stream, UNDER the
-               widest input's factorisation and column loop, which are chains of small dependent launches
-               that leave the matrix cores idle.
+               the narrow inputs in one grid, then the widest input alone on the chip.  [N=1, opt-in:
+               GQ_DEFER_NARROW=1] Only the WIDEST input is folded as the samples arrive; the narrow ones
+               (zero-copy references, a few GB) are kept and folded -- in the very same portions -- at
+               quantize() time on a side stream, UNDER the widest input's factorisation and column loop,
+               which are chains of small dependent launches that leave the matrix cores idle (-0.7 % per
+               step for 6 GB of kept activations: off by default).
   quantize()   phase 0  the remaining tokens are folded in (the postponed narrow inputs on a side stream);
                         [N>1] ONE all-reduce per distinct Hessian, widest first (gptq.py:131-132 does one per
                         handle);
@@ -104,7 +105,7 @@ class BlockSchedule:
         self.stats = {"syrk_launches": 0, "allreduce_bytes": 0, "reused_U": 0, "own_U": 0, "refactorised": 0}
         self.owners: Dict[str, Any] = {}  # name -> owner rank or "rows/<world>" of the last quantize()
         # postponed folds of the narrow inputs (single rank): on / off, and the bytes of activations it may keep
-        self.defer_narrow = os.environ.get("GQ_DEFER_NARROW", "1") == "1"
+        self.defer_narrow = os.environ.get("GQ_DEFER_NARROW", "0") == "1"
         self.defer_bytes = int(float(os.environ.get("GQ_DEFER_GB", 48)) * 2 ** 30)
 
     # ------------------------------------------------------------------ hook side

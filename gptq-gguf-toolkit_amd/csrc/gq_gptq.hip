@@ -575,8 +575,8 @@ static int column_loop(float* W, const float* U, int64_t R, int64_t C, int q_typ
                     return rc;
             }
             if (g1 < C) {
-                ProfScope ps(PT_TRAILING_FAR, helper);
                 GQ_HIP(hipStreamWaitEvent(helper, ready, 0));
+                ProfScope ps(PT_TRAILING_FAR, helper);
                 if ((rc = launch_gemm32_chain_full<LA_B>(W + g1, C, Err, ldE, U + S0 * C + g1, C, R, g2 - g1, S1 - S0, helper, far_wgs)))
                     return rc;
                 if ((rc = far_event(ev_i++, &ev))) return rc;
