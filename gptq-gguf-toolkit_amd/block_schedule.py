@@ -375,60 +375,67 @@ class BlockSchedule:
         # the costliest chain stays on the caller's stream (it ends last anyway), the others get side streams
         on_main = 1 if os.environ.get("GQ_CHAIN_MAIN", "1") == "1" else 0
         # a chain whose column loop keeps its far updates on the library's helper stream brings a hardware queue
-        # of its own: one lane fewer here (five queues cost more than the overlap gains)
-        lent = 1 if on_gpu and self.n_streams > 2 and any(
+        # of its own: one lane fewer here (five queues cost more than the overlap gains).  Only when
+        # every chain still gets a lane of its own or nearly so (a dense block: 4 chains); a Mixtral block's 20 chains
+        # need all the lanes, and the helper stays off
+        lent = 1 if on_gpu and 2 < self.n_streams and len(order) <= self.n_streams and any(
             _ops.uses_helper_stream(h.d_row, h.d_col, h.block_size) for h in handles.values()
             if h.owner_rank == rank and not h._row_split_active()) else 0
-        streams = [None] * on_main + _chain_streams(dev, min(self.n_streams - lent, len(order)) - on_main)
-        results: Dict[str, tuple] = {}
-        deq: Dict[str, torch.Tensor] = {}
-        lanes = []
-        trace = os.environ.get("GQ_SCHED_TRACE")
-        t_host = time.perf_counter()
-        # lanes: longest-processing-time-first over all lanes; the costliest chain comes first and lands on lane 0 = the
-        # caller's stream (a dense block: one chain per lane; a Mixtral block: 20 chains over 4 lanes)
-        cost = [sum(float(handles[n].d_row) * handles[n].d_col ** 2 + float(handles[n].d_col) ** 3 / 3 for n in names)
-                for names in order]
-        lane_of, load = [0] * len(order), [0.0] * max(len(streams), 1)
-        for k in range(len(order)):
-            lane_of[k] = min(range(len(streams)), key=lambda i: (load[i], i)) if streams else 0
-            load[lane_of[k]] += cost[k]
-        for k, names in enumerate(order):
-            if trace:
-                print(f"  [sched] +{1e3 * (time.perf_counter() - t_host):7.2f} ms: enqueue chain {k} {names} on lane {lane_of[k]}",
-                      file=sys.stderr)
-            lane = _Lane(streams[lane_of[k]] if streams else None, main)
-            lead = handles[names[0]].shared_H_with or handles[names[0]]
-            lane.wait(ready.get(id(lead), start))
-            born = []
-            with lane.run():
-                # the leader first: it factorises, the followers reuse its U
-                for n in sorted(names, key=lambda n: handles[n].shared_H_with is not None):
-                    h = handles[n]
-                    if self.verbose:
-                        print(f"[rank {rank}] Quantizing {n} with {qtypes[n].name}.")
-                    h.make_working_copy()
-                    # follower with the same zero columns as its leader: reuse (flag kept for verify());
-                    # different: own factorisation; unknown (first fed after the first sample): checked below
-                    res = h.compute(qtypes[n], defer_check=True, own_U=own.get(n, False))
-                    if n in own and h._pending_mismatch is not None:
-                        BlockSchedule.unverified.append(h._pending_mismatch)
-                        h._pending_mismatch = None
-                        self.stats["reused_U"] += 1
-                    elif own.get(n, False):
-                        self.stats["refactorised"] += 1
-                    results[n] = res
-                    born += list(res)
-                    if world == 1 and writeback:
-                        deq[n] = dequantize_linear_weight(qtypes[n], *res, out_dtype=h.layer.weight.data.dtype)
-                        born.append(deq[n])
-                    if extra is not None:
-                        out = extra(n, h, res)
-                        born += [t for t in (out if isinstance(out, (tuple, list)) else (out,))
-                                 if torch.is_tensor(t)]
-            lanes.append((lane, born))
-        for lane, born in lanes:
-            lane.join(born)
+        helper_was = _ops.far_helper_enable(bool(lent)) if on_gpu else None
+        try:
+            streams = [None] * on_main + _chain_streams(dev, min(self.n_streams - lent, len(order)) - on_main)
+            results: Dict[str, tuple] = {}
+            deq: Dict[str, torch.Tensor] = {}
+            lanes = []
+            trace = os.environ.get("GQ_SCHED_TRACE")
+            t_host = time.perf_counter()
+            # lanes: longest-processing-time-first over all lanes; the costliest chain comes first and lands on lane 0 = the
+            # caller's stream (a dense block: one chain per lane; a Mixtral block: 20 chains over 4 lanes)
+            cost = [sum(float(handles[n].d_row) * handles[n].d_col ** 2 + float(handles[n].d_col) ** 3 / 3 for n in names)
+                    for names in order]
+            lane_of, load = [0] * len(order), [0.0] * max(len(streams), 1)
+            for k in range(len(order)):
+                lane_of[k] = min(range(len(streams)), key=lambda i: (load[i], i)) if streams else 0
+                load[lane_of[k]] += cost[k]
+            for k, names in enumerate(order):
+                if trace:
+                    print(f"  [sched] +{1e3 * (time.perf_counter() - t_host):7.2f} ms: enqueue chain {k} {names} on lane {lane_of[k]}",
+                          file=sys.stderr)
+                lane = _Lane(streams[lane_of[k]] if streams else None, main)
+                lead = handles[names[0]].shared_H_with or handles[names[0]]
+                lane.wait(ready.get(id(lead), start))
+                born = []
+                with lane.run():
+                    # the leader first: it factorises, the followers reuse its U
+                    for n in sorted(names, key=lambda n: handles[n].shared_H_with is not None):
+                        h = handles[n]
+                        if self.verbose:
+                            print(f"[rank {rank}] Quantizing {n} with {qtypes[n].name}.")
+                        h.make_working_copy()
+                        # follower with the same zero columns as its leader: reuse (flag kept for verify());
+                        # different: own factorisation; unknown (first fed after the first sample): checked below
+                        res = h.compute(qtypes[n], defer_check=True, own_U=own.get(n, False))
+                        if n in own and h._pending_mismatch is not None:
+                            BlockSchedule.unverified.append(h._pending_mismatch)
+                            h._pending_mismatch = None
+                            self.stats["reused_U"] += 1
+                        elif own.get(n, False):
+                            self.stats["refactorised"] += 1
+                        results[n] = res
+                        born += list(res)
+                        if world == 1 and writeback:
+                            deq[n] = dequantize_linear_weight(qtypes[n], *res, out_dtype=h.layer.weight.data.dtype)
+                            born.append(deq[n])
+                        if extra is not None:
+                            out = extra(n, h, res)
+                            born += [t for t in (out if isinstance(out, (tuple, list)) else (out,))
+                                     if torch.is_tensor(t)]
+                lanes.append((lane, born))
+            for lane, born in lanes:
+                lane.join(born)
+        finally:
+            if helper_was is not None:
+                _ops.far_helper_enable(helper_was)
         if trace:
             print(f"  [sched] +{1e3 * (time.perf_counter() - t_host):7.2f} ms: all chains enqueued", file=sys.stderr)
 

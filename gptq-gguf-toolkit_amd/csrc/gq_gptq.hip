@@ -332,27 +332,56 @@ constexpr int LA_B = 128;  // only this block size takes the look-ahead path (th
 // bounded number of workgroups, so the loop's kernels always find free CUs instead of queueing behind 56-us GEMM
 // tiles.  Every element of W still sees ((w - E_0 U_0) - E_1 U_1) - ... in the same order: results are unchanged.
 // The error buffer is doubled (the helper may still read super-block s's errors while the loop fills s+1's).
+static std::atomic<int> g_far_enabled{1};
+int far_helper_enable(int on) { return g_far_enabled.exchange(on ? 1 : 0); }
 static bool far_async_shape(int64_t R, int64_t C, int64_t B, int la) {
+    if (!g_far_enabled.load()) return false;
     // read per call (three getenv per Linear): tests and A/B runs flip them inside one process
     const bool off = getenv("GQ_FAR_SYNC") != nullptr;
     const int64_t max_rows = getenv("GQ_FAR_ASYNC_MAX_ROWS") ? atol(getenv("GQ_FAR_ASYNC_MAX_ROWS")) : 8192;
     const int64_t min_sb = getenv("GQ_FAR_ASYNC_MIN_SB") ? atol(getenv("GQ_FAR_ASYNC_MIN_SB")) : 8;
     return !off && B == LA_B && R % 128 == 0 && C % 128 == 0 && R <= max_rows && C >= min_sb * (int64_t)la * B;
 }
+// One helper stream per device, held by ONE call at a time: from the start of its enqueue until its last helper launch
+// has finished on the device.  A call that finds it taken runs the one-stream schedule (same results) -- several
+// chains funnelled through one in-order helper stream would wait for each other's GEMMs (measured: 103 -> 112 ms
+// per block step with all seven Linears on it).
 struct FarHelper {
     hipStream_t st = nullptr;
+    hipEvent_t done = nullptr;  // recorded behind the holder's last helper launch
+    bool enqueueing = false, recorded = false;
 };
-static int far_helper_stream(hipStream_t* out) {
-    static std::mutex mu;
-    static FarHelper per_dev[64];
+static std::mutex g_far_mu;
+static FarHelper g_far[64];
+static int far_helper_acquire(FarHelper** out) {
+    *out = nullptr;
     int dev = 0;
     GQ_HIP(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> lk(mu);
-    FarHelper& h = per_dev[dev & 63];
-    if (!h.st) GQ_HIP(hipStreamCreateWithFlags(&h.st, hipStreamNonBlocking));
-    *out = h.st;
+    std::lock_guard<std::mutex> lk(g_far_mu);
+    FarHelper& h = g_far[dev & 63];
+    if (!h.st) {
+        GQ_HIP(hipStreamCreateWithFlags(&h.st, hipStreamNonBlocking));
+        GQ_HIP(hipEventCreateWithFlags(&h.done, hipEventDisableTiming));
+    }
+    if (h.enqueueing) return GQ_OK;
+    if (h.recorded && hipEventQuery(h.done) != hipSuccess) {
+        (void)hipGetLastError();  // hipErrorNotReady is not an error
+        return GQ_OK;
+    }
+    h.enqueueing = true;
+    *out = &h;
     return GQ_OK;
 }
+static void far_helper_release(FarHelper* h) {
+    if (!h) return;
+    std::lock_guard<std::mutex> lk(g_far_mu);
+    h->recorded = hipEventRecord(h->done, h->st) == hipSuccess;
+    h->enqueueing = false;
+}
+struct FarHold {  // releases on every return path of the column loop
+    FarHelper* h = nullptr;
+    ~FarHold() { far_helper_release(h); }
+};
 // re-recordable events of the calling host thread (a wait captures the record that precedes it)
 static int far_event(int i, hipEvent_t* out) {
     thread_local hipEvent_t pool[96] = {};
@@ -434,11 +463,16 @@ static int column_loop(float* W, const float* U, int64_t R, int64_t C, int q_typ
     const int64_t ldE = lookahead ? (int64_t)LA * B : B;
     float* Err0 = reinterpret_cast<float*>(((uintptr_t)ws + 255) & ~(uintptr_t)255);
     float* Wblk = Err0 + (size_t)R * B * (B == LA_B ? 2 * LA : 1);
-    const bool far_async = lookahead && far_async_shape(R, C, B, la);
+    bool far_async = lookahead && far_async_shape(R, C, B, la);
     const int far_wgs = getenv("GQ_FAR_WGS") ? atoi(getenv("GQ_FAR_WGS")) : 192;
+    FarHold hold;
     hipStream_t helper = nullptr;
     hipEvent_t ev_small_prev = nullptr, ev_bulk[2] = {nullptr, nullptr}, ev_last = nullptr;
-    if (far_async && (rc = far_helper_stream(&helper))) return rc;
+    if (far_async) {
+        if ((rc = far_helper_acquire(&hold.h))) return rc;
+        if (hold.h) helper = hold.h->st;
+        else far_async = false;  // taken by another call: the one-stream schedule
+    }
     int ev_i = 0;
     // one device word shared by all scale-search launches of this call (each leaves it at zero)
     unsigned* panel = reinterpret_cast<unsigned*>(

@@ -264,6 +264,11 @@ def uses_helper_stream(R: int, C: int, block_size) -> bool:
     return bool(lib().gq_gptq_uses_helper_stream(int(R), int(C), int(block_size or 0)))
 
 
+def far_helper_enable(on: bool) -> bool:
+    """Allow / forbid the library's helper stream for the column loops enqueued from now on; returns the previous setting."""
+    return bool(lib().gq_far_helper_enable(int(bool(on))))
+
+
 def gptq_quantize_perm(W: torch.Tensor, U: torch.Tensor, q_type: int, perm: torch.Tensor, d, s, dmin, m, block_size=128,
                        ws: Optional[torch.Tensor] = None) -> torch.Tensor:
     """GPTQ.step body with act_order (gptq.py:208-216, 233-235).  W (fp32) and U are already permuted by `perm`

@@ -162,13 +162,17 @@ int gq_gptq_quantize(float* W, const float* U, int64_t R, int64_t C, int q_type,
                      uint8_t* qweight, uint16_t* d, uint8_t* s, uint16_t* dmin, uint8_t* m,
                      void* ws, size_t ws_bytes, void* stream);
 
-/* 1 if gq_gptq_quantize / gq_gptq_quantize_perm / gq_obq_quantize on an R x C matrix will put the bulk of its far
+/* 1 if gq_gptq_quantize / gq_gptq_quantize_perm / gq_obq_quantize on an R x C matrix MAY put the bulk of its far
    trailing updates (gptq.py:270 beyond the current 1024-column super-block) on the library's own helper HIP stream,
    next to the column loop on the caller's stream (few rows, many super-blocks: the loop's kernels are latency-bound
-   and leave most of the chip idle).  All ordering is by events; the call still completes in stream order for the
+   and leave most of the chip idle); one call per device holds the helper at a time, a call that finds it taken runs
+   on the caller's stream alone (same results).  All ordering is by events; the call still completes in stream order for the
    caller.  A scheduler that runs several chains on streams of its own uses one stream fewer then: more than four
    hardware queues cost more than the overlap gains.  GQ_FAR_SYNC=1 switches the helper off. */
 int gq_gptq_uses_helper_stream(int64_t R, int64_t C, int block_size);
+/* Process-wide switch of that helper stream for the calls enqueued from now on (1 = allowed, the default); returns the
+   previous setting.  A scheduler with more chains than streams keeps all its streams and switches the helper off. */
+int gq_far_helper_enable(int on);
 
 /* GPTQ.step with act_order=True (gptq.py:208-216, 233-235, 272-276; implies static_groups, gptq.py:45-46;
    not for Q3_K, gptq.py:204-206).  The caller permutes: perm = argsort(diag(H), descending) (int32 [C], on the

@@ -76,6 +76,10 @@ def uses_helper_stream(R, C, block_size):
     return False
 
 
+def far_helper_enable(on):
+    return True
+
+
 def gptq_quantize_perm(W, U, q_type, perm, d, s, dmin, m, block_size=128, ws=None):
     calls["gptq_quantize"] += 1
     Wd, q = O.gptq_step_perm(W.numpy(), U.numpy(), q_type, perm.numpy(), _bits(d), s.numpy(), _bits(dmin), m.numpy(), block_size)

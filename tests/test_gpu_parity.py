@@ -176,7 +176,8 @@ def test_far_update_next_to_the_loop_changes_nothing(ops):
     the caller's stream, the rest on the library's helper stream as persistent launches (gq_gptq.hip) -- and runs next
     to the column loop.  Per element the same subtractions in the same order: bit-identical to the one-stream
     schedule (GQ_FAR_SYNC=1) and to gptq.py:270 block by block (GQ_NO_LOOKAHEAD=1); C = 9472 = 9.25 super-blocks.
-    Two such calls enqueued back to back on two streams share the helper stream and must not disturb each other."""
+    Of two such calls enqueued back to back on two streams only the first holds the helper (one holder per device at
+    a time; the other runs the one-stream schedule): neither disturbs the other."""
     torch.manual_seed(9)
     R, C = 384, 9472
     assert ops.uses_helper_stream(R, C, 128) and not ops.uses_helper_stream(R, 4096, 128)
