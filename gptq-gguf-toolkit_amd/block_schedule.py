@@ -390,7 +390,7 @@ class BlockSchedule:
             trace = os.environ.get("GQ_SCHED_TRACE")
             t_host = time.perf_counter()
             # lanes: longest-processing-time-first over all lanes; the costliest chain comes first and lands on lane 0 = the
-            # caller's stream (a dense block: one chain per lane; a Mixtral block: 20 chains over 4 lanes)
+            # caller's stream (a dense block: four chains over three lanes + the library's helper; a Mixtral block: 20 chains over 4 lanes)
             cost = [sum(float(handles[n].d_row) * handles[n].d_col ** 2 + float(handles[n].d_col) ** 3 / 3 for n in names)
                     for names in order]
             lane_of, load = [0] * len(order), [0.0] * max(len(streams), 1)
