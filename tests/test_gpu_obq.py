@@ -137,3 +137,29 @@ def test_fast_obq_not_positive_definite_raises(ops):
     h.update(x)
     with pytest.raises(torch.linalg.LinAlgError):
         h.quantize([4])
+
+
+def test_obq_quantize_random_small_shapes_vs_oracle(ops, oracle):
+    """A seeded sweep over ragged row counts, block sizes (incl. blocks wider than a segment and C itself), group sizes
+    (incl. groups wider than a block, and one grid per row) and bit widths: the whole matrix against the oracle."""
+    rng = np.random.default_rng(2026)
+    for case in range(24):
+        C = int(rng.choice([256, 512, 768, 1280]))
+        R = int(rng.choice([1, 7, 63, 64, 65, 130, 257]))
+        block = int(rng.choice([16, 48, 64, 128, 256, 512, 0]))
+        gs = int(rng.choice([g for g in (0, 16, 32, 64, 128, 256) if g == 0 or C % g == 0]))
+        sym, bits = bool(rng.integers(2)), int(rng.integers(1, 9))
+        X = rng.standard_normal((2 * C, C)).astype(np.float32) * np.exp(rng.standard_normal(C) * 0.5).astype(np.float32)
+        H = dev((2.0 / X.shape[0]) * (X.T @ X))
+        W = dev((rng.standard_normal((R, C)) * 0.05).astype(np.float32))
+        if case % 3 == 0:
+            W[:, int(rng.integers(C))] = 0.0
+        U, flag = ops.h_prepare(H, W, 0.01, obq_order=True)
+        assert int(flag.item()) == 0
+        W0, Un = W.cpu().numpy(), U.cpu().numpy()
+        q, sc, ze = ops.obq_quantize(W, U, bits, gs, sym, block)
+        Wd, q_ref, s_ref, z_ref = oracle.obq_step(W0, Un, bits, gs, sym, block)
+        tag = f"case {case}: R={R} C={C} block={block} group={gs} sym={sym} bits={bits}"
+        assert np.array_equal(q.cpu().numpy(), q_ref), tag
+        assert bits_eq(sc.cpu().numpy(), s_ref) and bits_eq(ze.cpu().numpy(), z_ref), tag
+        assert bits_eq(W.cpu().numpy(), Wd), tag
