@@ -611,12 +611,14 @@ __global__ __launch_bounds__(256) void diag_blk_kernel(float* __restrict__ A, in
         const int r = idx / (NB / 4), c = (idx % (NB / 4)) * 4;
         const float* sr = S + r * LDQ + c;
         const float* xr = X + r * LDQ + c;
-        if (c > r) continue;  // above the diagonal: A keeps its (unused) values, X was zeroed by gq_h_prepare
+        // the WHOLE block of X is written, zeros above the diagonal included: the k-range skips of the GEMMs end at tile
+        // boundaries and read them.  (Blocks of X above the block diagonal are never written and never read.)
+        *reinterpret_cast<float4*>(Xout + r * ldx + c) = make_float4(xr[0], xr[1], xr[2], xr[3]);
+        if (c > r) continue;  // above the diagonal A keeps its (unused) values
         if (c + 3 <= r) *reinterpret_cast<float4*>(A + r * lda + c) = make_float4(sr[0], sr[1], sr[2], sr[3]);
         else
             for (int u = 0; u < 4; ++u)
                 if (c + u <= r) A[r * lda + c + u] = sr[u];
-        *reinterpret_cast<float4*>(Xout + r * ldx + c) = make_float4(xr[0], xr[1], xr[2], xr[3]);
     }
 }
 
@@ -724,7 +726,9 @@ int h_prepare(float* H, float* W, int64_t R, int64_t C, float rel_damp, float* U
     GQ_LAUNCH_CHECK();
     hipLaunchKernelGGL(reverse_copy_kernel, dim3(4096), dim3(256), 0, st, A, H, n);
     GQ_LAUNCH_CHECK();
-    GQ_HIP(hipMemsetAsync(X, 0, (size_t)n * n * sizeof(float), st));
+    // X needs no clearing: every block that is read is written first (diagonal blocks whole, zeros included).  The
+    // test that pins this fills X with NaN patterns first (GQ_POISON_X=1) and expects the same U.
+    if (getenv("GQ_POISON_X")) GQ_HIP(hipMemsetAsync(X, 0xff, (size_t)n * n * sizeof(float), st));
     }
     static std::atomic<bool> attr_set{false};  // guards an idempotent call: a race sets the same value twice
     static const bool use_ref = getenv("GQ_DIAG_REF") != nullptr;  // A/B: the column-by-column kernel

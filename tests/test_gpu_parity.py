@@ -171,6 +171,28 @@ def test_gptq_lookahead_equals_per_block_updates(ops, R):
         assert torch.equal(a.view(torch.uint8), b.view(torch.uint8))
 
 
+def test_h_prepare_never_reads_unwritten_scratch(ops):
+    """gq_h_prepare does not clear its scratch: the inverse factor X is written block by block (diagonal blocks
+    whole, with their zeros) and the k-range skips of the GEMMs never leave the written blocks.  With X filled with
+    NaN patterns beforehand (GQ_POISON_X=1) the result must be the same, bit for bit, at a size that takes every
+    level of the recursion (fp32 and split-bf16 GEMMs, 64- and 128-tiles)."""
+    torch.manual_seed(4)
+    C = 4096 + 896
+    X = (torch.randn(2 * C, C, device="cuda") * torch.exp(torch.randn(C, device="cuda") * 0.5)).half()
+    H = torch.zeros(C, C, device="cuda")
+    ops.h_accumulate(H, X, 0.0, 2.0 / 4)
+    del X
+    W = torch.randn(64, C, device="cuda")
+    U0, f0 = ops.h_prepare(H.clone(), W.clone(), 0.01)
+    os.environ["GQ_POISON_X"] = "1"
+    try:
+        U1, f1 = ops.h_prepare(H.clone(), W.clone(), 0.01)
+    finally:
+        os.environ.pop("GQ_POISON_X", None)
+    assert int(f0.item()) == 0 and int(f1.item()) == 0
+    assert bool(torch.isfinite(U1).all()) and torch.equal(U0, U1)
+
+
 def test_far_update_next_to_the_loop_changes_nothing(ops):
     """Many super-blocks, few rows: the far update of a super-block is cut by 1024-column groups -- the next group on
     the caller's stream, the rest on the library's helper stream as persistent launches (gq_gptq.hip) -- and runs next
