@@ -140,11 +140,13 @@ int launch_rtn_elementwise(const void* W, int w_dtype, const uint16_t* d, const 
 }
 
 // ---------------------------------------------------------------- bit-packers
-// reference packing_utils.py:8-326.  A workgroup packs PB = 8 consecutive
-// 256-value blocks: the 8*256 input bytes are staged in LDS with coalesced 16-byte
-// loads, every thread assembles output bytes from LDS, and the 8*type_size output
-// bytes (a multiple of 16 for every type) leave as coalesced 16-byte stores.
-constexpr int PB = 8;
+// reference packing_utils.py:8-326.  A workgroup packs PB = 32 consecutive
+// 256-value blocks per turn: the 32*256 input bytes are staged in LDS with coalesced
+// 16-byte loads (two per thread in flight), every thread assembles FOUR consecutive
+// output bytes from LDS and stores them as one dword, and the 32*type_size output
+// bytes (a multiple of 16 for every type) leave as coalesced 16-byte stores.  (r01: 8
+// blocks and byte-wide LDS stores per turn kept too few bytes in flight, 2.0-2.3 TB/s.)
+constexpr int PB = 32;
 
 __device__ __forceinline__ uint8_t pack_scale_min_byte(const uint8_t* sc, const uint8_t* mn, int j) {
     // packing_utils.py:8-30, byte j of the 12
@@ -231,6 +233,85 @@ __device__ __forceinline__ uint8_t pack_byte(const uint8_t* q, const uint8_t* sb
     }
 }
 
+// ---- four output bytes at a time ----
+// Every field of every block layout starts at a multiple of 4 bytes (only the trailing fp16 `d` of Q3_K / Q6_K is a
+// 2-byte tail), and the strides the layouts combine (32, 64, 96, 128 input bytes) are multiples of 4 as well: output
+// dword w of a block is a handful of LDS dword reads and byte-parallel mask / shift / or operations.
+__device__ __forceinline__ uint32_t ld4(const uint8_t* p) { return *reinterpret_cast<const uint32_t*>(p); }
+// four independent byte additions (no carry across bytes)
+__device__ __forceinline__ uint32_t add4(uint32_t x, uint32_t c) {
+    return ((x & 0x7f7f7f7fu) + (c & 0x7f7f7f7fu)) ^ ((x ^ c) & 0x80808080u);
+}
+template <int QT>
+__device__ __forceinline__ uint32_t pack_dword(const uint8_t* q, const uint8_t* sb, const uint8_t* mb, uint16_t d,
+                                               uint16_t dmin, int w) {
+    const int o = 4 * w;
+    auto hdr = [&](int j0) {  // four bytes of the 12-byte scale/min field of Q4_K / Q5_K
+        return (uint32_t)pack_scale_min_byte(sb, mb, j0) | ((uint32_t)pack_scale_min_byte(sb, mb, j0 + 1) << 8) |
+               ((uint32_t)pack_scale_min_byte(sb, mb, j0 + 2) << 16) | ((uint32_t)pack_scale_min_byte(sb, mb, j0 + 3) << 24);
+    };
+    if constexpr (QT == GQ_Q2_K) {  // scales[16] qs[64] d dmin
+        if (o < 16) return (ld4(sb + o) & 0x0f0f0f0fu) | ((ld4(mb + o) & 0x0f0f0f0fu) << 4);
+        if (o < 80) {
+            const int t = o - 16, ch = t >> 5, l = t & 31;
+            const uint8_t* c = q + ch * 128 + l;
+            return ld4(c) | (ld4(c + 32) << 2) | (ld4(c + 64) << 4) | (ld4(c + 96) << 6);  // values 0..3: no masks
+        }
+        return (uint32_t)d | ((uint32_t)dmin << 16);
+    } else if constexpr (QT == GQ_Q3_K) {  // hmask[32] qs[64] scales[12] | d
+        if (o < 32) {
+            uint32_t h = 0;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) h |= ((add4(ld4(q + b * 32 + o), 0x04040404u) >> 2) & 0x01010101u) << b;  // (q+4) > 3
+            return h;
+        }
+        if (o < 96) {
+            const int t = o - 32, ch = t >> 5, l = t & 31;
+            const uint8_t* c = q + ch * 128 + l;
+            uint32_t r = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) r |= (add4(ld4(c + 32 * k), 0x04040404u) & 0x03030303u) << (2 * k);  // u > 3 ? u - 4 : u
+            return r;
+        }
+        uint32_t r = 0;  // the 12 scale bytes: byte-wise (o = 96, 100, 104)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r |= (uint32_t)pack_byte<QT>(q, sb, mb, d, dmin, o + k) << (8 * k);
+        return r;
+    } else if constexpr (QT == GQ_Q4_K) {  // d dmin scales[12] qs[128]
+        if (o == 0) return (uint32_t)d | ((uint32_t)dmin << 16);
+        if (o < 16) return hdr(o - 4);
+        const int t = o - 16, base = (t >> 5) * 64, l = t & 31;
+        return ld4(q + base + l) | (ld4(q + base + 32 + l) << 4);  // values 0..15
+    } else if constexpr (QT == GQ_Q5_K) {  // d dmin scales[12] qh[32] ql[128]
+        if (o == 0) return (uint32_t)d | ((uint32_t)dmin << 16);
+        if (o < 16) return hdr(o - 4);
+        if (o < 48) {
+            const int j = o - 16;
+            uint32_t h = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                h |= ((ld4(q + 64 * k + j) >> 4) & 0x01010101u) << (2 * k);           // values 0..31: > 15 is bit 4
+                h |= ((ld4(q + 64 * k + 32 + j) >> 4) & 0x01010101u) << (2 * k + 1);
+            }
+            return h;
+        }
+        const int t = o - 48, base = (t >> 5) * 64, j = t & 31;
+        return (ld4(q + base + j) & 0x0f0f0f0fu) | ((ld4(q + base + 32 + j) & 0x0f0f0f0fu) << 4);
+    } else {  // Q6_K  ql[128] qh[64] scales[16] | d ;  v = q + 32 in 0..63
+        auto v4 = [&](int idx) { return add4(ld4(q + idx), 0x20202020u); };
+        if (o < 128) {
+            const int ch = o >> 6, t = o & 63, l = t & 31, hi = t >> 5, b = ch * 128 + l + 32 * hi;
+            return (v4(b) & 0x0f0f0f0fu) | ((v4(b + 64) & 0x0f0f0f0fu) << 4);
+        }
+        if (o < 192) {
+            const int t = o - 128, ch = t >> 5, l = t & 31, b = ch * 128 + l;
+            return ((v4(b) >> 4) & 0x03030303u) | (((v4(b + 32) >> 4) & 0x03030303u) << 2) |
+                   (((v4(b + 64) >> 4) & 0x03030303u) << 4) | (((v4(b + 96) >> 4) & 0x03030303u) << 6);
+        }
+        return ld4(sb + (o - 192));
+    }
+}
+
 template <int QT, int TS, int NG>
 __global__ __launch_bounds__(256) void pack_kernel(const uint8_t* __restrict__ qw, const uint16_t* __restrict__ d,
                                                    const uint8_t* __restrict__ s, const uint16_t* __restrict__ dmin,
@@ -238,25 +319,45 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t* __restrict__ q
                                                    uint8_t* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) uint8_t sq[PB * 256];
     __shared__ __attribute__((aligned(16))) uint8_t so[PB * TS];
-    __shared__ uint8_t ss[PB * NG], sm[PB * NG];
+    __shared__ __attribute__((aligned(16))) uint8_t ss[PB * NG];
+    __shared__ __attribute__((aligned(16))) uint8_t sm[PB * NG];
     __shared__ uint16_t sd[PB], sdm[PB];
     const int tid = threadIdx.x;
     for (int64_t b0 = (int64_t)blockIdx.x * PB; b0 < nblocks; b0 += (int64_t)gridDim.x * PB) {
         const int nb = (int)((nblocks - b0) < PB ? (nblocks - b0) : PB);
-        // stage inputs: PB*256 bytes = 128 uint4
-        if (tid < nb * 16) reinterpret_cast<uint4*>(sq)[tid] = reinterpret_cast<const uint4*>(qw + b0 * 256)[tid];
-        if (tid < nb * NG) {
-            ss[tid] = s[b0 * NG + tid];
-            sm[tid] = m ? m[b0 * NG + tid] : 0;
+        // stage inputs: nb*256 bytes = nb*16 uint4 (two loads per thread before the first LDS write)
+        {
+            const uint4* src = reinterpret_cast<const uint4*>(qw + b0 * 256);
+            const int n16 = nb * 16;
+            uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0;
+            if (tid < n16) v0 = src[tid];
+            if (tid + 256 < n16) v1 = src[tid + 256];
+            if (tid < n16) reinterpret_cast<uint4*>(sq)[tid] = v0;
+            if (tid + 256 < n16) reinterpret_cast<uint4*>(sq)[tid + 256] = v1;
+        }
+        for (int t = tid; t < nb * NG; t += 256) {
+            ss[t] = s[b0 * NG + t];
+            sm[t] = m ? m[b0 * NG + t] : 0;
         }
         if (tid < nb) {
             sd[tid] = d[b0 + tid];
             sdm[tid] = dmin ? dmin[b0 + tid] : 0;
         }
         __syncthreads();
-        for (int o = tid; o < nb * TS; o += 256) {
-            const int b = o / TS, ob = o % TS;
-            so[o] = pack_byte<QT>(sq + b * 256, ss + b * NG, sm + b * NG, sd[b], sdm[b], ob);
+        constexpr int NDW = TS / 4;  // whole dwords of a block; TS % 4 == 2 (Q3_K, Q6_K): the fp16 d follows
+        for (int i = tid; i < nb * NDW; i += 256) {
+            const int b = i / NDW, w = i % NDW;
+            const uint32_t v = pack_dword<QT>(sq + b * 256, ss + b * NG, sm + b * NG, sd[b], sdm[b], w);
+            uint8_t* dst = so + b * TS + 4 * w;
+            if ((TS % 4 == 0) || !(b & 1)) {
+                *reinterpret_cast<uint32_t*>(dst) = v;
+            } else {  // odd block of a 110- / 210-byte layout: 2-byte aligned
+                reinterpret_cast<uint16_t*>(dst)[0] = (uint16_t)v;
+                reinterpret_cast<uint16_t*>(dst)[1] = (uint16_t)(v >> 16);
+            }
+        }
+        if constexpr (TS % 4 != 0) {
+            if (tid < nb) *reinterpret_cast<uint16_t*>(so + tid * TS + 4 * NDW) = sd[tid];
         }
         __syncthreads();
         uint8_t* op = out + b0 * TS;  // b0 % 8 == 0 and 8*TS % 16 == 0 -> 16-byte aligned
@@ -277,7 +378,7 @@ int launch_pack(int q_type, const uint8_t* q, const uint16_t* d, const uint8_t* 
     if (ti.k_search && (!dmin || !m)) GQ_FAIL(GQ_E_NULL, "gq_pack: dmin/m required for q_type %d", q_type);
     const int64_t nblocks = R * (C / 256);
     int64_t g = (nblocks + PB - 1) / PB;
-    dim3 grid((unsigned)(g < 4096 ? g : 4096)), block(256);
+    dim3 grid((unsigned)(g < 4096 ? g : 4096)), block(256);  // (1024 .. 16384 workgroups measured: no difference from 2048 up)
     ProfScope ps(PT_PACK, st);
     switch (q_type) {
     case GQ_Q2_K: hipLaunchKernelGGL((pack_kernel<GQ_Q2_K, 84, 16>), grid, block, 0, st, q, d, s, dmin, m, nblocks, out); break;
