@@ -198,7 +198,7 @@ def trailing_update_legs(wl, W16, X, in_region):
     with the U of a real gq_h_prepare on that Linear's Hessian:
       far_alone     the chained far updates (one per 1024-column super-block), alone on the GPU
       whole_alone   near (rest-of-super-block after every 128-column block) + far launches, alone on the GPU
-                    (both with GQ_FAR_SYNC=1: every GEMM has the chip to itself -- the kernels' own efficiency)
+                    (both with the helper stream off: every GEMM has the chip to itself -- the kernels' own efficiency)
       loop_ms       the Linear's whole column loop, alone: one stream, and as the product runs it (far updates cut
                     by column groups and moved next to the loop on the library's helper stream, persistent launches
                     with 192 workgroups: each far GEMM is slower, the loop as a whole shorter)
@@ -218,13 +218,10 @@ def trailing_update_legs(wl, W16, X, in_region):
         far = sum(2.0 * R * (min(s0 + sb, C) - s0) * (C - min(s0 + sb, C)) for s0 in range(0, C, sb))
         near = sum(2.0 * R * B * (min((c1 // sb + 1) * sb, C) - (c1 + B)) for c1 in range(0, C, B))
         best, loop_ms = {}, {}
-        had = os.environ.get("GQ_FAR_SYNC")
+        helper_was = ops.far_helper_enable(True)
         try:
             for mode in ("one_stream", "as_run"):
-                if mode == "one_stream":
-                    os.environ["GQ_FAR_SYNC"] = "1"
-                elif had is None:
-                    os.environ.pop("GQ_FAR_SYNC", None)
+                ops.far_helper_enable(mode == "as_run")
                 for it in range(3):  # un-profiled wall time of the whole loop
                     Wf = W16[name].float()
                     torch.cuda.synchronize()
@@ -247,10 +244,7 @@ def trailing_update_legs(wl, W16, X, in_region):
                         if k not in best or v[0] < best[k][0]:
                             best[k] = v
         finally:
-            if had is None:
-                os.environ.pop("GQ_FAR_SYNC", None)
-            else:
-                os.environ["GQ_FAR_SYNC"] = had
+            ops.far_helper_enable(helper_was)
         fms, fn, _ = best.get("trailing_far_gemm32", (0.0, 0, 0.0))
         nms, nn_, _ = best.get("trailing_gemm32", (0.0, 0, 0.0))
         out = {"bound": "mfma", "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "linear": f"{name} {R}x{C}",

@@ -16,7 +16,7 @@ WS_H_ACCUMULATE, WS_H_PREPARE, WS_GPTQ_QUANTIZE = 1, 2, 3
 
 EXPORTS = (
     "gq_abi_version", "gq_last_error", "gq_type_info", "gq_workspace_bytes", "gq_h_accumulate", "gq_h_accumulate_grouped", "gq_h_accumulate_segments", "gq_h_stage", "gq_h_prepare", "gq_w_prepare", "gq_h_pack_upper", "gq_h_unpack_upper",
-    "gq_scale_search", "gq_group_search", "gq_gptq_quantize", "gq_gptq_quantize_perm", "gq_gptq_uses_helper_stream", "gq_far_helper_enable", "gq_obq_h_prepare", "gq_obq_quantize", "gq_rtn_quantize", "gq_dequantize", "gq_pack", "gq_trailing_update",
+    "gq_scale_search", "gq_group_search", "gq_gptq_quantize", "gq_gptq_quantize_perm", "gq_gptq_uses_helper_stream", "gq_far_helper_enable", "gq_syrk_workgroups", "gq_obq_h_prepare", "gq_obq_quantize", "gq_rtn_quantize", "gq_dequantize", "gq_pack", "gq_trailing_update",
     "gq_prof_enable", "gq_prof_ntags", "gq_prof_name", "gq_prof_collect", "gq_prof_collect2",
 )
 
@@ -81,6 +81,7 @@ def lib():
     L.gq_gptq_quantize_perm.argtypes = [vp, vp, i64, i64, ci, ci, vp, vp, vp, vp, vp, vp, vp, sz, vp]
     L.gq_gptq_uses_helper_stream.argtypes = [i64, i64, ci]
     L.gq_far_helper_enable.argtypes = [ci]
+    L.gq_syrk_workgroups.argtypes = [ci]
     L.gq_obq_h_prepare.argtypes = L.gq_h_prepare.argtypes
     L.gq_obq_quantize.argtypes = [vp, vp, i64, i64, ci, ci, ci, ci, vp, vp, vp, vp, sz, vp]
     L.gq_rtn_quantize.argtypes = [vp, ci, i64, i64, ci, sp, vp, vp, vp, vp, vp, vp]

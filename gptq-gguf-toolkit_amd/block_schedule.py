@@ -330,15 +330,11 @@ class BlockSchedule:
             side[0].wait_event(entry)
             with torch.cuda.stream(side[0]):
                 # fewer resident SYRK workgroups than CUs: the widest chain's kernels always find free ones
-                prev = os.environ.get("GQ_SYRK_WGS")
-                os.environ["GQ_SYRK_WGS"] = os.environ.get("GQ_DEFER_WGS", "192")
+                prev = _ops.syrk_workgroups(int(os.environ.get("GQ_DEFER_WGS", "192")))
                 try:
                     held = self._fold_postponed()
                 finally:
-                    if prev is None:
-                        os.environ.pop("GQ_SYRK_WGS", None)
-                    else:
-                        os.environ["GQ_SYRK_WGS"] = prev
+                    _ops.syrk_workgroups(prev)
                 folded = torch.cuda.Event()
                 folded.record(side[0])
             for h in late:

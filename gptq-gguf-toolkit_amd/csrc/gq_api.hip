@@ -31,6 +31,7 @@ int obq_quantize(float*, const float*, int64_t, int64_t, int, int, int, int, uin
                  hipStream_t);
 int gptq_uses_helper_stream(int64_t, int64_t, int);
 int far_helper_enable(int);
+int syrk_workgroups(int);
 int w_prepare(const uint8_t*, float*, int64_t, int64_t, int*, hipStream_t);
 int h_pack_upper(const float*, int64_t, float*, hipStream_t);
 int h_unpack_upper(const float*, int64_t, float*, hipStream_t);
@@ -130,6 +131,7 @@ int gq_h_prepare(float* H, float* W, int64_t R, int64_t C, float rel_damp, float
 
 int gq_gptq_uses_helper_stream(int64_t R, int64_t C, int block_size) { return gptq_uses_helper_stream(R, C, block_size); }
 int gq_far_helper_enable(int on) { return far_helper_enable(on); }
+int gq_syrk_workgroups(int n) { return syrk_workgroups(n); }
 
 int gq_obq_h_prepare(float* H, float* W, int64_t R, int64_t C, float rel_damp, float* U, int* not_invertible,
                      uint8_t* col_flags_out, void* ws, size_t ws_bytes, void* stream) {

@@ -21,6 +21,15 @@
 
 namespace gq {
 
+// resident workgroups of the persistent SYRK launches enqueued by this host thread (gq_syrk_workgroups)
+static thread_local int g_syrk_wgs = 256;
+int syrk_workgroups(int n) {
+    const int prev = g_syrk_wgs;
+    g_syrk_wgs = (n >= 8 && n <= 256) ? (n & ~7) : 256;
+    return prev;
+}
+
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -1161,7 +1170,7 @@ static int syrk16_launch(int kind, const int* idx, int m, float* const* H, const
         // one tile per workgroup, or (grp.bar) one workgroup per CU walking its XCD's list in rounds
         // (GQ_SYRK_WGS, read per call: fewer resident workgroups for a fold that runs NEXT TO a latency-bound chain --
         // the block schedule's postponed folds -- so that the chain's kernels always find free CUs)
-        int wgs = 256;
+        int wgs = g_syrk_wgs;
         if (const char* e = getenv("GQ_SYRK_WGS")) wgs = (atoi(e) >= 8 && atoi(e) <= 256) ? (atoi(e) & ~7) : 256;
         const dim3 grid((unsigned)(grp.bar ? wgs : 8 * grp.per_xcd)), blk(512);
         if (bf) hipLaunchKernelGGL(syrk16_256n_kernel<true>, grid, blk, S_LDS_BYTES, st, grp);

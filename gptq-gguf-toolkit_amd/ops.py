@@ -269,6 +269,11 @@ def far_helper_enable(on: bool) -> bool:
     return bool(lib().gq_far_helper_enable(int(bool(on))))
 
 
+def syrk_workgroups(n: int) -> int:
+    """Resident workgroups of this thread's next persistent SYRK launches (gq_syrk_workgroups); returns the previous value."""
+    return int(lib().gq_syrk_workgroups(int(n)))
+
+
 def gptq_quantize_perm(W: torch.Tensor, U: torch.Tensor, q_type: int, perm: torch.Tensor, d, s, dmin, m, block_size=128,
                        ws: Optional[torch.Tensor] = None) -> torch.Tensor:
     """GPTQ.step body with act_order (gptq.py:208-216, 233-235).  W (fp32) and U are already permuted by `perm`

@@ -173,6 +173,10 @@ int gq_gptq_uses_helper_stream(int64_t R, int64_t C, int block_size);
 /* Process-wide switch of that helper stream for the calls enqueued from now on (1 = allowed, the default); returns the
    previous setting.  A scheduler with more chains than streams keeps all its streams and switches the helper off. */
 int gq_far_helper_enable(int on);
+/* Resident workgroups (8..256, a multiple of 8; anything else = 256, one per CU) of the persistent gq_h_accumulate*
+   launches the CALLING THREAD enqueues from now on; returns the previous value.  A fold that runs next to a
+   latency-bound chain of another stream leaves CUs free for it this way; results do not depend on it. */
+int gq_syrk_workgroups(int n);
 
 /* GPTQ.step with act_order=True (gptq.py:208-216, 233-235, 272-276; implies static_groups, gptq.py:45-46;
    not for Q3_K, gptq.py:204-206).  The caller permutes: perm = argsort(diag(H), descending) (int32 [C], on the
