@@ -621,3 +621,32 @@ def test_mse_quant_scale_golden(ops, oracle, name):
     assert np.array_equal(npy(q), rq) and np.array_equal(u16(d), rd) and np.array_equal(npy(s), rs)
     qa, da, sa, _, _ = ops.rtn_quantize(dev(W), t)
     assert not np.array_equal(npy(sa), npy(s))  # the mode matters on this matrix
+
+
+def test_gptq_quantize_random_small_shapes_vs_oracle(ops, oracle):
+    """A seeded sweep over ragged row counts (1 .. 257: partial workgroups), widths, block sizes (16 .. C: one segment,
+    several segments, the block scratch path), every K-quant type, lazy and static groups and search settings:
+    integers, scale ints, fp16 super-scales and the final W against the oracle on the same (W, U), bit for bit."""
+    rng = np.random.default_rng(77)
+    for case in range(30):
+        name = list(TYPES)[case % 5]
+        C = int(rng.choice([256, 512, 768, 1280]))
+        R = int(rng.choice([1, 5, 63, 64, 65, 129, 257]))
+        block = int(rng.choice([16, 32, 64, 128, 256, 384, 0]))
+        static = bool(rng.integers(2))
+        nstep = int(rng.choice([20, 20, 7, 0]))
+        X = rng.standard_normal((2 * C, C)).astype(np.float32) * np.exp(rng.standard_normal(C) * 0.5).astype(np.float32)
+        H = dev((2.0 / X.shape[0]) * (X.T @ X))
+        W = dev((rng.standard_normal((R, C)) * 0.05).astype(np.float32))
+        if case % 4 == 0:
+            W[:, int(rng.integers(C))] = 0.0
+        U, flag = ops.h_prepare(H, W, 0.01)
+        assert int(flag.item()) == 0
+        W0, Un = npy(W), npy(U)
+        q, d, s, dmin, m = ops.gptq_quantize(W, U, TYPES[name], block, static, nstep=nstep)
+        Wd, oq, od, os_, odm, om = oracle.gptq_step(W0, Un, TYPES[name], block_size=block, static_groups=static, nstep=nstep)
+        tag = f"case {case}: {name} R={R} C={C} block={block} static={static} nstep={nstep}"
+        assert np.array_equal(npy(q), oq), tag
+        assert np.array_equal(npy(s), os_) and np.array_equal(npy(m), om), tag
+        assert np.array_equal(u16(d), od) and np.array_equal(u16(dmin), odm), tag
+        assert bits_eq(npy(W), Wd), tag
