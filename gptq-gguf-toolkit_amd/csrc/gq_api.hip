@@ -36,6 +36,9 @@ int w_prepare(const uint8_t*, float*, int64_t, int64_t, int*, hipStream_t);
 int h_pack_upper(const float*, int64_t, float*, hipStream_t);
 int h_unpack_upper(const float*, int64_t, float*, hipStream_t);
 int h_stage(void*, const void*, int64_t, hipStream_t);
+size_t chol_gemm_workspace_bytes(int64_t, int64_t, int64_t);
+int chol_gemm(float*, int64_t, const float*, int64_t, const float*, int64_t, int64_t, int64_t, int64_t, int, int, int, int, int,
+              void*, size_t, hipStream_t);
 }  // namespace gq
 
 #include <algorithm>
@@ -91,6 +94,7 @@ size_t gq_workspace_bytes(int op, int64_t R, int64_t C, int64_t T, int block_siz
     case GQ_WS_H_ACCUMULATE: return h_accumulate_workspace_bytes(T, C);
     case GQ_WS_H_PREPARE: return h_prepare_workspace_bytes(R, C);
     case GQ_WS_GPTQ_QUANTIZE: return gptq_workspace_bytes(R, C, block_size);
+    case GQ_WS_CHOL_GEMM: return chol_gemm_workspace_bytes(R, C, T);
     default: return 0;
     }
 }
@@ -221,13 +225,20 @@ int gq_trailing_update(float* Cmat, int64_t ldc, const float* A, int64_t lda, co
     return launch_trailing_update(Cmat, ldc, A, lda, B, ldb, M, N, K, (hipStream_t)stream);
 }
 
+int gq_chol_gemm(float* Cmat, int64_t ldc, const float* A, int64_t lda, const float* B, int64_t ldb, int64_t M, int64_t N,
+                 int64_t K, int trans_b, int mode, int k_range, int lower, int planes, void* ws, size_t ws_bytes, void* stream) {
+    return chol_gemm(Cmat, ldc, A, lda, B, ldb, M, N, K, trans_b, mode, k_range, lower, planes, ws, ws_bytes,
+                     (hipStream_t)stream);
+}
+
 // ---- profiling (bench.py): HIP-event timing of selected kernels on their launch stream ----
 void gq_prof_enable(unsigned tag_mask) { g_prof_mask = tag_mask; }
 int gq_prof_ntags(void) { return PT_COUNT; }
 const char* gq_prof_name(int tag) {
     static const char* names[PT_COUNT] = {"transpose16", "syrk", "prepare_elementwise", "diag_potrf_inv", "potrf_gemm32",
                                           "trtri_gemm32", "scale_search", "gptq_segment", "trailing_gemm32",
-                                          "block_far_update", "dequantize", "rtn_quantize", "pack", "trailing_far_gemm32"};
+                                          "block_far_update", "dequantize", "rtn_quantize", "pack", "trailing_far_gemm32",
+                                          "chol_image_gemm", "chol_image_split"};
     return (tag >= 0 && tag < PT_COUNT) ? names[tag] : "?";
 }
 /* synchronises the recorded events; ms[tag], n[tag] accumulate; records are recycled.

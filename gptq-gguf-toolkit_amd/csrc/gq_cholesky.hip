@@ -19,6 +19,11 @@
 #include "gq_common.hpp"
 #include "gq_gemm32.hpp"
 #include "gq_gemm3b.hpp"
+#include "gq_gemm3p.hpp"
+
+#include <map>
+#include <memory>
+#include <mutex>
 
 namespace gq {
 
@@ -185,24 +190,44 @@ __global__ __launch_bounds__(1024) void damp_kernel(float* __restrict__ H, int64
     for (int64_t i = threadIdx.x; i < C; i += 1024) H[i * C + i] += damp;
 }
 
-// A[i,j] = H[n-1-i, n-1-j]
+// Equilibration by powers of two: s_j = 2^-e_j with H_jj s_j^2 in [0.5, 2).  The chain factorises S H S (unit-order
+// diagonal, entries <= 2) and U = U_hat S (finish_u_kernel).  Scaling by powers of two commutes with every fp32
+// operation (no overflow / underflow at these magnitudes), so the fp32 and exact-split bf16 kernels compute bit for bit
+// what they would without it; what it buys is that all k of a product weigh the same, which the row-scaled fp16 images
+// of gq_gemm3p.hpp need for their error bound to mean something (a row of H spans sigma_max / sigma_min of the channels).
+__global__ __launch_bounds__(256) void equil_kernel(const float* __restrict__ H, int64_t n, float* __restrict__ s) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const float h = H[j * n + j];
+    float v = 1.0f;
+    if (h > 0.0f && h < 3.0e38f) {
+        int e;
+        (void)frexpf(h, &e);                       // h = m 2^e, m in [0.5, 1)
+        const int half = (e >= 0 ? e : e - 1) / 2;  // floor(e / 2): h 2^(-2 half) in [0.5, 2)
+        v = ldexpf(1.0f, -half);
+    }
+    s[j] = v;
+}
+// A[i,j] = H[n-1-i, n-1-j] s[n-1-i] s[n-1-j]
 __global__ __launch_bounds__(256) void reverse_copy_kernel(float* __restrict__ A, const float* __restrict__ H,
-                                                           int64_t n) {
+                                                           int64_t n, const float* __restrict__ s) {
     const int64_t total = n * n;
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x)
-        A[t] = H[total - 1 - t];
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t src = total - 1 - t;
+        A[t] = s ? H[src] * (s[src / n] * s[src % n]) : H[src];
+    }
 }
 
-// U[i,j] = X[n-1-i, n-1-j] for j >= i, 0 below; identity if *flag
+// U[i,j] = X[n-1-i, n-1-j] s[j] for j >= i, 0 below; identity if *flag
 __global__ __launch_bounds__(256) void finish_u_kernel(float* __restrict__ U, const float* __restrict__ X, int64_t n,
-                                                       const int* __restrict__ flag) {
+                                                       const int* __restrict__ flag, const float* __restrict__ s) {
     const int64_t total = n * n;
     const bool bad = *flag != 0;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
         const int64_t i = t / n, j = t % n;
         float v;
         if (bad) v = (i == j) ? 1.0f : 0.0f;  // gptq.py:321-323
-        else v = (j >= i) ? X[total - 1 - t] : 0.0f;
+        else v = (j >= i) ? (s ? X[total - 1 - t] * s[j] : X[total - 1 - t]) : 0.0f;
         U[t] = v;
     }
 }
@@ -622,10 +647,98 @@ __global__ __launch_bounds__(256) void diag_blk_kernel(float* __restrict__ A, in
     }
 }
 
+// ---- the top recursion levels on pre-split operand images (gq_gemm3p.hpp) ----
+// A node (n1 | n2) goes there when both halves are multiples of 256 and at least p3_min() wide.  The schedules of all
+// its GEMMs depend on C only: they are planned once per C (cached), and uploaded with ONE copy per gq_h_prepare
+// call (the upload also zeroes the pop counters).
+static int64_t p3_min() {
+    static const int64_t v = getenv("GQ_CHOL_3P_MIN") ? atol(getenv("GQ_CHOL_3P_MIN")) : 1792;  // 0: never
+    return v;
+}
+static int p3_planes() {
+    static const int v = getenv("GQ_CHOL_BF16X3") ? 3 : 2;  // default: row-scaled fp16 x 2 on the equilibrated matrix
+    return v;
+}
+static inline bool p3_node(int64_t n1, int64_t n2) {
+    return p3_min() > 0 && n1 >= p3_min() && n2 >= p3_min() && n1 % 256 == 0 && n2 % 256 == 0;
+}
+constexpr int P3_MAX_SLOTS = 1024;  // 256 MiB of K-split partial sums
+struct P3Gemm {
+    size_t table_at, rlist_at;  // word offsets into the uploaded buffer
+    int n_reduce;
+};
+struct P3Plans {
+    std::vector<uint32_t> words;
+    std::vector<P3Gemm> gemms;  // four per node, in the order chol_inv_rec issues them
+};
+static void p3_collect(P3Plans& pl, int64_t lo, int64_t hi) {
+    if (hi - lo == 1) return;
+    const int64_t mid = (lo + hi) / 2;
+    const int64_t n1 = (mid - lo) * NB, n2 = (hi - mid) * NB;
+    p3_collect(pl, lo, mid);
+    const bool big = p3_node(n1, n2);
+    const int gran = p3_planes() == 3 ? 2 : 4;
+    auto add = [&](const p3::GemmShape& sh) {
+        p3::Plan p = p3::make_plan(sh, 0, gran, P3_MAX_SLOTS, 0);
+        P3Gemm g;
+        while (pl.words.size() % 4) pl.words.push_back(0u);
+        g.table_at = pl.words.size();
+        pl.words.insert(pl.words.end(), p.table.begin(), p.table.end());
+        g.rlist_at = pl.words.size();
+        pl.words.insert(pl.words.end(), p.rlist.begin(), p.rlist.end());
+        g.n_reduce = (int)(p.rlist.size() / 2);
+        if (p.nslots < 0) fprintf(stderr, "gq: image GEMM plan needs more than %d partial slots\n", P3_MAX_SLOTS), abort();
+        if (getenv("GQ_CHOL_3P_VERBOSE"))
+            fprintf(stderr, "p3 plan MT=%d NT=%d KC=%d kr=%d lower=%d: units=%zu split tiles=%d slots=%d makespan=%.1f ideal=%.1f chunks\n",
+                    sh.MT, sh.NT, sh.KC, sh.kr, (int)sh.lower, (p.table.size() - p3::T_UNITS) / 4, g.n_reduce, p.nslots,
+                    p.makespan, p.ideal);
+        pl.gemms.push_back(g);
+    };
+    if (big) {
+        const int t1 = (int)(n1 / 256), t2 = (int)(n2 / 256), k1 = (int)(n1 / 32);
+        add({t2, t1, k1, 1, false});  // L21 = A21 X11^T
+        add({t2, t2, k1, 0, true});   // A22 -= L21 L21^T
+        add({t2, t1, k1, 2, false});  // L21 X11
+    }
+    p3_collect(pl, mid, hi);
+    if (big) add({(int)(n2 / 256), (int)(n1 / 256), (int)(n2 / 32), 3, false});  // X21 = -X22 (L21 X11)
+}
+static std::shared_ptr<const P3Plans> p3_plans_for(int64_t nblk) {
+    static std::mutex mu;
+    static std::map<int64_t, std::shared_ptr<const P3Plans>> cache;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find(nblk);
+    if (it != cache.end()) return it->second;
+    auto pl = std::make_shared<P3Plans>();
+    p3_collect(*pl, 0, nblk);
+    cache[nblk] = pl;
+    return pl;
+}
+struct P3Run {  // per gq_h_prepare call
+    const P3Plans* plans = nullptr;
+    const uint32_t* words_dev = nullptr;
+    size_t next = 0;
+    unsigned char* img[2] = {nullptr, nullptr};
+    float* partial = nullptr;
+    unsigned* rmax = nullptr;     // NP == 2: [2][n/2] row maxima (bits) ...
+    float* inv_scale = nullptr;   // ... and [2][n/2] epilogue scales
+};
+static size_t p3_image_bytes(int64_t C) { return (size_t)(C / 2) * (size_t)(C / 2) * 2 * (size_t)p3_planes(); }
+static bool p3_used(int64_t C) {
+    const int64_t nblk = C / NB, mid = nblk / 2;
+    return nblk >= 2 && p3_node(mid * NB, (nblk - mid) * NB);
+}
+
 size_t h_prepare_workspace_bytes(int64_t R, int64_t C) {
     (void)R;
     const size_t n2 = (size_t)C * (size_t)C * sizeof(float);
-    return 2 * n2 + 2 * (size_t)C + 1024;
+    size_t extra = 0;
+    if (p3_used(C)) {
+        auto pl = p3_plans_for(C / NB);
+        extra = 2 * (p3_image_bytes(C) + 256) + (size_t)P3_MAX_SLOTS * p3::TILE * p3::TILE * 4 + pl->words.size() * 4 +
+                4 * (size_t)C * 4 + 2048;
+    }
+    return 2 * n2 + 2 * (size_t)C + 4 * (size_t)C + 1024 + extra;
 }
 
 // Recursive blocked Cholesky WITH inverse, all level-3 work on the fp32 matrix cores:
@@ -639,8 +752,59 @@ size_t h_prepare_workspace_bytes(int64_t R, int64_t C) {
 // (Measured and dropped, r02: L21 X11 of the large nodes on helper streams -- one per recursion depth -- under the
 // recursion into A22, which it does not depend on: h_prepare(14336) alone 24.3 -> 23.5 ms, but inside a block's
 // four-chain schedule the three extra hardware queues cost far more than that: 102 -> 113 ms per step.)
+template <int NP>
+static int p3_gemm(P3Run& run, const unsigned char* Aimg, int64_t Ka, const unsigned char* Bimg, int64_t Kb, float* Cm,
+                   int64_t ldc, int mode, const float* rs, const float* cs, hipStream_t st) {
+    const P3Gemm& gm = run.plans->gemms[run.next++];
+    p3::Group g;
+    g.p[0] = p3::Problem{Aimg, Bimg, (uint32_t)(Ka / 32 * NP * p3::BLK), (uint32_t)(Kb / 32 * NP * p3::BLK), Cm, ldc, mode,
+                         rs, cs, run.partial};
+    g.p[1] = g.p[0];
+    g.table = run.words_dev + gm.table_at;
+    return p3::launch_gemm<NP>(g, gm.n_reduce, run.words_dev + gm.rlist_at, st);
+}
+
 static int chol_inv_rec(float* A, float* X, float* Tmp, int* flag, int64_t n, int64_t lo, int64_t hi, size_t diag_lds,
-                        hipStream_t st) {
+                        hipStream_t st, P3Run& run);
+
+// One node of the recursion on the image GEMMs.  Same products as the generic path below; L21 X11 moves in front of
+// the recursion into A22 (it does not depend on it), so that the image of L21 serves both of its consumers.
+template <int NP>
+static int chol_node_p3(float* A, float* X, float* Tmp, int* flag, int64_t n, int64_t lo, int64_t mid, int64_t hi,
+                        size_t diag_lds, hipStream_t st, P3Run& run) {
+    const int64_t n1 = (mid - lo) * NB, n2 = (hi - mid) * NB;
+    const int64_t o21 = (mid * NB) * n + lo * NB, o11 = (lo * NB) * n + lo * NB, o22 = (mid * NB) * n + mid * NB;
+    unsigned* rm0 = run.rmax, *rm1 = run.rmax ? run.rmax + n / 2 : nullptr;
+    float* is0 = run.inv_scale, *is1 = run.inv_scale ? run.inv_scale + n / 2 : nullptr;
+    const float* s0 = NP == 2 ? is0 : nullptr;
+    const float* s1 = NP == 2 ? is1 : nullptr;
+    int rc;
+    {
+        ProfScope ps(PT_CHOL_GEMM, st);
+        // L21 = A21 X11^T  (X11 lower-triangular: k < 256 (tn + 1))
+        if ((rc = p3::launch_split<NP>(false, A + o21, n, n2, n1, 0, 0, run.img[0], rm0, is0, st))) return rc;
+        if ((rc = p3::launch_split<NP>(false, X + o11, n, n1, n1, 1, 0, run.img[1], rm1, is1, st))) return rc;
+        if ((rc = p3_gemm<NP>(run, run.img[0], n1, run.img[1], n1, Tmp + o21, n, 1, s0, s1, st))) return rc;
+        // A22 -= L21 L21^T (lower tiles); the image of L21 has its chunks in reverse order for the product after it
+        if ((rc = p3::launch_split<NP>(false, Tmp + o21, n, n2, n1, 0, 1, run.img[0], rm0, is0, st))) return rc;
+        if ((rc = p3_gemm<NP>(run, run.img[0], n1, run.img[0], n1, A + o22, n, 0, s0, s0, st))) return rc;
+    }
+    {
+        ProfScope ps(PT_TRTRI_GEMM, st);
+        // A21 <- L21 X11  (X11[k][j] = 0 for k < j: in the reversed images every tile starts at chunk 0)
+        if ((rc = p3::launch_split<NP>(true, X + o11, n, n1, n1, 2, 1, run.img[1], rm1, is1, st))) return rc;
+        if ((rc = p3_gemm<NP>(run, run.img[0], n1, run.img[1], n1, A + o21, n, 1, s0, s1, st))) return rc;
+    }
+    if ((rc = chol_inv_rec(A, X, Tmp, flag, n, mid, hi, diag_lds, st, run))) return rc;
+    ProfScope ps(PT_TRTRI_GEMM, st);
+    // X21 = -X22 (L21 X11)  (X22 lower-triangular: k < 256 (tm + 1))
+    if ((rc = p3::launch_split<NP>(false, X + o22, n, n2, n2, 1, 0, run.img[0], rm0, is0, st))) return rc;
+    if ((rc = p3::launch_split<NP>(true, A + o21, n, n1, n2, 0, 0, run.img[1], rm1, is1, st))) return rc;
+    return p3_gemm<NP>(run, run.img[0], n2, run.img[1], n2, X + o21, n, 2, s0, s1, st);
+}
+
+static int chol_inv_rec(float* A, float* X, float* Tmp, int* flag, int64_t n, int64_t lo, int64_t hi, size_t diag_lds,
+                        hipStream_t st, P3Run& run) {
     if (hi - lo == 1) {
         ProfScope ps(PT_DIAG_POTRF, st);
         const int64_t o = (lo * NB) * n + lo * NB;
@@ -653,8 +817,11 @@ static int chol_inv_rec(float* A, float* X, float* Tmp, int* flag, int64_t n, in
     }
     const int64_t mid = (lo + hi) / 2;
     int rc;
-    if ((rc = chol_inv_rec(A, X, Tmp, flag, n, lo, mid, diag_lds, st))) return rc;
+    if ((rc = chol_inv_rec(A, X, Tmp, flag, n, lo, mid, diag_lds, st, run))) return rc;
     const int64_t n1 = (mid - lo) * NB, n2 = (hi - mid) * NB;
+    if (run.plans && p3_node(n1, n2))
+        return p3_planes() == 3 ? chol_node_p3<3>(A, X, Tmp, flag, n, lo, mid, hi, diag_lds, st, run)
+                                : chol_node_p3<2>(A, X, Tmp, flag, n, lo, mid, hi, diag_lds, st, run);
     const int64_t o21 = (mid * NB) * n + lo * NB, o11 = (lo * NB) * n + lo * NB, o22 = (mid * NB) * n + mid * NB;
     // large nodes: fp32-accurate products on the bf16 matrix cores (gq_gemm3b.hpp); small ones are
     // latency-bound and stay on the fp32 instruction
@@ -667,7 +834,7 @@ static int chol_inv_rec(float* A, float* X, float* Tmp, int* flag, int64_t n, in
         if ((rc = GQ_CHOL_GEMM(true, 1, false, 1, Tmp + o21, n, A + o21, n, X + o11, n, n2, n1, n1, st))) return rc;
         if ((rc = GQ_CHOL_GEMM(true, 0, true, 0, A + o22, n, Tmp + o21, n, Tmp + o21, n, n2, n2, n1, st))) return rc;
     }
-    if ((rc = chol_inv_rec(A, X, Tmp, flag, n, mid, hi, diag_lds, st))) return rc;
+    if ((rc = chol_inv_rec(A, X, Tmp, flag, n, mid, hi, diag_lds, st, run))) return rc;
     ProfScope ps(PT_TRTRI_GEMM, st);
     if ((rc = GQ_CHOL_GEMM(false, 1, false, 2, A + o21, n, Tmp + o21, n, X + o11, n, n2, n1, n1, st))) return rc;
     return GQ_CHOL_GEMM(false, 2, false, 3, X + o21, n, X + o22, n, A + o21, n, n2, n1, n2, st);
@@ -704,7 +871,31 @@ int h_prepare(float* H, float* W, int64_t R, int64_t C, float rel_damp, float* U
     uint8_t* zc = dead + n;
     int rc;
 
+    P3Run run;
+    std::shared_ptr<const P3Plans> plans;
+    if (p3_used(C)) {
+        plans = p3_plans_for(nblk);
+        unsigned char* p = reinterpret_cast<unsigned char*>(zc + n);
+        p = reinterpret_cast<unsigned char*>(((uintptr_t)p + 255) & ~(uintptr_t)255) + (((size_t)n * 4 + 255) & ~(size_t)255);
+        run.img[0] = p; p += (p3_image_bytes(C) + 255) & ~(size_t)255;
+        run.img[1] = p; p += (p3_image_bytes(C) + 255) & ~(size_t)255;
+        run.partial = reinterpret_cast<float*>(p); p += (size_t)P3_MAX_SLOTS * p3::TILE * p3::TILE * 4;
+        if (p3_planes() == 2) {
+            run.rmax = reinterpret_cast<unsigned*>(p); p += (size_t)n * 4;
+            run.inv_scale = reinterpret_cast<float*>(p); p += (size_t)n * 4;
+        } else {
+            p += 2 * (size_t)n * 4;
+        }
+        p = reinterpret_cast<unsigned char*>(((uintptr_t)p + 255) & ~(uintptr_t)255);
+        if (p + plans->words.size() * 4 > reinterpret_cast<unsigned char*>(ws) + ws_bytes)
+            GQ_FAIL(GQ_E_WORKSPACE, "gq_h_prepare: workspace too small for the image GEMMs");
+        // pageable source: staged before the call returns; the plans object outlives it (cached for the process)
+        GQ_HIP(hipMemcpyAsync(p, plans->words.data(), plans->words.size() * 4, hipMemcpyHostToDevice, st));
+        run.words_dev = reinterpret_cast<const uint32_t*>(p);
+        run.plans = plans.get();
+    }
     GQ_HIP(hipMemsetAsync(not_invertible, 0, sizeof(int), st));
+    float* eq_s = nullptr;
     {
     ProfScope ps(PT_PREP_ELEM, st);
     if ((uintptr_t)W % 16 == 0)  // C % 128 == 0 here
@@ -724,7 +915,12 @@ int h_prepare(float* H, float* W, int64_t R, int64_t C, float rel_damp, float* U
         hipLaunchKernelGGL(damp_kernel, dim3(1), dim3(1024), 0, st, H, C, rel_damp);
     }
     GQ_LAUNCH_CHECK();
-    hipLaunchKernelGGL(reverse_copy_kernel, dim3(4096), dim3(256), 0, st, A, H, n);
+    static const bool equil = getenv("GQ_CHOL_NO_EQUIL") == nullptr;
+    if (equil) {
+        eq_s = reinterpret_cast<float*>(((uintptr_t)(zc + n) + 255) & ~(uintptr_t)255);
+        hipLaunchKernelGGL(equil_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, H, n, eq_s);
+    }
+    hipLaunchKernelGGL(reverse_copy_kernel, dim3(4096), dim3(256), 0, st, A, H, n, eq_s);
     GQ_LAUNCH_CHECK();
     // X needs no clearing: every block that is read is written first (diagonal blocks whole, zeros included).  The
     // test that pins this fills X with NaN patterns first (GQ_POISON_X=1) and expects the same U.
@@ -740,11 +936,71 @@ int h_prepare(float* H, float* W, int64_t R, int64_t C, float rel_damp, float* U
                                    (int)DIAG_BLK_LDS));
         attr_set = true;
     }
-    if ((rc = chol_inv_rec(A, X, U, not_invertible, n, 0, nblk, diag_lds, st))) return rc;
+    if ((rc = chol_inv_rec(A, X, U, not_invertible, n, 0, nblk, diag_lds, st, run))) return rc;
     ProfScope ps(PT_PREP_ELEM, st);
-    hipLaunchKernelGGL(finish_u_kernel, dim3(4096), dim3(256), 0, st, U, X, n, not_invertible);
+    hipLaunchKernelGGL(finish_u_kernel, dim3(4096), dim3(256), 0, st, U, X, n, not_invertible, eq_s);
     GQ_LAUNCH_CHECK();
     return GQ_OK;
+}
+
+// ---- gq_chol_gemm: one product of the chain through the image path, for tests and benchmarks ----
+size_t chol_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+    const size_t img = (size_t)3 * 2 * (size_t)K;
+    return img * (size_t)M + img * (size_t)N + (size_t)P3_MAX_SLOTS * p3::TILE * p3::TILE * 4 + 2 * (size_t)(M + N) * 4 +
+           ((size_t)(M / 256 + 1) * (size_t)(N / 256 + 1) * 6 * 4 + 64) * 4 + 4096;
+}
+template <int NP>
+static int chol_gemm_np(float* Cm, int64_t ldc, const float* A, int64_t lda, const float* B, int64_t ldb, int64_t M, int64_t N,
+                        int64_t K, int trans_b, int mode, int kr, int lower, unsigned char* p, unsigned char* end,
+                        hipStream_t st) {
+    auto take = [&](size_t bytes) {
+        unsigned char* q = p;
+        p += (bytes + 255) & ~(size_t)255;
+        return q;
+    };
+    unsigned char* ia = take((size_t)NP * 2 * M * K);
+    unsigned char* ib = take((size_t)NP * 2 * N * K);
+    float* partial = reinterpret_cast<float*>(take((size_t)P3_MAX_SLOTS * p3::TILE * p3::TILE * 4));
+    unsigned* rma = reinterpret_cast<unsigned*>(take((size_t)M * 4));
+    unsigned* rmb = reinterpret_cast<unsigned*>(take((size_t)N * 4));
+    float* isa = reinterpret_cast<float*>(take((size_t)M * 4));
+    float* isb = reinterpret_cast<float*>(take((size_t)N * 4));
+    const p3::GemmShape sh{(int)(M / 256), (int)(N / 256), (int)(K / 32), kr, lower != 0};
+    const p3::Plan pl = p3::make_plan(sh, 0, NP == 3 ? 2 : 4, P3_MAX_SLOTS, 0);
+    if (pl.nslots < 0) GQ_FAIL(GQ_E_UNSUPPORTED, "gq_chol_gemm: the schedule needs more than %d partial slots", P3_MAX_SLOTS);
+    std::vector<uint32_t> words(pl.table);
+    const size_t rl_at = words.size();
+    words.insert(words.end(), pl.rlist.begin(), pl.rlist.end());
+    uint32_t* wd = reinterpret_cast<uint32_t*>(take(words.size() * 4));
+    if (p > end) GQ_FAIL(GQ_E_WORKSPACE, "gq_chol_gemm: workspace too small");
+    GQ_HIP(hipMemcpyAsync(wd, words.data(), words.size() * 4, hipMemcpyHostToDevice, st));  // pageable: staged before return
+    const int rev = kr == 2;
+    int rc;
+    if ((rc = p3::launch_split<NP>(false, A, lda, M, K, kr == 3 ? 1 : 0, rev, ia, rma, isa, st))) return rc;
+    if (!(lower && A == B && trans_b)) {
+        if ((rc = p3::launch_split<NP>(!trans_b, B, ldb, N, K, kr == 1 ? 1 : (kr == 2 ? 2 : 0), rev, ib, rmb, isb, st))) return rc;
+    } else {
+        ib = ia;
+        isb = isa;
+    }
+    p3::Group g;
+    g.p[0] = p3::Problem{ia, ib, (uint32_t)(K / 32 * NP * p3::BLK), (uint32_t)(K / 32 * NP * p3::BLK), Cm, ldc, mode,
+                         NP == 2 ? isa : nullptr, NP == 2 ? isb : nullptr, partial};
+    g.p[1] = g.p[0];
+    g.table = wd;
+    return p3::launch_gemm<NP>(g, (int)(pl.rlist.size() / 2), wd + rl_at, st);
+}
+int chol_gemm(float* Cm, int64_t ldc, const float* A, int64_t lda, const float* B, int64_t ldb, int64_t M, int64_t N, int64_t K,
+              int trans_b, int mode, int kr, int lower, int planes, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (!Cm || !A || !B || !ws) GQ_FAIL(GQ_E_NULL, "gq_chol_gemm: null pointer");
+    if (M <= 0 || N <= 0 || K <= 0 || M % 256 || N % 256 || K % 128 || lda % 4 || ldb % 4 || ldc % 4)
+        GQ_FAIL(GQ_E_BAD_SHAPE, "gq_chol_gemm: M=%ld N=%ld (multiples of 256) K=%ld (of 128), ld %% 4 == 0", (long)M, (long)N, (long)K);
+    if (mode < 0 || mode > 2 || kr < 0 || kr > 3 || (planes != 2 && planes != 3) || (kr == 1 && !trans_b) || (kr == 2 && trans_b))
+        GQ_FAIL(GQ_E_UNSUPPORTED, "gq_chol_gemm: mode=%d kr=%d planes=%d trans_b=%d", mode, kr, planes, trans_b);
+    unsigned char* p = reinterpret_cast<unsigned char*>(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+    unsigned char* end = reinterpret_cast<unsigned char*>(ws) + ws_bytes;
+    return planes == 3 ? chol_gemm_np<3>(Cm, ldc, A, lda, B, ldb, M, N, K, trans_b, mode, kr, lower, p, end, st)
+                       : chol_gemm_np<2>(Cm, ldc, A, lda, B, ldb, M, N, K, trans_b, mode, kr, lower, p, end, st);
 }
 
 }  // namespace gq

@@ -89,7 +89,8 @@ __device__ __forceinline__ float dequantize1(float q, float ds, float dm) { retu
 // ---- optional per-kernel timing with HIP events on the launch stream (bench.py) ----
 enum ProfTag {
     PT_TRANSPOSE = 0, PT_SYRK, PT_PREP_ELEM, PT_DIAG_POTRF, PT_CHOL_GEMM, PT_TRTRI_GEMM, PT_SCALE_SEARCH,
-    PT_GPTQ_SEGMENT, PT_TRAILING, PT_BLOCK_FAR, PT_DEQUANT, PT_RTN, PT_PACK, PT_TRAILING_FAR, PT_COUNT
+    PT_GPTQ_SEGMENT, PT_TRAILING, PT_BLOCK_FAR, PT_DEQUANT, PT_RTN, PT_PACK, PT_TRAILING_FAR, PT_CHOL_IMG_GEMM,
+    PT_CHOL_SPLIT, PT_COUNT
 };
 extern unsigned g_prof_mask;
 void prof_begin(int tag, hipStream_t st);

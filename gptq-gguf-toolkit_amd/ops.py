@@ -358,6 +358,22 @@ def trailing_update(Cm: torch.Tensor, A: torch.Tensor, B: torch.Tensor):
     return Cm
 
 
+def chol_gemm(Cm: torch.Tensor, A: torch.Tensor, B: torch.Tensor, trans_b: bool, mode: int, k_range: int = 0,
+              lower: bool = False, planes: int = 3):
+    """One product of the blocked Cholesky chain through the pre-split image kernels (gq_chol_gemm):
+    mode 0: Cm -= A op(B), 1: Cm = A op(B), 2: Cm = -(A op(B)); fp32-GEMM accuracy (tolerance class)."""
+    _need_cuda(Cm, A, B)
+    M, K = A.shape
+    N = B.shape[0] if trans_b else B.shape[1]
+    assert (B.shape[1] if trans_b else B.shape[0]) == K and Cm.shape == (M, N)
+    assert Cm.stride(1) == 1 and A.stride(1) == 1 and B.stride(1) == 1
+    ws = _ws(workspace_bytes(_cabi.WS_CHOL_GEMM, M, N, K), Cm.device)
+    check(lib().gq_chol_gemm(_ptr(Cm), Cm.stride(0), _ptr(A), A.stride(0), _ptr(B), B.stride(0), M, N, K, int(trans_b),
+                             int(mode), int(k_range), int(lower), int(planes), _ptr(ws), ws.numel(), _stream(Cm)),
+          "gq_chol_gemm")
+    return Cm
+
+
 def group_search(x: torch.Tensor, q_type: int, rmin=-1.0, rdelta=0.1, nstep=20, **mq):
     """make_k_quants / make_quants on a [rows,256] panel (fp32, or fp16/bf16 with per-op rounding).
     Returns (group_scale f32[rows,ng], group_zero f32[rows,ng], d, s, dmin, m)."""

@@ -81,7 +81,7 @@ const char* gq_last_error(void);
 int gq_type_info(int q_type, gq_type_info_t* out_host);
 
 /* Scratch bytes needed by an entry point.  op: one of GQ_WS_*; unused dims = 0. */
-enum { GQ_WS_H_ACCUMULATE = 1, GQ_WS_H_PREPARE = 2, GQ_WS_GPTQ_QUANTIZE = 3 };
+enum { GQ_WS_H_ACCUMULATE = 1, GQ_WS_H_PREPARE = 2, GQ_WS_GPTQ_QUANTIZE = 3, GQ_WS_CHOL_GEMM = 4 /* R = M, C = N, T = K */ };
 size_t gq_workspace_bytes(int op, int64_t R, int64_t C, int64_t T, int block_size);
 
 /* replaces gptq.py:96,108-112 (GPTQ.update):  H = beta*H + alpha * X^T X.
@@ -229,6 +229,18 @@ int gq_pack(int q_type, const uint8_t* qweight, const uint16_t* d, const uint8_t
    exposed for tests and benchmarks. */
 int gq_trailing_update(float* Cmat, int64_t ldc, const float* A, int64_t lda, const float* B, int64_t ldb,
                        int64_t M, int64_t N, int64_t K, void* stream);
+
+/* One product of gq_h_prepare's blocked Cholesky / triangular inverse (linalg_utils.py:8-12) through the kernels its top
+   recursion levels use, exposed for tests and benchmarks: every fp32 operand is split once into 16-bit planes
+   (planes = 3: bf16, exact split, six products per term; planes = 2: row-scaled fp16, three products) and multiplied on
+   the 16-bit matrix cores with fp32 accumulation -- fp32-GEMM accuracy, NOT the bit-exact chain of gq_trailing_update.
+     mode 0: C -= A op(B);  1: C = A op(B);  2: C = -(A op(B));   A is [M,K];  op(B) = B^T with B [N,K] if trans_b, else B [K,N];
+     k_range 0: all k;  1: k < 256 (tile col + 1) (B^T lower-triangular; trans_b);  2: k >= 256 tile col (B lower-triangular;
+     !trans_b);  3: k < 256 (tile row + 1) (A lower-triangular);  lower: only 256-tiles with tile row >= tile col.
+   128 x 128 blocks of a triangular operand beyond its block diagonal are never read.  M, N % 256 == 0, K % 128 == 0.
+   Workspace: gq_workspace_bytes(GQ_WS_CHOL_GEMM, M, N, K, 0). */
+int gq_chol_gemm(float* Cmat, int64_t ldc, const float* A, int64_t lda, const float* B, int64_t ldb, int64_t M, int64_t N,
+                 int64_t K, int trans_b, int mode, int k_range, int lower, int planes, void* ws, size_t ws_bytes, void* stream);
 
 /* Optional HIP-event timing of the library's own kernels, on the stream they are
    launched on (bench.py's roofline leg).  tag_mask bit t enables tag t; collect()
