@@ -208,27 +208,44 @@ __global__ __launch_bounds__(256) void equil_kernel(const float* __restrict__ H,
     }
     s[j] = v;
 }
-// A[i,j] = H[n-1-i, n-1-j] s[n-1-i] s[n-1-j]
+// A[i,j] = H[n-1-i, n-1-j] s[n-1-i] s[n-1-j] for the 128x128 blocks on and below the block diagonal (the chain never
+// reads A above it).  One workgroup per row, 16-byte accesses on both sides (n % 128 == 0).
 __global__ __launch_bounds__(256) void reverse_copy_kernel(float* __restrict__ A, const float* __restrict__ H,
                                                            int64_t n, const float* __restrict__ s) {
-    const int64_t total = n * n;
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t src = total - 1 - t;
-        A[t] = s ? H[src] * (s[src / n] * s[src % n]) : H[src];
+    const int64_t i = blockIdx.x, r = n - 1 - i;
+    const int64_t jend = (i / 128 + 1) * 128;
+    const float si = s ? s[r] : 1.0f;
+    for (int64_t j = 4 * (int64_t)threadIdx.x; j < jend; j += 4 * 256) {
+        const float4 h = *reinterpret_cast<const float4*>(H + r * n + (n - 4 - j));  // columns n-4-j .. n-1-j
+        float4 a = make_float4(h.w, h.z, h.y, h.x);
+        if (s) {
+            const float4 sc = *reinterpret_cast<const float4*>(s + (n - 4 - j));
+            a.x *= si * sc.w; a.y *= si * sc.z; a.z *= si * sc.y; a.w *= si * sc.x;
+        }
+        *reinterpret_cast<float4*>(A + i * n + j) = a;
     }
 }
 
-// U[i,j] = X[n-1-i, n-1-j] s[j] for j >= i, 0 below; identity if *flag
+// U[i,j] = X[n-1-i, n-1-j] s[j] for j >= i, 0 below; identity if *flag.  One workgroup per row.
 __global__ __launch_bounds__(256) void finish_u_kernel(float* __restrict__ U, const float* __restrict__ X, int64_t n,
                                                        const int* __restrict__ flag, const float* __restrict__ s) {
-    const int64_t total = n * n;
+    const int64_t i = blockIdx.x, r = n - 1 - i;
     const bool bad = *flag != 0;
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t i = t / n, j = t % n;
-        float v;
-        if (bad) v = (i == j) ? 1.0f : 0.0f;  // gptq.py:321-323
-        else v = (j >= i) ? (s ? X[total - 1 - t] * s[j] : X[total - 1 - t]) : 0.0f;
-        U[t] = v;
+    for (int64_t j = 4 * (int64_t)threadIdx.x; j < n; j += 4 * 256) {
+        float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bad) {  // gptq.py:321-323
+            u.x = (j == i) ? 1.0f : 0.0f; u.y = (j + 1 == i) ? 1.0f : 0.0f;
+            u.z = (j + 2 == i) ? 1.0f : 0.0f; u.w = (j + 3 == i) ? 1.0f : 0.0f;
+        } else if (j + 3 >= i) {
+            const float4 x = *reinterpret_cast<const float4*>(X + r * n + (n - 4 - j));
+            float4 sc = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (s) sc = *reinterpret_cast<const float4*>(s + j);
+            u.x = (j >= i) ? x.w * sc.x : 0.0f;
+            u.y = (j + 1 >= i) ? x.z * sc.y : 0.0f;
+            u.z = (j + 2 >= i) ? x.y * sc.z : 0.0f;
+            u.w = x.x * sc.w;
+        }
+        *reinterpret_cast<float4*>(U + i * n + j) = u;
     }
 }
 
@@ -651,14 +668,12 @@ __global__ __launch_bounds__(256) void diag_blk_kernel(float* __restrict__ A, in
 // A node (n1 | n2) goes there when both halves are multiples of 256 and at least p3_min() wide.  The schedules of all
 // its GEMMs depend on C only: they are planned once per C (cached), and uploaded with ONE copy per gq_h_prepare
 // call (the upload also zeroes the pop counters).
+// (The switches are read on every call -- a handful per transformer block -- so that tests can flip them.)
 static int64_t p3_min() {
-    static const int64_t v = getenv("GQ_CHOL_3P_MIN") ? atol(getenv("GQ_CHOL_3P_MIN")) : 1792;  // 0: never
-    return v;
+    const char* e = getenv("GQ_CHOL_3P_MIN");
+    return e ? atol(e) : 1792;  // 0: never
 }
-static int p3_planes() {
-    static const int v = getenv("GQ_CHOL_BF16X3") ? 3 : 2;  // default: row-scaled fp16 x 2 on the equilibrated matrix
-    return v;
-}
+static int p3_planes() { return getenv("GQ_CHOL_BF16X3") ? 3 : 2; }  // default: row-scaled fp16 x 2, equilibrated matrix
 static inline bool p3_node(int64_t n1, int64_t n2) {
     return p3_min() > 0 && n1 >= p3_min() && n2 >= p3_min() && n1 % 256 == 0 && n2 % 256 == 0;
 }
@@ -669,7 +684,7 @@ struct P3Gemm {
 };
 struct P3Plans {
     std::vector<uint32_t> words;
-    std::vector<P3Gemm> gemms;  // four per node, in the order chol_inv_rec issues them
+    std::vector<P3Gemm> gemms;  // three launches per node, in the order chol_inv_rec issues them
 };
 static void p3_collect(P3Plans& pl, int64_t lo, int64_t hi) {
     if (hi - lo == 1) return;
@@ -678,8 +693,9 @@ static void p3_collect(P3Plans& pl, int64_t lo, int64_t hi) {
     p3_collect(pl, lo, mid);
     const bool big = p3_node(n1, n2);
     const int gran = p3_planes() == 3 ? 2 : 4;
-    auto add = [&](const p3::GemmShape& sh) {
-        p3::Plan p = p3::make_plan(sh, 0, gran, P3_MAX_SLOTS, 0);
+    auto add = [&](const std::vector<p3::GemmShape>& shs) {
+        const p3::GemmShape& sh = shs[0];
+        p3::Plan p = p3::make_plan(shs, gran, P3_MAX_SLOTS);
         P3Gemm g;
         while (pl.words.size() % 4) pl.words.push_back(0u);
         g.table_at = pl.words.size();
@@ -696,22 +712,22 @@ static void p3_collect(P3Plans& pl, int64_t lo, int64_t hi) {
     };
     if (big) {
         const int t1 = (int)(n1 / 256), t2 = (int)(n2 / 256), k1 = (int)(n1 / 32);
-        add({t2, t1, k1, 1, false});  // L21 = A21 X11^T
-        add({t2, t2, k1, 0, true});   // A22 -= L21 L21^T
-        add({t2, t1, k1, 2, false});  // L21 X11
+        add({{t2, t1, k1, 1, false}});                          // L21 = A21 X11^T
+        add({{t2, t2, k1, 0, true}, {t2, t1, k1, 2, false}});   // A22 -= L21 L21^T  and  L21 X11, one launch
     }
     p3_collect(pl, mid, hi);
-    if (big) add({(int)(n2 / 256), (int)(n1 / 256), (int)(n2 / 32), 3, false});  // X21 = -X22 (L21 X11)
+    if (big) add({{(int)(n2 / 256), (int)(n1 / 256), (int)(n2 / 32), 3, false}});  // X21 = -X22 (L21 X11)
 }
 static std::shared_ptr<const P3Plans> p3_plans_for(int64_t nblk) {
     static std::mutex mu;
-    static std::map<int64_t, std::shared_ptr<const P3Plans>> cache;
+    static std::map<std::pair<int64_t, int64_t>, std::shared_ptr<const P3Plans>> cache;
     std::lock_guard<std::mutex> lk(mu);
-    auto it = cache.find(nblk);
+    const std::pair<int64_t, int64_t> key{nblk, p3_min() * 4 + p3_planes()};
+    auto it = cache.find(key);
     if (it != cache.end()) return it->second;
     auto pl = std::make_shared<P3Plans>();
     p3_collect(*pl, 0, nblk);
-    cache[nblk] = pl;
+    cache[key] = pl;
     return pl;
 }
 struct P3Run {  // per gq_h_prepare call
@@ -753,13 +769,17 @@ size_t h_prepare_workspace_bytes(int64_t R, int64_t C) {
 // recursion into A22, which it does not depend on: h_prepare(14336) alone 24.3 -> 23.5 ms, but inside a block's
 // four-chain schedule the three extra hardware queues cost far more than that: 102 -> 113 ms per step.)
 template <int NP>
-static int p3_gemm(P3Run& run, const unsigned char* Aimg, int64_t Ka, const unsigned char* Bimg, int64_t Kb, float* Cm,
-                   int64_t ldc, int mode, const float* rs, const float* cs, hipStream_t st) {
+static p3::Problem p3_problem(P3Run& run, const unsigned char* Aimg, int64_t Ka, const unsigned char* Bimg, int64_t Kb,
+                              float* Cm, int64_t ldc, int mode, const float* rs, const float* cs) {
+    return p3::Problem{Aimg, Bimg, (uint32_t)(Ka / 32 * NP * p3::BLK), (uint32_t)(Kb / 32 * NP * p3::BLK), Cm, ldc, mode,
+                       rs, cs, run.partial};
+}
+template <int NP>
+static int p3_gemm(P3Run& run, const p3::Problem& p0, const p3::Problem* p1, hipStream_t st) {
     const P3Gemm& gm = run.plans->gemms[run.next++];
     p3::Group g;
-    g.p[0] = p3::Problem{Aimg, Bimg, (uint32_t)(Ka / 32 * NP * p3::BLK), (uint32_t)(Kb / 32 * NP * p3::BLK), Cm, ldc, mode,
-                         rs, cs, run.partial};
-    g.p[1] = g.p[0];
+    g.p[0] = p0;
+    g.p[1] = p1 ? *p1 : p0;
     g.table = run.words_dev + gm.table_at;
     return p3::launch_gemm<NP>(g, gm.n_reduce, run.words_dev + gm.rlist_at, st);
 }
@@ -768,7 +788,7 @@ static int chol_inv_rec(float* A, float* X, float* Tmp, int* flag, int64_t n, in
                         hipStream_t st, P3Run& run);
 
 // One node of the recursion on the image GEMMs.  Same products as the generic path below; L21 X11 moves in front of
-// the recursion into A22 (it does not depend on it), so that the image of L21 serves both of its consumers.
+// the recursion into A22 (it does not depend on it) and shares the launch -- and the image of L21 -- with the SYRK update.
 template <int NP>
 static int chol_node_p3(float* A, float* X, float* Tmp, int* flag, int64_t n, int64_t lo, int64_t mid, int64_t hi,
                         size_t diag_lds, hipStream_t st, P3Run& run) {
@@ -784,23 +804,23 @@ static int chol_node_p3(float* A, float* X, float* Tmp, int* flag, int64_t n, in
         // L21 = A21 X11^T  (X11 lower-triangular: k < 256 (tn + 1))
         if ((rc = p3::launch_split<NP>(false, A + o21, n, n2, n1, 0, 0, run.img[0], rm0, is0, st))) return rc;
         if ((rc = p3::launch_split<NP>(false, X + o11, n, n1, n1, 1, 0, run.img[1], rm1, is1, st))) return rc;
-        if ((rc = p3_gemm<NP>(run, run.img[0], n1, run.img[1], n1, Tmp + o21, n, 1, s0, s1, st))) return rc;
-        // A22 -= L21 L21^T (lower tiles); the image of L21 has its chunks in reverse order for the product after it
+        const p3::Problem g1 = p3_problem<NP>(run, run.img[0], n1, run.img[1], n1, Tmp + o21, n, 1, s0, s1);
+        if ((rc = p3_gemm<NP>(run, g1, nullptr, st))) return rc;
+        // A22 -= L21 L21^T (lower tiles) and A21 <- L21 X11 in ONE launch: both need only L21.  X11[k][j] = 0 for k < j,
+        // so both images have their chunks in reverse order: every tile of the second product starts at chunk 0
         if ((rc = p3::launch_split<NP>(false, Tmp + o21, n, n2, n1, 0, 1, run.img[0], rm0, is0, st))) return rc;
-        if ((rc = p3_gemm<NP>(run, run.img[0], n1, run.img[0], n1, A + o22, n, 0, s0, s0, st))) return rc;
-    }
-    {
-        ProfScope ps(PT_TRTRI_GEMM, st);
-        // A21 <- L21 X11  (X11[k][j] = 0 for k < j: in the reversed images every tile starts at chunk 0)
         if ((rc = p3::launch_split<NP>(true, X + o11, n, n1, n1, 2, 1, run.img[1], rm1, is1, st))) return rc;
-        if ((rc = p3_gemm<NP>(run, run.img[0], n1, run.img[1], n1, A + o21, n, 1, s0, s1, st))) return rc;
+        const p3::Problem g2 = p3_problem<NP>(run, run.img[0], n1, run.img[0], n1, A + o22, n, 0, s0, s0);
+        const p3::Problem g3 = p3_problem<NP>(run, run.img[0], n1, run.img[1], n1, A + o21, n, 1, s0, s1);
+        if ((rc = p3_gemm<NP>(run, g2, &g3, st))) return rc;
     }
     if ((rc = chol_inv_rec(A, X, Tmp, flag, n, mid, hi, diag_lds, st, run))) return rc;
     ProfScope ps(PT_TRTRI_GEMM, st);
     // X21 = -X22 (L21 X11)  (X22 lower-triangular: k < 256 (tm + 1))
     if ((rc = p3::launch_split<NP>(false, X + o22, n, n2, n2, 1, 0, run.img[0], rm0, is0, st))) return rc;
     if ((rc = p3::launch_split<NP>(true, A + o21, n, n1, n2, 0, 0, run.img[1], rm1, is1, st))) return rc;
-    return p3_gemm<NP>(run, run.img[0], n2, run.img[1], n2, X + o21, n, 2, s0, s1, st);
+    const p3::Problem g4 = p3_problem<NP>(run, run.img[0], n2, run.img[1], n2, X + o21, n, 2, s0, s1);
+    return p3_gemm<NP>(run, g4, nullptr, st);
 }
 
 static int chol_inv_rec(float* A, float* X, float* Tmp, int* flag, int64_t n, int64_t lo, int64_t hi, size_t diag_lds,
@@ -829,14 +849,20 @@ static int chol_inv_rec(float* A, float* X, float* Tmp, int* flag, int64_t n, in
     const bool big = n1 >= min3b && n2 >= min3b;
 #define GQ_CHOL_GEMM(TB, MODE, LOW, KRV, ...) \
     (big ? launch_gemm3b<TB, MODE, LOW, KRV>(__VA_ARGS__) : launch_gemm32<TB, MODE, LOW, KRV>(__VA_ARGS__))
+    // small nodes: the SYRK update and L21 X11 (both need only L21) share one launch of whole 64-tiles, in front of the
+    // recursion into A22 (bit-identical to separate launches: every output element is the same k-ordered chain)
+    const bool pair = !big && !getenv("GQ_CHOL_NO_PAIR") && n % 4 == 0 && gemm32_uses_64_full(n2, n2, n1, true) &&
+                      gemm32_uses_64_full(n2, n1, n1, false);
     {
         ProfScope ps(PT_CHOL_GEMM, st);
         if ((rc = GQ_CHOL_GEMM(true, 1, false, 1, Tmp + o21, n, A + o21, n, X + o11, n, n2, n1, n1, st))) return rc;
-        if ((rc = GQ_CHOL_GEMM(true, 0, true, 0, A + o22, n, Tmp + o21, n, Tmp + o21, n, n2, n2, n1, st))) return rc;
+        if (pair) {
+            if ((rc = launch_gemm32_pair(A + o22, Tmp + o21, n2, n1, A + o21, Tmp + o21, X + o11, n2, n1, n1, n, st))) return rc;
+        } else if ((rc = GQ_CHOL_GEMM(true, 0, true, 0, A + o22, n, Tmp + o21, n, Tmp + o21, n, n2, n2, n1, st))) return rc;
     }
     if ((rc = chol_inv_rec(A, X, Tmp, flag, n, mid, hi, diag_lds, st, run))) return rc;
     ProfScope ps(PT_TRTRI_GEMM, st);
-    if ((rc = GQ_CHOL_GEMM(false, 1, false, 2, A + o21, n, Tmp + o21, n, X + o11, n, n2, n1, n1, st))) return rc;
+    if (!pair && (rc = GQ_CHOL_GEMM(false, 1, false, 2, A + o21, n, Tmp + o21, n, X + o11, n, n2, n1, n1, st))) return rc;
     return GQ_CHOL_GEMM(false, 2, false, 3, X + o21, n, X + o22, n, A + o21, n, n2, n1, n2, st);
 #undef GQ_CHOL_GEMM
 }
@@ -915,16 +941,17 @@ int h_prepare(float* H, float* W, int64_t R, int64_t C, float rel_damp, float* U
         hipLaunchKernelGGL(damp_kernel, dim3(1), dim3(1024), 0, st, H, C, rel_damp);
     }
     GQ_LAUNCH_CHECK();
-    static const bool equil = getenv("GQ_CHOL_NO_EQUIL") == nullptr;
+    const bool equil = getenv("GQ_CHOL_NO_EQUIL") == nullptr;
     if (equil) {
         eq_s = reinterpret_cast<float*>(((uintptr_t)(zc + n) + 255) & ~(uintptr_t)255);
         hipLaunchKernelGGL(equil_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, H, n, eq_s);
     }
-    hipLaunchKernelGGL(reverse_copy_kernel, dim3(4096), dim3(256), 0, st, A, H, n, eq_s);
+    // Neither A above its block diagonal nor X needs clearing: every block that is read is written first (diagonal
+    // blocks whole, zeros included).  The test that pins this fills both with NaN patterns first (GQ_POISON_X=1) and
+    // expects the same U.
+    if (getenv("GQ_POISON_X")) GQ_HIP(hipMemsetAsync(A, 0xff, 2 * (size_t)n * n * sizeof(float), st));
+    hipLaunchKernelGGL(reverse_copy_kernel, dim3((unsigned)n), dim3(256), 0, st, A, H, n, eq_s);
     GQ_LAUNCH_CHECK();
-    // X needs no clearing: every block that is read is written first (diagonal blocks whole, zeros included).  The
-    // test that pins this fills X with NaN patterns first (GQ_POISON_X=1) and expects the same U.
-    if (getenv("GQ_POISON_X")) GQ_HIP(hipMemsetAsync(X, 0xff, (size_t)n * n * sizeof(float), st));
     }
     static std::atomic<bool> attr_set{false};  // guards an idempotent call: a race sets the same value twice
     static const bool use_ref = getenv("GQ_DIAG_REF") != nullptr;  // A/B: the column-by-column kernel
@@ -938,7 +965,7 @@ int h_prepare(float* H, float* W, int64_t R, int64_t C, float rel_damp, float* U
     }
     if ((rc = chol_inv_rec(A, X, U, not_invertible, n, 0, nblk, diag_lds, st, run))) return rc;
     ProfScope ps(PT_PREP_ELEM, st);
-    hipLaunchKernelGGL(finish_u_kernel, dim3(4096), dim3(256), 0, st, U, X, n, not_invertible, eq_s);
+    hipLaunchKernelGGL(finish_u_kernel, dim3((unsigned)n), dim3(256), 0, st, U, X, n, not_invertible, eq_s);
     GQ_LAUNCH_CHECK();
     return GQ_OK;
 }
@@ -966,7 +993,7 @@ static int chol_gemm_np(float* Cm, int64_t ldc, const float* A, int64_t lda, con
     float* isa = reinterpret_cast<float*>(take((size_t)M * 4));
     float* isb = reinterpret_cast<float*>(take((size_t)N * 4));
     const p3::GemmShape sh{(int)(M / 256), (int)(N / 256), (int)(K / 32), kr, lower != 0};
-    const p3::Plan pl = p3::make_plan(sh, 0, NP == 3 ? 2 : 4, P3_MAX_SLOTS, 0);
+    const p3::Plan pl = p3::make_plan({sh}, NP == 3 ? 2 : 4, P3_MAX_SLOTS);
     if (pl.nslots < 0) GQ_FAIL(GQ_E_UNSUPPORTED, "gq_chol_gemm: the schedule needs more than %d partial slots", P3_MAX_SLOTS);
     std::vector<uint32_t> words(pl.table);
     const size_t rl_at = words.size();

@@ -127,13 +127,15 @@ __device__ __forceinline__ void g32_load_kn_full(float4 (&v)[NV], const float* B
 }
 
 constexpr int G32_COMMIT_AT = 24;  // k position (of 32) where chunk t+1 is written to LDS: 3/4 through the MFMA block
+// one output tile (tile column bxr of gx, tile row byr of gy, in dispatch order) by the calling workgroup
 template <bool TRANS_B, int MODE, bool LOWER, int KR = 0, int CHAIN = 0, int TS = 128, bool FULL = false, int NW = 4>
-__global__ __launch_bounds__(NW * 64, 2) void gemm32_kernel(float* Cmat, int64_t ldc, const float* A, int64_t lda,
-                                                        const float* B, int64_t ldb, int64_t M, int64_t N, int64_t K) {
+__device__ __forceinline__ void gemm32_tile(float* Cmat, int64_t ldc, const float* A, int64_t lda, const float* B,
+                                            int64_t ldb, int64_t M, int64_t N, int64_t K, unsigned bxr, unsigned byr,
+                                            unsigned gx, unsigned gy) {
     extern __shared__ __attribute__((aligned(16))) float g32_smem[];
     // triangular k-ranges make tile cost grow with n0 (KR 1) or m0 (KR 3): dispatch the long tiles first
-    const unsigned bx = (KR == 1) ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
-    const unsigned by = (KR == 3) ? gridDim.y - 1 - blockIdx.y : blockIdx.y;
+    const unsigned bx = (KR == 1) ? gx - 1 - bxr : bxr;
+    const unsigned by = (KR == 3) ? gy - 1 - byr : byr;
     if (LOWER && bx > by) return;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     // waves 2 x NW/2: wave tile WTM x WTN = NIM x NIN MFMA tiles (NW = 8 halves the accumulator registers
@@ -266,6 +268,65 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm32_kernel(float* Cmat, int64_t
                 }
             }
         }
+}
+
+template <bool TRANS_B, int MODE, bool LOWER, int KR = 0, int CHAIN = 0, int TS = 128, bool FULL = false, int NW = 4>
+__global__ __launch_bounds__(NW * 64, 2) void gemm32_kernel(float* Cmat, int64_t ldc, const float* A, int64_t lda,
+                                                        const float* B, int64_t ldb, int64_t M, int64_t N, int64_t K) {
+    gemm32_tile<TRANS_B, MODE, LOWER, KR, CHAIN, TS, FULL, NW>(Cmat, ldc, A, lda, B, ldb, M, N, K, blockIdx.x, blockIdx.y,
+                                                               gridDim.x, gridDim.y);
+}
+
+// Two independent products of one Cholesky recursion node in ONE launch (whole 64-tiles):
+//   blocks [0, n_a):  C_a -= A_a A_a^T, lower tiles     (A22 -= L21 L21^T,  gemm32_kernel<true, 0, true, 0>)
+//   the rest:         C_b  = A_b B_b,   k >= n0          (L21 X11,           gemm32_kernel<false, 1, false, 2>)
+// Both need only L21; alone each is a latency-bound launch of a few microseconds on a fraction of the chip.
+struct G32Pair {
+    float* Ca; const float* Aa; int64_t Ma, Ka;          // SYRK update: [Ma, Ma] -= [Ma, Ka] [Ma, Ka]^T
+    float* Cb; const float* Ab; const float* Bb; int64_t Mb, Nb, Kb;
+    int64_t ld;                                          // one leading dimension: everything lives in n x n matrices
+    unsigned gxa, n_a, gxb, gyb;                         // the SYRK's lower tiles are enumerated row by row
+};
+template <int TS>  // 64 (a template so that every translation unit including this header may instantiate it)
+__global__ __launch_bounds__(256, 2) void gemm32_pair_kernel(const G32Pair p) {
+    unsigned id = blockIdx.x;
+    if (id < p.n_a) {
+        // lower tile (by, bx), bx <= by, from the linear index id = by (by + 1) / 2 + bx
+        unsigned by = (unsigned)((__fsqrt_rn(8.0f * (float)id + 1.0f) - 1.0f) * 0.5f);
+        while ((by + 1) * (by + 2) / 2 <= id) ++by;
+        while (by * (by + 1) / 2 > id) --by;
+        const unsigned bx = id - by * (by + 1) / 2;
+        gemm32_tile<true, 0, true, 0, 0, TS, true, 4>(p.Ca, p.ld, p.Aa, p.ld, p.Aa, p.ld, p.Ma, p.Ma, p.Ka, bx, by, p.gxa, p.gxa);
+    } else {
+        id -= p.n_a;
+        gemm32_tile<false, 1, false, 2, 0, TS, true, 4>(p.Cb, p.ld, p.Ab, p.ld, p.Bb, p.ld, p.Mb, p.Nb, p.Kb, id % p.gxb,
+                                                        id / p.gxb, p.gxb, p.gyb);
+    }
+}
+inline int launch_gemm32_pair(float* Ca, const float* Aa, int64_t Ma, int64_t Ka, float* Cb, const float* Ab, const float* Bb,
+                              int64_t Mb, int64_t Nb, int64_t Kb, int64_t ld, hipStream_t st) {
+    static std::atomic<bool> attr_set{false};
+    if (!attr_set) {
+        GQ_HIP(hipFuncSetAttribute((const void*)gemm32_pair_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, G32<64>::LDS_BYTES));
+        attr_set = true;
+    }
+    G32Pair p;
+    p.Ca = Ca; p.Aa = Aa; p.Ma = Ma; p.Ka = Ka;
+    p.Cb = Cb; p.Ab = Ab; p.Bb = Bb; p.Mb = Mb; p.Nb = Nb; p.Kb = Kb;
+    p.ld = ld;
+    p.gxa = (unsigned)(Ma / 64);
+    p.n_a = p.gxa * (p.gxa + 1) / 2;
+    p.gxb = (unsigned)(Nb / 64);
+    p.gyb = (unsigned)(Mb / 64);
+    hipLaunchKernelGGL(gemm32_pair_kernel<64>, dim3(p.n_a + p.gxb * p.gyb), dim3(256), G32<64>::LDS_BYTES, st, p);
+    GQ_LAUNCH_CHECK();
+    return GQ_OK;
+}
+// does launch_gemm32 pick whole 64-tiles for a Cholesky-node product of this size?
+inline bool gemm32_uses_64_full(int64_t M, int64_t N, int64_t K, bool lower) {
+    static const int64_t max64 = getenv("GQ_GEMM32_64_MAX") ? atol(getenv("GQ_GEMM32_64_MAX")) : 256;
+    const int64_t tiles128 = ((M + 127) / 128) * ((N + 127) / 128) / (lower ? 2 : 1);
+    return tiles128 < max64 && M % 64 == 0 && N % 64 == 0 && K % TK == 0;
 }
 
 // ---- the GPTQ far trailing update on whole tiles: C = (..((C - A_0 B_0) - A_1 B_1)..), NN, 128x128 tiles ----

@@ -537,30 +537,39 @@ inline int tile_len(const GemmShape& s, int tm, int tn) {
 // workgroup ends within a few chunks of T, with at most ~33 cut tiles per XCD.  Unit lengths are multiples of `gran`
 // chunks (NP = 3: 2, NP = 2: 4; every k boundary is a multiple of 128 = 4 chunks); the cost of a unit is its length plus
 // OVH chunks (prologue + epilogue).
-inline Plan make_plan(const GemmShape& s, int prob, int gran, int max_slots, int slot_base) {
+inline Plan make_plan(const std::vector<GemmShape>& shapes, int gran, int max_slots) {
     constexpr int OVH = 2, MINP = 8;
-    struct Tile { int tm, tn, len; };
+    const int slot_base = 0;
+    struct Tile { int prob, tm, tn, len; };
     std::vector<Tile> tiles;
-    const bool by_m = s.kr == 3;
-    const int bm = by_m ? 4 : 8, bn = by_m ? 8 : 4;
-    const int nbm = (s.MT + bm - 1) / bm, nbn = (s.NT + bn - 1) / bn;
-    std::vector<std::pair<int, std::pair<int, int>>> blocks;  // (-maxlen, (bi, bj))
-    for (int bi = 0; bi < nbm; ++bi)
-        for (int bj = 0; bj < nbn; ++bj) {
-            int mx = 0;
-            for (int tm = bi * bm; tm < std::min(s.MT, (bi + 1) * bm); ++tm)
-                for (int tn = bj * bn; tn < std::min(s.NT, (bj + 1) * bn); ++tn)
-                    if (!s.lower || tm >= tn) mx = std::max(mx, tile_len(s, tm, tn));
-            if (mx > 0) blocks.push_back({-mx, {bi, bj}});
-        }
-    std::stable_sort(blocks.begin(), blocks.end());
-    for (auto& b : blocks)
-        for (int tm = b.second.first * bm; tm < std::min(s.MT, (b.second.first + 1) * bm); ++tm)
-            for (int tn = b.second.second * bn; tn < std::min(s.NT, (b.second.second + 1) * bn); ++tn)
+    struct Blk { int neg_len, prob, bi, bj; };
+    std::vector<Blk> blocks;
+    for (int prob = 0; prob < (int)shapes.size(); ++prob) {
+        const GemmShape& s = shapes[prob];
+        const bool by_m = s.kr == 3;
+        const int bm = by_m ? 4 : 8, bn = by_m ? 8 : 4;
+        const int nbm = (s.MT + bm - 1) / bm, nbn = (s.NT + bn - 1) / bn;
+        for (int bi = 0; bi < nbm; ++bi)
+            for (int bj = 0; bj < nbn; ++bj) {
+                int mx = 0;
+                for (int tm = bi * bm; tm < std::min(s.MT, (bi + 1) * bm); ++tm)
+                    for (int tn = bj * bn; tn < std::min(s.NT, (bj + 1) * bn); ++tn)
+                        if (!s.lower || tm >= tn) mx = std::max(mx, tile_len(s, tm, tn));
+                if (mx > 0) blocks.push_back({-mx, prob, bi, bj});
+            }
+    }
+    std::stable_sort(blocks.begin(), blocks.end(), [](const Blk& a, const Blk& b) { return a.neg_len < b.neg_len; });
+    for (auto& b : blocks) {
+        const GemmShape& s = shapes[b.prob];
+        const bool by_m = s.kr == 3;
+        const int bm = by_m ? 4 : 8, bn = by_m ? 8 : 4;
+        for (int tm = b.bi * bm; tm < std::min(s.MT, (b.bi + 1) * bm); ++tm)
+            for (int tn = b.bj * bn; tn < std::min(s.NT, (b.bj + 1) * bn); ++tn)
                 if (!s.lower || tm >= tn) {
                     const int len = tile_len(s, tm, tn);
-                    if (len > 0) tiles.push_back({tm, tn, len});
+                    if (len > 0) tiles.push_back({b.prob, tm, tn, len});
                 }
+    }
     struct Piece { int tile, cb, ce; };
     long total = 0;
     for (auto& t : tiles) total += t.len + OVH;
@@ -656,7 +665,7 @@ inline Plan make_plan(const GemmShape& s, int prob, int gran, int max_slots, int
         if (npieces[t] > 1) {
             first_slot[t] = slot_base + slots;
             slots += npieces[t];
-            pl.rlist.push_back((uint32_t)prob << 28 | (uint32_t)tiles[t].tm << 14 | (uint32_t)tiles[t].tn);
+            pl.rlist.push_back((uint32_t)tiles[t].prob << 28 | (uint32_t)tiles[t].tm << 14 | (uint32_t)tiles[t].tn);
             pl.rlist.push_back((uint32_t)first_slot[t] << 8 | (uint32_t)npieces[t]);
         }
     pl.nslots = slots;
@@ -666,7 +675,7 @@ inline Plan make_plan(const GemmShape& s, int prob, int gran, int max_slots, int
         pl.table[b] = at;
         for (auto& p : wg[b]) {
             const Tile& t = tiles[p.tile];
-            pl.table.push_back((uint32_t)prob << 28 | (uint32_t)t.tm << 14 | (uint32_t)t.tn);
+            pl.table.push_back((uint32_t)t.prob << 28 | (uint32_t)t.tm << 14 | (uint32_t)t.tn);
             pl.table.push_back((uint32_t)p.cb);
             pl.table.push_back((uint32_t)p.ce);
             pl.table.push_back(npieces[p.tile] > 1 ? (uint32_t)(first_slot[p.tile] + seen[p.tile]++ + 1) : 0u);

@@ -174,8 +174,9 @@ def test_gptq_lookahead_equals_per_block_updates(ops, R):
 def test_h_prepare_never_reads_unwritten_scratch(ops):
     """gq_h_prepare does not clear its scratch: the inverse factor X is written block by block (diagonal blocks
     whole, with their zeros) and the k-range skips of the GEMMs never leave the written blocks.  With X filled with
-    NaN patterns beforehand (GQ_POISON_X=1) the result must be the same, bit for bit, at a size that takes every
-    level of the recursion (fp32 and split-bf16 GEMMs, 64- and 128-tiles)."""
+    NaN patterns beforehand (GQ_POISON_X=1; r03: A above its block diagonal too) the result must be the same, bit for
+    bit, at a size that takes every level of the recursion below the image GEMMs (fp32 and split-bf16 GEMMs, 64- and
+    128-tiles; the image levels: tests/test_gpu_round3.py)."""
     torch.manual_seed(4)
     C = 4096 + 896
     X = (torch.randn(2 * C, C, device="cuda") * torch.exp(torch.randn(C, device="cuda") * 0.5)).half()

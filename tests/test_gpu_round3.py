@@ -1,0 +1,159 @@
+"""Round 3, on the GPU: the image GEMMs of the Cholesky chain (gq_gemm3p.hpp) and what came with them."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from gptq_gguf_toolkit_amd import ops as _ops
+    return _ops
+
+
+def _poison_upper_blocks(T):
+    """128x128 blocks beyond the block diagonal of a lower-triangular operand are never written by the chain."""
+    n = T.shape[0] // 128
+    for i in range(n):
+        T[128 * i:128 * i + 128, 128 * (i + 1):] = float("nan")
+    return T
+
+
+# (trans_b, mode, k_range, lower): the four products of a recursion node + the two plain forms
+CASES = [(True, 1, 1, False), (True, 0, 0, True), (False, 1, 2, False), (False, 2, 3, False), (True, 1, 0, False),
+         (False, 0, 0, False)]
+
+
+@pytest.mark.parametrize("planes", [2, 3])
+@pytest.mark.parametrize("case", CASES)
+def test_chol_gemm_against_fp64(ops, planes, case):
+    """gq_chol_gemm (linalg_utils.py:8-12's level-3 work as this build does it): every mode / k-range against fp64.
+    Tolerance class, stated: |C - C64| <= 2e-6 (|A||B| + |C0|) componentwise (an fp32 sgemm of these sizes: ~1e-6);
+    rows of A span e^+-4 in scale, triangular operands carry NaN in the blocks the chain never writes."""
+    trans_b, mode, kr, lower = case
+    dev = "cuda"
+    torch.manual_seed(10 * planes + kr)
+    for n in (512, 1024):
+        M = N = K = n
+        if kr == 0 and not lower:
+            M, N, K = n, 768, 640
+        A = torch.randn(M, K, device=dev) * torch.exp(torch.randn(M, 1, device=dev) * 2)
+        B = (torch.randn(N, K, device=dev) if trans_b else torch.randn(K, N, device=dev)) * 0.1
+        if kr == 3:
+            A = _poison_upper_blocks(torch.tril(A))
+        if kr in (1, 2):
+            B = _poison_upper_blocks(torch.tril(B))
+        if lower:
+            B = A
+        C0 = torch.randn(M, N, device=dev)
+        Cm = C0.clone()
+        ops.chol_gemm(Cm, A, B, trans_b, mode, kr, lower, planes)
+        A64, B64 = torch.nan_to_num(A).double(), torch.nan_to_num(B).double()
+        P = A64 @ (B64.T if trans_b else B64)
+        ref = C0.double() - P if mode == 0 else (P if mode == 1 else -P)
+        bound = A64.abs() @ (B64.abs().T if trans_b else B64.abs()) + C0.abs().double()
+        msk = torch.ones(M, N, device=dev, dtype=torch.bool)
+        if lower:  # only 256-tiles with tile row >= tile col are computed
+            msk = torch.ones(M // 256, N // 256, device=dev).tril().bool().repeat_interleave(256, 0).repeat_interleave(256, 1)
+            assert torch.equal(Cm[~msk], C0[~msk])
+        assert bool(torch.isfinite(Cm[msk]).all())
+        err = ((Cm.double() - ref).abs() / bound)[msk].max().item()
+        assert err < 2e-6, (case, planes, n, err)
+        Cm2 = C0.clone()  # deterministic: the K-split partial sums are added in fixed order
+        ops.chol_gemm(Cm2, A, B, trans_b, mode, kr, lower, planes)
+        assert torch.equal(Cm, Cm2)
+
+
+def _hessian(C, seed, spread=0.5, outlier=20.0):
+    torch.manual_seed(seed)
+    sig = torch.exp(torch.randn(C, device="cuda") * spread)
+    sig[torch.randperm(C, device="cuda")[:8]] *= outlier
+    X = (torch.randn(2 * C, C, device="cuda") * sig).half()
+    H = torch.zeros(C, C, device="cuda")
+    from gptq_gguf_toolkit_amd import ops as _ops
+    _ops.h_accumulate(H, X, 0.0, 2.0 / 4)
+    return H
+
+
+def test_h_prepare_image_levels_never_read_unwritten_scratch(ops):
+    """As test_h_prepare_never_reads_unwritten_scratch, at a width whose two top recursion levels run on the image
+    GEMMs (7168 = 3584 | 3584 = (1792 | 1792) x 2): A above its block diagonal and X are NaN-filled first."""
+    C = 7168
+    H = _hessian(C, 4)
+    W = torch.randn(64, C, device="cuda")
+    U0, f0 = ops.h_prepare(H.clone(), W.clone(), 0.01)
+    os.environ["GQ_POISON_X"] = "1"
+    try:
+        U1, f1 = ops.h_prepare(H.clone(), W.clone(), 0.01)
+    finally:
+        os.environ.pop("GQ_POISON_X", None)
+    assert int(f0.item()) == 0 and int(f1.item()) == 0
+    assert bool(torch.isfinite(U1).all()) and torch.equal(U0, U1)
+
+
+def test_equilibration_is_exact_for_the_scale_invariant_kernels(ops):
+    """gq_h_prepare factorises S H S with S = powers of two (H_jj S_jj^2 in [0.5, 2)) and returns U_hat S.  Scaling by
+    powers of two commutes with fp32 arithmetic, so with the image GEMMs off (fp32 + exact-split bf16 kernels only) U
+    is the same bit for bit with and without it -- the chain below the image levels is what r02 shipped."""
+    C = 4096
+    H = _hessian(C, 5)
+    W = torch.randn(64, C, device="cuda")
+    os.environ["GQ_CHOL_3P_MIN"] = "0"
+    try:
+        U0, _ = ops.h_prepare(H.clone(), W.clone(), 0.01)
+        os.environ["GQ_CHOL_NO_EQUIL"] = "1"
+        U1, _ = ops.h_prepare(H.clone(), W.clone(), 0.01)
+    finally:
+        os.environ.pop("GQ_CHOL_3P_MIN", None)
+        os.environ.pop("GQ_CHOL_NO_EQUIL", None)
+    assert torch.equal(U0, U1)
+
+
+@pytest.mark.parametrize("mode", ["fp16x2", "bf16x3"])
+def test_image_chain_accuracy_wide_channel_scales(ops, mode):
+    """U = chol_upper((H + damp)^-1) against the fp64 chain on Hessians whose channel scales span five decades plus
+    x1000 outliers (H = S Z^T Z S built in fp32): the row-scaled fp16 images need the equilibration for their error
+    bound; asserted rowwise -- max_j |U_ij - U64_ij| <= 4e-6 max_j |U64_ij| for every row -- and on the diagonal."""
+    C = 3584
+    torch.manual_seed(7)
+    Z = torch.randn(2 * C, C, device="cuda").half()
+    H = torch.zeros(C, C, device="cuda")
+    ops.h_accumulate(H, Z, 0.0, 2.0 / 4)
+    sig = torch.exp(torch.randn(C, device="cuda") * 2.5)
+    sig[torch.randperm(C, device="cuda")[:8]] *= 1000.0
+    H = H * sig[:, None] * sig[None, :]
+    H = (H + H.T) * 0.5
+    W = torch.randn(64, C, device="cuda")
+    if mode == "bf16x3":
+        os.environ["GQ_CHOL_BF16X3"] = "1"
+    try:
+        Hc = H.clone()
+        U, flag = ops.h_prepare(Hc, W.clone(), 0.01)
+    finally:
+        os.environ.pop("GQ_CHOL_BF16X3", None)
+    assert int(flag.item()) == 0
+    Hd = Hc.double()  # damped in place by the call (gptq.py:315-316)
+    ref = torch.linalg.cholesky(torch.cholesky_inverse(torch.linalg.cholesky(Hd)), upper=True)
+    d = (U.double() - ref).abs()
+    assert (d.max(dim=1).values / ref.abs().max(dim=1).values).max().item() < 4e-6
+    assert (d.diagonal() / ref.diagonal()).max().item() < 4e-6
+
+
+def test_paired_node_launches_change_nothing(ops):
+    """Below the image levels a recursion node issues its SYRK update and L21 X11 as ONE launch of 64-tiles
+    (gemm32_pair_kernel); every output element is the same k-ordered fp32 chain as in the two separate launches
+    (GQ_CHOL_NO_PAIR=1), so U is identical bit for bit."""
+    C = 4096 + 896
+    H = _hessian(C, 6)
+    W = torch.randn(64, C, device="cuda")
+    U0, f0 = ops.h_prepare(H.clone(), W.clone(), 0.01)
+    os.environ["GQ_CHOL_NO_PAIR"] = "1"
+    try:
+        U1, f1 = ops.h_prepare(H.clone(), W.clone(), 0.01)
+    finally:
+        os.environ.pop("GQ_CHOL_NO_PAIR", None)
+    assert int(f0.item()) == 0 and torch.equal(U0, U1)
