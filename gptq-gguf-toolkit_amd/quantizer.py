@@ -451,8 +451,19 @@ class Quantizer:
         # gq_rtn_quantize reproduces that per-op rounding.  non_block_fp32 opts into an fp32 search instead.
         if w.dtype != torch.float32 and self.non_block_fp32:
             w = w.float()
+        # quant_scale is forwarded like the reference does (quantizer.py:293-295; grid / maxshrink stay at
+        # Quantizer.configure's defaults there, quant_utils.py:65-66).  make_k_quants ignores it.
+        quant_scale = getattr(kw.get("quant_scale", "absmax"), "value", kw.get("quant_scale", "absmax"))
+        if quant_scale == "mse" and w.dtype != torch.float32 and \
+                q_type in (GGMLQuantizationType.Q3_K, GGMLQuantizationType.Q6_K):
+            # the reference cannot run this combination: make_quants builds min_loss in fp32 (quant_utils.py:165) and
+            # index_puts the model-dtype loss into it (:187) -> RuntimeError; same error class here, before any work
+            raise RuntimeError(
+                f"quant_scale='mse' on a {w.dtype} weight with {q_type.name}: the reference raises here (Index put "
+                "requires the source and destination dtypes match, quant_utils.py:187). Use --dtype float32 or "
+                "--non_block_fp32.")
         return _ops.rtn_quantize(w.contiguous(), int(q_type), kw.get("rmin", -1.0), kw.get("rdelta", 0.1),
-                                 kw.get("nstep", 20))
+                                 kw.get("nstep", 20), quant_scale=quant_scale)
 
     def _quant_and_save_non_block(self, name, module, quant_config):
         if self.verbose:

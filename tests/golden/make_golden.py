@@ -476,10 +476,49 @@ def g13_two_rank():
     save("g13_two_rank", **out)
 
 
+def g15_rtn_mse():
+    """_quant_non_block_module with quantizer_kwargs["quant_scale"] = "mse" (quantizer.py:293-295 forwards it; the
+    grid / maxshrink stay at Quantizer.configure's defaults 100 / 0.8): embed-like weights in fp32 / fp16 / bf16 with
+    entries beyond +-32 present -- below that every candidate of the grid search quantizes to q_int = 0 and the branch
+    returns the absmax scale (g12) -- for the two types that use make_quants, plus Q4_K (make_k_quants ignores it).
+    Found on the way: with fp16 / bf16 weights the reference RAISES for Q3_K / Q6_K (recorded as `<tag>_<type>_raises`)."""
+    set_sqrt("ieee")
+    out = {}
+    R, C = 40, 512
+    torch.manual_seed(150)
+    W = torch.randn(R, C) * 0.05
+    W[:, 7] *= 900.0             # one hot column: |w| up to ~100
+    W[5, 256:272] = torch.linspace(-60.0, 75.0, 16)
+    W[6, :16] = 33.0             # constant group beyond 32
+    W[7] = 0.0
+    W[8, 100] = -48.5
+    drv = RefDriver.__new__(RefDriver)
+    for dt, tag in ((torch.float32, "f32"), (torch.float16, "f16"), (torch.bfloat16, "bf16")):
+        Wl = W.to(dt)
+        out[f"W_{tag}"] = Wl.float().numpy()
+        for qt in (T.Q3_K, T.Q6_K, T.Q4_K):
+            drv.quantizer_kwargs = {"quant_scale": "mse"}
+            try:
+                q, d, s, dmin, m = drv._quant_non_block_module(Wl.clone(), qt)
+            except RuntimeError as e:
+                # fp16 / bf16 weights + make_quants: quant_utils.py:165 creates min_loss in fp32, :187 index_puts the
+                # model-dtype loss into it -> "Index put requires the source and destination dtypes match"
+                out[f"{tag}_{qt.name}_raises"] = np.array(str(e).splitlines()[0])
+                continue
+            out[f"{tag}_{qt.name}_q"] = q.numpy()
+            out[f"{tag}_{qt.name}_d"], out[f"{tag}_{qt.name}_dmin"] = u16(d), u16(dmin)
+            out[f"{tag}_{qt.name}_s"], out[f"{tag}_{qt.name}_m"] = s.numpy(), m.numpy()
+            drv.quantizer_kwargs = {}
+            qa, da, sa, _, _ = drv._quant_non_block_module(Wl.clone(), qt)
+            # how much the branch matters on this weight (reported by the tests, not asserted)
+            out[f"{tag}_{qt.name}_differs_from_absmax"] = np.array(float((qa != q).float().mean()))
+    save("g15_rtn_mse", **out)
+
+
 def _main_all():
     torch.set_num_threads(8)
     for fn in (g1_make_quants, g2_scale_search, g3_elementwise, g4_g5_hessian, g6_g7_step_and_pack,
-               g8_g9_rtn_dequant, g11_act_order, g12_mse_scale, g13_two_rank):
+               g8_g9_rtn_dequant, g11_act_order, g12_mse_scale, g13_two_rank, g15_rtn_mse):
         print(fn.__name__)
         fn()
     g10_driver()
@@ -568,5 +607,7 @@ if __name__ == "__main__":
         g12_mse_scale()
     elif "g13" in sys.argv[1:]:
         g13_two_rank()
+    elif "g15" in sys.argv[1:]:
+        g15_rtn_mse()
     else:
         _main_all()

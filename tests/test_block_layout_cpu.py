@@ -71,3 +71,29 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
                 src = open(os.path.join(dp, f)).read()
                 assert "oracle" not in src.replace("# oracle", "") or f == "README.md", f"{f} mentions the oracle"
+
+
+def test_integration_doc_search_struct_matches_the_header(tmp_path):
+    """INTEGRATION.md's binding snippet declares `_Search`; a maintainer who copies it passes that struct to
+    gq_gptq_quantize, which reads all of gq_search_t.  The snippet's class is executed as written and compared, size and
+    field offsets, with the header's struct as gcc lays it out (r02: the doc still showed the 3-field ABI-1 struct)."""
+    import subprocess
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    m = re.search(r"class _Search\(ctypes\.Structure\):.*?\n((?:    .*\n)+)", doc)
+    assert m, "INTEGRATION.md no longer shows the _Search binding"
+    ns = {"ctypes": ctypes}
+    exec("class _Search(ctypes.Structure):\n" + m.group(1), ns)
+    S = ns["_Search"]
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "gptq_gguf.h"\n'
+                   'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(gq_search_t), offsetof(gq_search_t, rmin),'
+                   ' offsetof(gq_search_t, rdelta), offsetof(gq_search_t, nstep), offsetof(gq_search_t, quant_scale),'
+                   ' offsetof(gq_search_t, grid), offsetof(gq_search_t, maxshrink)); return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    size, *offs = map(int, subprocess.check_output([str(exe)]).split())
+    assert ctypes.sizeof(S) == size
+    assert [getattr(S, n).offset for n, _ in S._fields_] == offs
+    from gptq_gguf_toolkit_amd import _cabi
+    assert ctypes.sizeof(_cabi.Search) == size
+    assert [n for n, _ in S._fields_] == [n for n, _ in _cabi.Search._fields_]

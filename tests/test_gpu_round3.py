@@ -157,3 +157,23 @@ def test_paired_node_launches_change_nothing(ops):
     finally:
         os.environ.pop("GQ_CHOL_NO_PAIR", None)
     assert int(f0.item()) == 0 and torch.equal(U0, U1)
+
+
+@pytest.mark.parametrize("name", ["Q3_K", "Q6_K", "Q4_K"])
+def test_rtn_quant_scale_mse_golden(ops, name):
+    """gq_rtn_quantize with gq_search_t.quant_scale = 1 on the fp32 embed-like weight of G15 (entries beyond +-32, where
+    the grid search of quant_utils.py:164-191 really differs from absmax): the reference's own
+    _quant_non_block_module(quant_scale="mse") run, bit for bit; Q4_K (make_k_quants) ignores the switch."""
+    import numpy as np
+    from conftest import load_golden
+    g = load_golden("g15_rtn_mse")
+    t = {"Q3_K": 11, "Q6_K": 14, "Q4_K": 12}[name]
+    W = torch.from_numpy(g["W_f32"].copy()).cuda()
+    q, d, s, dmin, m = ops.rtn_quantize(W, t, quant_scale="mse")
+    assert np.array_equal(q.cpu().numpy(), g[f"f32_{name}_q"])
+    assert np.array_equal(d.cpu().view(torch.int16).numpy().view(np.uint16), g[f"f32_{name}_d"])
+    assert np.array_equal(s.cpu().numpy(), g[f"f32_{name}_s"])
+    assert np.array_equal(dmin.cpu().view(torch.int16).numpy().view(np.uint16), g[f"f32_{name}_dmin"])
+    assert np.array_equal(m.cpu().numpy(), g[f"f32_{name}_m"])
+    qa, *_ = ops.rtn_quantize(W, t)  # absmax
+    assert bool((qa != q).any()) == (name != "Q4_K")

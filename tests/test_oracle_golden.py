@@ -305,3 +305,26 @@ def test_obq_step_per_row_grid(oracle):
         assert np.array_equal(q[:, i], qq.astype(np.uint8)) and np.array_equal(Wd[:, i], wq)
         err = ((blk[:, i] - wq) / U[i, i]).astype(np.float32)
         blk[:, i:] = blk[:, i:] + (-err)[:, None] * U[i, i:128][None]
+
+
+@pytest.mark.parametrize("name", ["Q3_K", "Q6_K", "Q4_K"])
+def test_g15_rtn_with_quant_scale_mse(oracle, name):
+    """_quant_non_block_module with quant_scale="mse" (quantizer.py:293-295) on an embed-like fp32 weight with entries
+    beyond +-32: the reference's run (G15), bit for bit.  With fp16 / bf16 weights the reference raises for the two
+    make_quants types (recorded in the fixture; the driver mirrors that, tests/test_host_logic_cpu.py)."""
+    g = load_golden("g15_rtn_mse")
+    t = TYPES[name]
+    oracle.set_quant_scale("mse")
+    try:
+        q, d, s, dmin, m = oracle.rtn_quantize(g["W_f32"], t)
+    finally:
+        oracle.set_quant_scale("absmax")
+    assert np.array_equal(q, g[f"f32_{name}_q"])
+    assert np.array_equal(d, g[f"f32_{name}_d"]) and np.array_equal(s, g[f"f32_{name}_s"])
+    assert np.array_equal(dmin, g[f"f32_{name}_dmin"]) and np.array_equal(m, g[f"f32_{name}_m"])
+    if name != "Q4_K":
+        assert float(g[f"f32_{name}_differs_from_absmax"]) > 0.0  # the branch matters on this weight
+        for tag in ("f16", "bf16"):
+            assert "Index put requires" in str(g[f"{tag}_{name}_raises"])
+    else:
+        assert float(g["f32_Q4_K_differs_from_absmax"]) == 0.0 and "bf16_Q4_K_q" in g.files
