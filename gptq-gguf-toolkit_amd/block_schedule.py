@@ -29,8 +29,9 @@ schedules kernels:
                         rank; the dequantized weight is written back (quantizer.py:257-264).
 quantize() never synchronises the host with the device (dense Linears): everything is ordered by streams and
 events, so the caller's next launches (the block's second forward, or the next block of a benchmark) queue up
-behind the chains.  The device-side flags of the reused factorisations are kept in `BlockSchedule.unverified`
-and asserted by `verify()` (the Quantizer calls it once, at the end of the model).
+behind the chains.  The device-side flags of the reused factorisations are kept in `BlockSchedule.unverified`,
+sent to pinned host memory behind an event after every block and asserted by `verify()` as they arrive (the
+Quantizer: after every block without waiting, and once more, waiting, at the end of the model).
 """
 import contextlib
 import os
@@ -165,13 +166,50 @@ class BlockSchedule:
             ev.synchronize()  # recorded during the first sample of the block: long complete
         return dict(zip(followers, host.tolist()))
 
+    _staged_checks: List[Any] = []  # (pinned host bool, event): flags on their way to the host
+
     @classmethod
-    def verify(cls) -> None:
-        """One host read for all blocks so far: no reused factorisation saw a different column set."""
+    def stage_verify(cls) -> None:
+        """Send the flags collected so far to pinned host memory behind an event (no synchronisation)."""
         flags, cls.unverified = cls.unverified, []
-        if flags and bool(torch.stack([f.reshape(()) for f in flags]).any().item()):
-            raise RuntimeError("a Linear reused its leader's Cholesky factor although their dead / zero-column sets "
-                               "differ (gq_w_prepare flag)")
+        if not flags:
+            return
+        anyf = torch.stack([f.reshape(()) for f in flags]).any().reshape(1)
+        if anyf.is_cuda:
+            host = torch.empty(1, dtype=torch.bool, pin_memory=True)
+            host.copy_(anyf, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(anyf.device))
+            cls._staged_checks.append((host, ev))
+        else:
+            cls._staged_checks.append((anyf, None))
+
+    @classmethod
+    def verify(cls, wait: bool = True) -> None:
+        """No reused factorisation saw a different column set.  wait=False (the Quantizer, once per block): only the
+        flags that have already arrived are looked at -- a block's flags are checked while the next block runs, so a
+        mismatch stops the run one block later at most, without ever stalling the host; wait=True (end of the
+        model, tests): everything, one host read."""
+        cls.stage_verify()
+        keep = []
+        for host, ev in cls._staged_checks:
+            if ev is not None and not wait and not ev.query():
+                keep.append((host, ev))
+                continue
+            if ev is not None:
+                ev.synchronize()
+            if bool(host.item()):
+                cls._staged_checks = []
+                raise RuntimeError("a Linear reused its leader's Cholesky factor although their dead / zero-column sets "
+                                   "differ (gq_w_prepare flag)")
+        cls._staged_checks = keep
+
+    @classmethod
+    def discard_checks(cls) -> None:
+        """Drop every pending flag (Quantizer.quantize's finally: a run that raised must not leave flags behind for
+        the next Quantizer of the process)."""
+        cls.unverified = []
+        cls._staged_checks = []
 
     def leaders(self) -> List[GPTQ]:
         return [h for h in self.handles.values() if h.shared_H_with is None]

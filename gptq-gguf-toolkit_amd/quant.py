@@ -112,9 +112,20 @@ def load_calibration(path_or_name, num_tokens, seq_len, tokenizer):
 
 def main(argv=None):
     args = parse_args(argv)
-    from transformers import AutoModelForCausalLM, AutoTokenizer
+    if args.eval_perplexity:  # refused BEFORE any work (the reference evaluates WikiText-2 here: a dataset download)
+        raise SystemExit("--eval_perplexity is not available in this package (WikiText-2 needs a dataset download); "
+                         "run the quantization without it and evaluate the saved model separately")
     if dist.is_available() and "RANK" in os.environ:
         dist.init_process_group(backend="nccl", init_method="env://")  # RCCL
+    try:
+        _run(args)
+    finally:  # also when the run raises: torchrun then reports the real error, not a hung rendezvous
+        if dist_utils.is_dist_available_and_initialized():
+            dist.destroy_process_group()
+
+
+def _run(args):
+    from transformers import AutoModelForCausalLM, AutoTokenizer
     world_size, rank = dist_utils.get_world_size(), dist_utils.get_rank()
     device = f"cuda:{int(os.environ.get('LOCAL_RANK', rank))}"
     torch.cuda.set_device(device)
@@ -157,11 +168,6 @@ def main(argv=None):
     t2 = time.perf_counter()
     dist_utils.print_on_main(f"Quantization took {(t2 - t1)} s.")
     dist_utils.barrier()
-    if args.eval_perplexity:
-        raise NotImplementedError("--eval_perplexity: the WikiText-2 evaluation (a dataset download) is outside this "
-                                  "package; the quantized model was written to " + args.save_dir)
-    if dist_utils.is_dist_available_and_initialized():
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

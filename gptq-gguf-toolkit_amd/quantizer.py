@@ -19,6 +19,7 @@ GQ_TIMING=gpu, HIP-event seconds per phase on the main stream).
 """
 import os
 import queue
+import sys
 import threading
 import time
 from typing import Any, Dict, Iterable, List, Optional
@@ -95,24 +96,34 @@ def _writer_process(save_dir, slots, inbox, freeq, outbox):
     """Body of the writer PROCESS.  `slots` are the parent's pinned staging buffers (shared memory): a message names
     a slot and the layout of a module's five tensors inside it; they are copied out, the slot goes back to the parent,
     then torch.save runs here -- with this process's interpreter lock, not the parent's."""
+    failed = None
+    busy = 0.0
     try:
         torch.set_num_threads(1)
-        busy = 0.0
         while True:
             item = inbox.get()
             if item is None:
                 break
             t0 = time.perf_counter()
-            if item[0] == "slot":
-                _, sid, name, q_type, layout = item
-                host = [v.clone() for v in _slot_views(slots[sid], layout)]
-                freeq.put(sid)
-            else:  # a module larger than a slot: its host tensors came through the queue
-                _, name, q_type, host = item
-            _write_data_pth(save_dir, name, q_type, *host)
-            del item, host
+            try:
+                if item[0] == "slot":
+                    _, sid, name, q_type, layout = item
+                    try:
+                        host = [v.clone() for v in _slot_views(slots[sid], layout)] if failed is None else None
+                    finally:
+                        freeq.put(sid)  # ALWAYS handed back: the parent's copier must never wait on a writer that failed
+                else:  # a module larger than a slot: its host tensors came through the queue
+                    _, name, q_type, host = item
+                if failed is None:
+                    _write_data_pth(save_dir, name, q_type, *host)
+            except BaseException as e:  # disk full, unwritable save_dir, ...: reported at once, later items are dropped
+                if failed is None:
+                    failed = f"{name}: {e!r}"
+                    outbox.put(("error", failed))
+            del item
+            host = None
             busy += time.perf_counter() - t0
-        outbox.put(("ok", busy))
+        outbox.put(("ok", busy) if failed is None else ("error", failed))
     except BaseException as e:  # reported to the parent
         outbox.put(("error", repr(e)))
 
@@ -135,12 +146,25 @@ class _Saver:
         self.thread = None
         self.proc = self.inbox = self.outbox = self.freeq = None
         self.slots: List[torch.Tensor] = []
+        self._writer_dead = False
+        self._final = None
         self.use_process = os.environ.get("GQ_SAVE_MODE", "process") == "process"
         self.slot_bytes = int(os.environ.get("GQ_SAVE_SLOT_MB", 704)) << 20  # embed_tokens of Llama-3 in Q4_K: 657 MB
 
     def _start_process(self):
         import torch.multiprocessing as tmp
         ctx = tmp.get_context("spawn")
+        # the slots are files in /dev/shm: ftruncate succeeds on a small tmpfs (Docker's default is 64 MB) and the
+        # first write into the slot then kills the process with SIGBUS -- ask before allocating
+        need = 2 * self.slot_bytes + (64 << 20)
+        try:
+            st = os.statvfs("/dev/shm")
+            free = st.f_bavail * st.f_frsize
+        except OSError:
+            free = 0
+        if free < need:
+            raise OSError(f"/dev/shm has {free >> 20} MiB free, the writer process needs {need >> 20} MiB "
+                          f"(GQ_SAVE_SLOT_MB={self.slot_bytes >> 20})")
         self.slots = [torch.empty(self.slot_bytes, dtype=torch.uint8).share_memory_() for _ in range(2)]
         self._registered = []
         for t in self.slots:  # pin the shared pages: device-to-host copies into them are plain DMA
@@ -174,15 +198,21 @@ class _Saver:
                     off += (n + 255) & ~255
                 with torch.cuda.stream(stream):
                     stream.wait_event(ev)
-                    if self.proc is not None and off <= self.slot_bytes:
-                        sid = self.freeq.get()
-                        for v, t in zip(_slot_views(self.slots[sid], layout), tensors):
-                            v.copy_(t.contiguous(), non_blocking=True)
-                        stream.synchronize()
-                        self.inbox.put(("slot", sid, name, int(q_type), layout))
+                    sid = self._get_slot() if (self.proc is not None and off <= self.slot_bytes) else None
+                    if sid is not None:
+                        sent = False
+                        try:
+                            for v, t in zip(_slot_views(self.slots[sid], layout), tensors):
+                                v.copy_(t.contiguous(), non_blocking=True)
+                            stream.synchronize()
+                            self.inbox.put(("slot", sid, name, int(q_type), layout))
+                            sent = True
+                        finally:
+                            if not sent:  # an exception between taking the slot and handing it over: no leak
+                                self.freeq.put(sid)
                     else:
                         host = [t.cpu() for t in tensors]
-                        if self.proc is not None:
+                        if self.proc is not None and not self._writer_dead:
                             self.inbox.put(("host", name, int(q_type), host))
                         else:
                             _write_data_pth(self.save_dir, name, q_type, *host)
@@ -190,6 +220,38 @@ class _Saver:
                 self.busy_s += time.perf_counter() - t0
             except BaseException as e:  # surfaced by close()
                 self.err = self.err or e
+
+    def _poll_writer(self) -> None:
+        """Non-blocking look at the writer: an error message or a dead process switches to in-thread writing (the
+        failed file is reported by close(); nothing ever waits on a writer that cannot answer)."""
+        if self.proc is None or self._writer_dead:
+            return
+        try:
+            while True:
+                status, info = self.outbox.get_nowait()
+                if status == "error":
+                    self._writer_failed(info)
+                else:
+                    self._final = (status, info)
+        except queue.Empty:
+            pass
+        if self._final is None and not self._writer_dead and not self.proc.is_alive():
+            self._writer_failed(f"writer process exited with code {self.proc.exitcode}")
+
+    def _writer_failed(self, info) -> None:
+        self._writer_dead = True
+        self.err = self.err or RuntimeError(f"data.pth writer process failed: {info}")
+
+    def _get_slot(self):
+        """A free staging slot, or None when the writer process is gone (the caller then writes in this thread)."""
+        while True:
+            self._poll_writer()
+            if self._writer_dead:
+                return None
+            try:
+                return self.freeq.get(timeout=1.0)
+            except queue.Empty:
+                continue
 
     def warm_up(self, device) -> None:
         """Start the writer process and pin its slots now (0.3 s), in the background of the capture forward."""
@@ -201,8 +263,11 @@ class _Saver:
             try:
                 if self.use_process:
                     self._start_process()
-            except BaseException as e:
-                self.err = self.err or e
+            except BaseException as e:  # no writer process (small /dev/shm, spawn failure): this thread writes, as
+                # GQ_SAVE_MODE=thread does -- a start-up problem of an optimisation is logged, not raised after hours
+                dist_utils.print_on_main(f"[gq] data.pth writer process not started ({e}); writing from a thread")
+                self.proc = None
+                self.slots = []
             ready.set()
             self._loop()
 
@@ -224,14 +289,31 @@ class _Saver:
     def close(self):
         if self.thread is not None:
             self.q.put(None)
-            self.thread.join()
+            while self.thread.is_alive():  # the copier never blocks for good (_get_slot polls the writer), but look anyway
+                self.thread.join(timeout=5.0)
+                self._poll_writer()
             self.thread = None
         if self.proc is not None:
-            self.inbox.put(None)
+            self._poll_writer()
+            status, info = "error", "no answer"
             try:
-                status, info = self.outbox.get(timeout=600)
+                self.inbox.put(None)
+                deadline = time.time() + 600
+                while self._final is None and time.time() < deadline:
+                    try:
+                        st, inf = self.outbox.get(timeout=1.0)
+                        if st == "error" and not self._writer_dead:
+                            self._writer_failed(inf)
+                        self._final = (st, inf)
+                    except queue.Empty:
+                        if not self.proc.is_alive():
+                            break
+                if self._final is not None:
+                    status, info = self._final
+                elif not self.proc.is_alive():
+                    info = f"writer process exited with code {self.proc.exitcode}"
             except Exception as e:
-                status, info = "error", f"writer process did not answer: {e!r}"
+                info = f"writer process did not answer: {e!r}"
             self.proc.join(timeout=60)
             for t in getattr(self, "_registered", []):
                 try:
@@ -240,7 +322,7 @@ class _Saver:
                     pass
             self.proc = self.inbox = self.outbox = self.freeq = None
             self.slots = []
-            if status == "ok":
+            if status == "ok" and not self._writer_dead:
                 self.writer_busy_s = float(info)
             else:
                 self.err = self.err or RuntimeError(f"data.pth writer process failed: {info}")
@@ -325,12 +407,15 @@ class Quantizer:
         self._saver = _Saver(self.save_dir, sync=os.environ.get("GQ_SYNC_SAVE") == "1")
         if os.environ.get("GQ_SAVE_SKIP") != "1":
             self._saver.warm_up(device)
+        self._saved_names: List[str] = []
         try:
             self._quantize(quant_config, device)
         finally:
+            BlockSchedule.discard_checks()  # nothing of this run may leak into the next Quantizer of the process
             t0 = time.perf_counter()
             self._saver.close()
             dist_utils.barrier()  # every rank's files are on disk
+            self._check_saved_files()
             if getattr(self, "_phases", None) is not None:
                 self._phases.host["save_tail"] = time.perf_counter() - t0
                 self.timing = self._phases.result()
@@ -400,6 +485,10 @@ class Quantizer:
                 block.cpu()
             del handles, hooks, sched
             self._schedule = None
+            # reused-factorisation flags: this block's go to the host behind an event, earlier blocks' are read if
+            # they have arrived -- a mismatch (the host-side pre-check makes it unlikely) stops the run at once
+            # instead of after the whole model, and the host never waits for the device here
+            BlockSchedule.verify(wait=False)
             ph.mark("forward2")
 
         if self.quant_non_block_modules:
@@ -407,7 +496,7 @@ class Quantizer:
                 self._quant_and_save_non_block(name, module.to(device), quant_config)
         if use_cache is not None:
             self.model.config.use_cache = use_cache
-        BlockSchedule.verify()  # the only host read of the reused-factorisation flags, all blocks at once
+        BlockSchedule.verify()  # whatever is still on its way
         ph.mark("rtn_post")
         dist_utils.barrier()
 
@@ -425,7 +514,19 @@ class Quantizer:
         return self._schedule.handles, hooks
 
     # ------------------------------------------------------------- quantize
+    def _check_saved_files(self) -> None:
+        """The data.pth files are dealt to the ranks; all of them must end up in ONE directory (the packer treats a
+        missing module as unquantized and would silently write it as f16).  After the barrier rank 0 looks: on a
+        multi-node run with a node-local save_dir this is where it shows."""
+        if not dist_utils.is_main() or os.environ.get("GQ_SAVE_SKIP") == "1" or sys.exc_info()[0] is not None:
+            return
+        missing = [n for n in self._saved_names if not os.path.isfile(os.path.join(self.save_dir, n, "data.pth"))]
+        if missing:
+            raise RuntimeError(f"{len(missing)} of {len(self._saved_names)} data.pth files are not in {self.save_dir} "
+                               f"(first: {missing[0]}): save_dir must be shared by all ranks")
+
     def _save(self, name, q_type, qweight, d, s, dmin, m):
+        self._saved_names.append(name)
         # every rank holds every result after the exchange: the files are dealt round-robin to the ranks of the
         # node (the reference lets every rank write every file, quantizer.py:267-275), so that the device-to-host
         # copies and the zip/CRC work of torch.save -- ~1 GB/s per writer, 8.7 GB for Llama-3-8B -- scale with

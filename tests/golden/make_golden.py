@@ -515,10 +515,47 @@ def g15_rtn_mse():
     save("g15_rtn_mse", **out)
 
 
+def g16_conv_handle():
+    """The _ConvNd branch of the handle (gptq.py:76, 96-104, 138-139): a small nn.Conv2d through GPTQ.update (nn.Unfold
+    patches as rows) and GPTQ.quantize; d_col = C_in * kh * kw = 256.  Stored: the conv weight, the three input
+    batches, H after the updates, W / H entering step, U, and the 5-tuple for two types."""
+    set_sqrt("ieee")
+    out = {}
+    torch.manual_seed(160)
+    conv = nn.Conv2d(64, 48, kernel_size=2, stride=2, padding=1, bias=False)
+    conv.weight.data = (torch.randn_like(conv.weight) * 0.05).half().float()
+    out["weight"] = conv.weight.detach().numpy().copy()
+    out["conv"] = np.array([64, 48, 2, 2, 1])  # in, out, kernel, stride, padding
+    xs = [(torch.randn(2, 64, 9, 9) * torch.exp(torch.randn(1, 64, 1, 1) * 0.4)).half().float() for _ in range(3)]
+    out["x"] = np.stack([x.numpy() for x in xs])
+    for qt in (T.Q4_K, T.Q6_K):
+        g = RefGPTQ(conv, rel_damp=0.01, block_size=128)
+        for x in xs:
+            g.update(x)
+        out["H_updated"] = g.H.numpy().copy()
+        out["num_samples"] = np.array(g.num_samples)
+        g.quantization_pre_step()
+        out["W0"], out["H0"] = g.W.numpy().copy(), g.H.numpy().copy()
+        cap = {}
+        orig = g._prepare
+
+        def prep():
+            u = orig()
+            cap["U"] = u.clone()
+            return u
+
+        g._prepare = prep
+        q, d, s, dmin, m = g.step(qt)
+        out["U_triu"] = _triu_pack(cap["U"].numpy())
+        for k, v in zip(("q", "d", "s", "dmin", "m"), (q.numpy(), u16(d), s.numpy(), u16(dmin), m.numpy())):
+            out[f"{qt.name}_{k}"] = v
+    save("g16_conv_handle", **out)
+
+
 def _main_all():
     torch.set_num_threads(8)
     for fn in (g1_make_quants, g2_scale_search, g3_elementwise, g4_g5_hessian, g6_g7_step_and_pack,
-               g8_g9_rtn_dequant, g11_act_order, g12_mse_scale, g13_two_rank, g15_rtn_mse):
+               g8_g9_rtn_dequant, g11_act_order, g12_mse_scale, g13_two_rank, g15_rtn_mse, g16_conv_handle):
         print(fn.__name__)
         fn()
     g10_driver()
@@ -609,5 +646,7 @@ if __name__ == "__main__":
         g13_two_rank()
     elif "g15" in sys.argv[1:]:
         g15_rtn_mse()
+    elif "g16" in sys.argv[1:]:
+        g16_conv_handle()
     else:
         _main_all()

@@ -147,3 +147,26 @@ def test_moe_driver_on_gpu(tmp_path):
     assert bool(torch.isfinite(logits).all())
     idle = torch.load(os.path.join(tmp_path, "model.layers.0.block_sparse_moe.experts.4.w2", "data.pth"), weights_only=True)
     assert idle["qweight"].abs().sum() > 0  # quantized by round-to-nearest on H = I, not skipped
+
+
+@pytest.mark.timeout(300)
+def test_unwritable_save_dir_raises_instead_of_hanging(tmp_path):
+    """with the default writer process, a torch.save that fails (here: save_dir is a FILE) used to
+    leave the copier thread blocked on a slot that never came back -- quantize() hung on every rank.  Now the slots
+    keep coming back, the copier falls back to in-thread writing, and quantize() raises the writer's error."""
+    from make_golden_shim import tiny_calib, tiny_llama
+    from gptq_gguf_toolkit_amd.quant_utils import GGMLQuantizationType as T
+    from gptq_gguf_toolkit_amd.quantizer import Quantizer
+    bad = tmp_path / "not_a_dir"
+    bad.write_text("x")
+    model = tiny_llama().cuda()
+    data = [([], {"input_ids": ids}) for ids in tiny_calib()]
+    drv = Quantizer(model, data_loader=data, quantizable_modules=r".*layers.*((q|k|v|o|gate|up|down)_proj)$",
+                    quantizer_kwargs=dict(rel_damp=0.01, block_size=128, act_order=False, quant_scale="absmax",
+                                          static_groups=False, rmin=-1.0, rdelta=0.1, nstep=20, verbose=False),
+                    pre_block_modules=["model.embed_tokens"], block_modules="model.layers",
+                    post_block_modules=["lm_head"], quant_non_block_modules=True, device="cuda:0", save_dir=str(bad))
+    with pytest.raises((RuntimeError, OSError)):
+        drv.quantize({"q_proj": T.Q4_K})
+    from gptq_gguf_toolkit_amd.block_schedule import BlockSchedule
+    assert BlockSchedule.unverified == [] and BlockSchedule._staged_checks == []

@@ -177,3 +177,34 @@ def test_rtn_quant_scale_mse_golden(ops, name):
     assert np.array_equal(m.cpu().numpy(), g[f"f32_{name}_m"])
     qa, *_ = ops.rtn_quantize(W, t)  # absmax
     assert bool((qa != q).any()) == (name != "Q4_K")
+
+
+@pytest.mark.parametrize("name", ["Q4_K", "Q6_K"])
+def test_conv_handle_golden(ops, name):
+    """GPTQ(nn.Conv2d).update / quantize on the GPU against the reference's run G16 (gptq.py:76, 96-104, 138-139): the
+    unfolded patches through the SYRK (H to 3e-6 of its maximum), the flattened working copy exactly, the 5-tuple
+    bit-exact GIVEN the reference's (W, U) and by rate (< 1 % of the ints) end to end."""
+    import numpy as np
+    from conftest import load_golden, triu_unpack
+    from gptq_gguf_toolkit_amd.gptq import GPTQ
+    g = load_golden("g16_conv_handle")
+    t = {"Q4_K": 12, "Q6_K": 14}[name]
+    cin, cout, k, st, pad = (int(v) for v in g["conv"])
+    conv = torch.nn.Conv2d(cin, cout, kernel_size=k, stride=st, padding=pad, bias=False)
+    conv.weight.data = torch.from_numpy(g["weight"].copy())
+    conv = conv.cuda()
+    h = GPTQ(conv, rel_damp=0.01, block_size=128)
+    for x in g["x"]:
+        h.update(torch.from_numpy(x.copy()).cuda())
+    h.flush()
+    assert h.num_samples == int(g["num_samples"])
+    assert float((h.H.cpu() - torch.from_numpy(g["H_updated"])).abs().max()) <= 3e-6 * float(np.abs(g["H_updated"]).max())
+    from gptq_gguf_toolkit_amd.quant_utils import GGMLQuantizationType
+    q, d, s, dmin, m = h.quantize(GGMLQuantizationType(t))
+    assert float((q.cpu().numpy() != g[f"{name}_q"]).mean()) < 0.01
+    W = torch.from_numpy(g["W0"].copy()).cuda()
+    U = torch.from_numpy(triu_unpack(g["U_triu"], W.shape[1])).cuda()
+    q2, d2, s2, dmin2, m2 = ops.gptq_quantize(W, U, t, 128)
+    assert np.array_equal(q2.cpu().numpy(), g[f"{name}_q"])
+    assert np.array_equal(d2.cpu().view(torch.int16).numpy().view(np.uint16), g[f"{name}_d"])
+    assert np.array_equal(s2.cpu().numpy(), g[f"{name}_s"]) and np.array_equal(m2.cpu().numpy(), g[f"{name}_m"])

@@ -227,6 +227,93 @@ def test_handle_act_order_matches_reference():
         GPTQ(torch.nn.Linear(C, R, bias=False), act_order=True, static_groups=False)  # gptq.py:45-46
 
 
+def test_data_pth_writer_failure_never_blocks_the_copier(tmp_path):
+    """when torch.save fails in the writer (disk full, unwritable save_dir) the staging slots must keep
+    coming back and the error must be reported at once -- the copier thread used to block forever on `freeq.get()`.
+    The writer body runs here in a thread on plain queues (same protocol as the spawned process)."""
+    import queue
+    import threading
+    from gptq_gguf_toolkit_amd import quantizer as qz
+    bad_dir = tmp_path / "file_not_dir"
+    bad_dir.write_text("x")  # os.makedirs(<file>/<name>) fails for every module
+    slots = [torch.zeros(4096, dtype=torch.uint8) for _ in range(2)]
+    inbox, freeq, outbox = queue.Queue(), queue.Queue(), queue.Queue()
+    layout = [(0, 256, torch.uint8, (256,)), (256, 32, torch.float16, (16,)), (512, 8, torch.uint8, (8,)),
+              (768, 32, torch.float16, (16,)), (1024, 8, torch.uint8, (8,))]
+    th = threading.Thread(target=qz._writer_process, args=(str(bad_dir), slots, inbox, freeq, outbox), daemon=True)
+    th.start()
+    for i in range(5):  # more items than slots: each slot must come back although every write fails
+        inbox.put(("slot", i % 2, f"m{i}", 12, layout))
+        assert freeq.get(timeout=20) == i % 2
+    status, info = outbox.get(timeout=20)
+    assert status == "error" and "m0" in info  # reported with the first failure, not at the end
+    inbox.put(None)
+    th.join(timeout=20)
+    assert not th.is_alive()
+    assert outbox.get(timeout=5)[0] == "error"  # the final message repeats it
+    # and a healthy directory still works through the same body
+    good = tmp_path / "ok"
+    good.mkdir()
+    th = threading.Thread(target=qz._writer_process, args=(str(good), slots, inbox, freeq, outbox), daemon=True)
+    th.start()
+    inbox.put(("slot", 0, "m", 12, layout))
+    assert freeq.get(timeout=20) == 0
+    inbox.put(None)
+    th.join(timeout=20)
+    assert outbox.get(timeout=5)[0] == "ok" and (good / "m" / "data.pth").is_file()
+
+
+def test_missing_data_pth_is_reported(tmp_path):
+    """the files are dealt to the ranks; rank 0 checks after the barrier that all of them are in save_dir."""
+    from gptq_gguf_toolkit_amd.quantizer import Quantizer
+    q = Quantizer.__new__(Quantizer)
+    q.save_dir = str(tmp_path)
+    q._saved_names = ["a.b", "c.d"]
+    (tmp_path / "a.b").mkdir()
+    (tmp_path / "a.b" / "data.pth").write_text("x")
+    with pytest.raises(RuntimeError, match="save_dir must be shared"):
+        q._check_saved_files()
+    (tmp_path / "c.d").mkdir()
+    (tmp_path / "c.d" / "data.pth").write_text("x")
+    q._check_saved_files()
+
+
+def _conv_from_golden(g, device="cpu"):
+    cin, cout, k, st, pad = (int(v) for v in g["conv"])
+    conv = torch.nn.Conv2d(cin, cout, kernel_size=k, stride=st, padding=pad, bias=False)
+    conv.weight.data = torch.from_numpy(g["weight"].copy())
+    return conv.to(device)
+
+
+def test_conv_handle_matches_reference_run(oracle):
+    """The _ConvNd branch of the handle (reference gptq.py:76, 96-104, 138-139) against the reference's own run on a
+    small nn.Conv2d (G16): nn.Unfold patches as Hessian rows, the flattened [out, in*kh*kw] working copy, the 5-tuple.
+    H to fp32 summation order; the ints exactly GIVEN the reference's (W, U) and by rate through the handle (U here
+    comes from the fp64 oracle, the reference's from fp32 LAPACK)."""
+    import fake_ops
+    from conftest import triu_unpack
+    from gptq_gguf_toolkit_amd.gptq import GPTQ
+    from gptq_gguf_toolkit_amd.quant_utils import GGMLQuantizationType as T
+    fake_ops.install()
+    g = load_golden("g16_conv_handle")
+    for qt in (T.Q4_K, T.Q6_K):
+        conv = _conv_from_golden(g)
+        h = GPTQ(conv, rel_damp=0.01, block_size=128)
+        assert (h.d_row, h.d_col) == g["W0"].shape
+        for x in g["x"]:
+            h.update(torch.from_numpy(x.copy()))
+        h.flush()
+        assert h.num_samples == int(g["num_samples"])
+        assert np.abs(h.H.numpy() - g["H_updated"]).max() <= 2e-6 * np.abs(g["H_updated"]).max()
+        q, d, s, dmin, m = h.quantize(qt)
+        assert q.shape == g[f"{qt.name}_q"].shape
+        assert float((q.numpy() != g[f"{qt.name}_q"]).mean()) < 0.01
+        U = triu_unpack(g["U_triu"], g["W0"].shape[1])
+        _, oq, od, os_, odm, om = oracle.gptq_step(g["W0"], U, int(qt), block_size=128)
+        assert np.array_equal(oq, g[f"{qt.name}_q"]) and np.array_equal(od, g[f"{qt.name}_d"])
+        assert np.array_equal(os_, g[f"{qt.name}_s"]) and np.array_equal(om, g[f"{qt.name}_m"])
+
+
 def _worker(rank, world, port, tmp, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
