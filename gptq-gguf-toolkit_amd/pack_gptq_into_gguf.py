@@ -10,15 +10,20 @@ converter fork that touches the hot path:
   * `LlamaModel.permute` / `modify_tensors` (:2177-2183, :2217-2221) and the HF -> GGUF tensor names.
   * the Llama metadata in the reference's order (:412-441, :594-638, :2160-2175), `rope_freqs.weight` for
     rope_type "llama3" (:2259-2287), linear rope-scaling keys, Mixtral's router and stacked expert tensors.
-Everything else of the fork (110 other architectures, SentencePiece / Mistral vocabularies, split files, remote
-models) is out of scope and REFUSED loudly rather than mis-written.  The container is written by gguf_writer.py (spec-level; whole-file byte
-parity with gguf-py is unpinned), the tensor payloads by the GPU bit-packers.
+  * `LlamaModel.set_vocab` (:2126-2139): the SentencePiece vocabulary (`tokenizer.model` -> tokenizer model "llama",
+    scores, token types, byte fallback; :1018-1118 -- TinyLlama, Llama-2, Mistral, Mixtral) and the byte-level BPE one
+    (Llama-3), both closed by gguf.SpecialVocab's keys (special token ids, add_bos/eos flags, chat template).
+Everything else of the fork (110 other architectures, Mistral-format / tekken vocabularies, split files, remote
+models) is out of scope and REFUSED loudly rather than mis-written.  The container is written by gguf_writer.py
+(spec-level; whole-file byte identity with gguf-py 0.17.1 is UNPINNED: that package cannot be installed here and no
+reference-produced file exists to compare with), the tensor payloads by the GPU bit-packers.
 """
 import argparse
 import json
 import os
 import sys
 from pathlib import Path
+from typing import Optional
 
 import numpy as np
 import torch
@@ -84,20 +89,138 @@ def iter_hf_tensors(dir_model: Path):
                 yield k, f.get_tensor(k)
 
 
+# llama.cpp token types (reference pack_gptq_into_gguf.py:47-53)
+TOK_NORMAL, TOK_UNKNOWN, TOK_CONTROL, TOK_USER_DEFINED, TOK_UNUSED, TOK_BYTE = 1, 2, 3, 4, 5, 6
+_SPECIAL_TYPES = ("bos", "eos", "unk", "sep", "pad", "cls", "mask")
+# the GGUF key of each special token id (gguf-py constants.py Keys.Tokenizer; "seperator" is the spec's spelling)
+_SPECIAL_KEYS = {"bos": "bos_token_id", "eos": "eos_token_id", "unk": "unknown_token_id", "sep": "seperator_token_id",
+                 "pad": "padding_token_id", "cls": "cls_token_id", "mask": "mask_token_id"}
+
+
+def does_token_look_special(token: str) -> bool:
+    """reference pack_gptq_into_gguf.py:649-670: added tokens that ought to be control tokens whatever their flag."""
+    return (token in ("<pad>", "<mask>", "<2mass>", "[@BOS@]")
+            or (token.startswith("<|") and token.endswith("|>"))
+            or (token.startswith("<\uff5c") and token.endswith("\uff5c>"))
+            or (token.startswith("<unused") and token.endswith(">")))
+
+
+def add_special_vocab(w: GGUFWriter, dir_model: Path, n_vocab: int, merges=None) -> None:
+    """What `gguf.SpecialVocab(dir_model, n_vocab=...).add_to_gguf(writer)` leaves in the file (the reference's vocab
+    paths all end with it, pack_gptq_into_gguf.py:1027-1028): merges (BPE only), the special token ids, the
+    add_<type>_token flags, the chat template.  gguf-py 0.17.1 is not installable here; this follows its published
+    behaviour: for every type in (bos, eos, unk, sep, pad, cls, mask) tokenizer_config.json's "<type>_token" (a string or
+    {"content": ...}) is looked up among tokenizer.json's added_tokens, then config.json's "<type>_token_id" fills
+    what is still unset; ids >= n_vocab are dropped; "add_<type>_token" booleans and "chat_template" come from
+    tokenizer_config.json (chat_template.json as the alternative source)."""
+    ids, add_flags, chat_template = {}, {}, None
+
+    def set_id(typ, tid):
+        if not isinstance(tid, int) or isinstance(tid, bool) or tid < 0 or typ in ids:
+            return
+        if n_vocab is None or tid < n_vocab:
+            ids[typ] = tid
+
+    tj, tcj, cj = dir_model / "tokenizer.json", dir_model / "tokenizer_config.json", dir_model / "config.json"
+    added = json.load(open(tj, encoding="utf-8")).get("added_tokens", []) if tj.is_file() else []
+    if tcj.is_file():
+        cfg = json.load(open(tcj, encoding="utf-8"))
+        alt = dir_model / "chat_template.json"
+        tmpl = cfg.get("chat_template", json.load(open(alt, encoding="utf-8")).get("chat_template") if alt.is_file() else None)
+        if isinstance(tmpl, (str, list)):
+            chat_template = tmpl
+        for typ in _SPECIAL_TYPES:
+            if isinstance(cfg.get(f"add_{typ}_token"), bool):
+                add_flags[typ] = cfg[f"add_{typ}_token"]
+            entry = cfg.get(f"{typ}_token")
+            content = entry if isinstance(entry, str) else (entry.get("content") if isinstance(entry, dict) else None)
+            if isinstance(content, str):
+                set_id(typ, next((a.get("id") for a in added if a.get("content") == content), None))
+    if cj.is_file():
+        cfg = json.load(open(cj, encoding="utf-8"))
+        for typ in _SPECIAL_TYPES:
+            set_id(typ, cfg.get(f"{typ}_token_id"))
+    if merges:
+        w.add_array("tokenizer.ggml.merges", merges, GGUFValueType.STRING)
+    for typ, tid in ids.items():
+        w.add_uint32(f"tokenizer.ggml.{_SPECIAL_KEYS[typ]}", tid)
+    for typ, flag in add_flags.items():
+        w.add_bool(f"tokenizer.ggml.add_{typ}_token", flag)
+    if isinstance(chat_template, list):  # several named templates: "default" is the one llama.cpp reads first
+        named = {t.get("name"): t.get("template") for t in chat_template if isinstance(t, dict)}
+        chat_template = named.get("default")
+        for name, text in named.items():
+            if name != "default" and isinstance(text, str):
+                w.add_string(f"tokenizer.chat_template.{name}", text)
+    if isinstance(chat_template, str):
+        w.add_string("tokenizer.chat_template", chat_template)
+
+
+def create_vocab_sentencepiece(dir_model: Path, vocab_size: Optional[int]):
+    """reference pack_gptq_into_gguf.py:1030-1118 (_create_vocab_sentencepiece): (tokens, scores, token types) of a
+    SentencePiece checkpoint -- every piece with its score and its type (normal / unknown / control / unused / byte),
+    added_tokens.json entries as USER_DEFINED with score -1000, tokenizer_config.json's added_tokens_decoder entries as
+    CONTROL (flagged or special-looking) or USER_DEFINED (with the U+2581 pre-normalisation), [PAD<i>] / UNUSED for
+    ids the model file does not cover."""
+    from sentencepiece import SentencePieceProcessor
+    path = dir_model / "tokenizer.model"
+    if not path.is_file():
+        raise FileNotFoundError(f"File not found: {path}")
+    sp = SentencePieceProcessor()
+    sp.LoadFromFile(str(path))
+    vocab_size = vocab_size or sp.vocab_size()
+    tokens = [f"[PAD{i}]" for i in range(vocab_size)]
+    scores = [-10000.0] * vocab_size
+    types = [TOK_UNUSED] * vocab_size
+    for tid in range(min(sp.vocab_size(), vocab_size)):
+        tokens[tid] = sp.IdToPiece(tid)
+        scores[tid] = float(sp.GetScore(tid))
+        types[tid] = (TOK_UNKNOWN if sp.IsUnknown(tid) else TOK_CONTROL if sp.IsControl(tid) else
+                      TOK_UNUSED if sp.IsUnused(tid) else TOK_BYTE if sp.IsByte(tid) else TOK_NORMAL)
+    added_file = dir_model / "added_tokens.json"
+    if added_file.is_file():
+        for key, tid in json.load(open(added_file, encoding="utf-8")).items():
+            if tid < vocab_size:
+                tokens[tid], scores[tid], types[tid] = key, -1000.0, TOK_USER_DEFINED
+    tcj = dir_model / "tokenizer_config.json"
+    if tcj.is_file():
+        for tid, data in json.load(open(tcj, encoding="utf-8")).get("added_tokens_decoder", {}).items():
+            tid, token = int(tid), data["content"]
+            if tid >= vocab_size:
+                continue
+            if data.get("special") or does_token_look_special(token):
+                types[tid] = TOK_CONTROL
+            else:
+                token = token.replace("\u2581", " ")  # pre-normalize user-defined spaces (:1104)
+                types[tid] = TOK_USER_DEFINED
+            scores[tid] = -1000.0
+            tokens[tid] = token
+    return tokens, scores, types
+
+
 def add_tokenizer(w: GGUFWriter, dir_model: Path, vocab_size: int):
-    """The BPE (`gpt2`) vocabulary path of the reference's set_vocab (:2126-2139 falls through sentencepiece and
-    llama_hf to _set_vocab_gpt2 for Llama-3).  SentencePiece checkpoints (tokenizer.model: Llama-2, Mistral, Mixtral)
-    need the `llama` tokenizer model with scores and byte fallback, which is not reproduced: refused, not mis-written."""
-    if (dir_model / "tokenizer.model").exists():
-        raise NotImplementedError("SentencePiece vocabulary (tokenizer.model): only the BPE tokenizer.json path of "
-                                  "the reference converter is reproduced; pass --no_vocab to write tensors only")
+    """LlamaModel.set_vocab (reference :2126-2139): the SentencePiece vocabulary when the checkpoint has a
+    tokenizer.model (Llama-2, TinyLlama, Mistral, Mixtral: tokenizer model "llama", pre-tokenizer "default", scores,
+    byte fallback; :1018-1028), else the byte-level BPE path (`gpt2`, Llama-3; :2137).  The middle fallback
+    (`_set_vocab_llama_hf`: a tokenizer.json of a SentencePiece-derived vocabulary without tokenizer.model) is not
+    reproduced and refused."""
+    if (dir_model / "tokenizer.model").is_file():
+        tokens, scores, types = create_vocab_sentencepiece(dir_model, vocab_size)
+        w.add_string("tokenizer.ggml.model", "llama")
+        w.add_string("tokenizer.ggml.pre", "default")
+        w.add_array("tokenizer.ggml.tokens", tokens, GGUFValueType.STRING)
+        w.add_array("tokenizer.ggml.scores", scores, GGUFValueType.FLOAT32)
+        w.add_array("tokenizer.ggml.token_type", types, GGUFValueType.INT32)
+        add_special_vocab(w, dir_model, len(tokens))
+        _add_space_prefix(w, dir_model)
+        return
     tj = dir_model / "tokenizer.json"
     if not tj.exists():
         raise FileNotFoundError(f"{tj} not found: no vocabulary to write (pass --no_vocab to write tensors only)")
     tok = json.load(open(tj, encoding="utf-8"))
     if tok["model"].get("type", "BPE") != "BPE" or tok["model"].get("byte_fallback"):
-        raise NotImplementedError("tokenizer.json is not a byte-level BPE vocabulary (SentencePiece-derived models need "
-                                  "the `llama` tokenizer model, which is not reproduced)")
+        raise NotImplementedError("tokenizer.json holds a SentencePiece-derived vocabulary but there is no tokenizer.model "
+                                  "next to it (the reference's _set_vocab_llama_hf path is not reproduced)")
     vocab = tok["model"]["vocab"]
     added = {a["id"]: a for a in tok.get("added_tokens", [])}
     rev = {i: t for t, i in vocab.items()}
@@ -105,13 +228,14 @@ def add_tokenizer(w: GGUFWriter, dir_model: Path, vocab_size: int):
     for i in range(vocab_size):
         if i in added:
             tokens.append(added[i]["content"])
-            types.append(3 if added[i].get("special") else 4)  # CONTROL / USER_DEFINED
+            types.append(TOK_CONTROL if added[i].get("special") or does_token_look_special(added[i]["content"])
+                         else TOK_USER_DEFINED)
         elif i in rev:
             tokens.append(rev[i])
-            types.append(1)  # NORMAL
+            types.append(TOK_NORMAL)
         else:
             tokens.append(f"[PAD{i}]")
-            types.append(5)  # UNUSED
+            types.append(TOK_UNUSED)
     merges = [m if isinstance(m, str) else " ".join(m) for m in tok["model"].get("merges", [])]
     if vocab_size != 128256:
         print("warning: tokenizer.ggml.pre is written as 'llama-bpe' (the Llama-3 pre-tokenizer); the reference "
@@ -120,16 +244,14 @@ def add_tokenizer(w: GGUFWriter, dir_model: Path, vocab_size: int):
     w.add_string("tokenizer.ggml.pre", "llama-bpe")
     w.add_array("tokenizer.ggml.tokens", tokens, GGUFValueType.STRING)
     w.add_array("tokenizer.ggml.token_type", types, GGUFValueType.INT32)
-    w.add_array("tokenizer.ggml.merges", merges, GGUFValueType.STRING)
+    add_special_vocab(w, dir_model, len(tokens), merges=merges)
+    _add_space_prefix(w, dir_model)
+
+
+def _add_space_prefix(w: GGUFWriter, dir_model: Path) -> None:
     cfgp = dir_model / "tokenizer_config.json"
     cfg = json.load(open(cfgp, encoding="utf-8")) if cfgp.exists() else {}
-    tok2id = {t: i for i, t in enumerate(tokens)}
-    for key, name in (("bos_token", "bos_token_id"), ("eos_token", "eos_token_id"), ("pad_token", "padding_token_id")):
-        v = cfg.get(key)
-        v = v.get("content") if isinstance(v, dict) else v
-        if v in tok2id:
-            w.add_uint32(f"tokenizer.ggml.{name}", tok2id[v])
-    if "add_prefix_space" in cfg:  # :2152-2153
+    if "add_prefix_space" in cfg:  # :2150-2153
         w.add_bool("tokenizer.ggml.add_space_prefix", bool(cfg["add_prefix_space"]))
 
 
