@@ -584,6 +584,7 @@ def main():
     _cabi.prof_enable(["syrk", "trailing_far_gemm32"])
     keep = {}
     sched = None
+    coll0 = dict(dist_utils.collective_calls)
     t0 = time.perf_counter()
     for i in range(args.steps):
         sched = block_step(wl, layers, W16, X, keep=keep if i == args.steps - 1 else None)
@@ -591,6 +592,9 @@ def main():
     dt = time.perf_counter() - t0
     prof = _cabi.prof_collect(busy=True)
     _cabi.prof_enable([])
+    # data-path collectives one step issued on this rank (N > 1: one all-reduce per distinct Hessian, ONE all-gather of
+    # the block's results, no broadcast -- asserted by tests/test_gpu_round3.py)
+    coll = {k: (v - coll0.get(k, 0)) / args.steps for k, v in dist_utils.collective_calls.items()}
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -653,7 +657,10 @@ def main():
                                    f"block_size 128, rel_damp 0.01, nstep 20",
                        "calib_seqs_per_rank": nseq_local, "parallelism": f"calib-dp{world}+matrix-fanout",
                        "owners": sched.owners if world > 1 else "rank0"},
-            "ranks_seen": ranks_seen, "allreduce_probe": ar_probe, "schedule": sched.stats,
+            "ranks_seen": ranks_seen, "collective_backend": (f"{args.backend} (RCCL over xGMI)" if args.backend == "nccl"
+                                                             else args.backend) if world > 1 else None,
+            "collectives_per_step": coll if world > 1 else None,
+            "allreduce_probe": ar_probe, "schedule": sched.stats,
             "wall_s_llama3_8b_32_blocks_extrapolated": round(dt / args.steps * 32, 2)
             if args.workload.startswith("llama3-8b") else None,
             "roofline": roof,

@@ -45,6 +45,7 @@ import torch.nn as nn
 from . import dist_utils
 from . import ops as _ops
 from .gptq import GPTQ
+from .quant_utils import GGML_QUANT_SIZES
 from .quant_utils import GGMLQuantizationType, dequantize_linear_weight
 
 _stream_pool: Dict[Any, List["torch.cuda.Stream"]] = {}
@@ -490,15 +491,74 @@ class BlockSchedule:
                     self.stats["reused_U"] += 1
         self.stats["own_U"] = len(results) - self.stats["reused_U"]
 
-        # ---- phase 2: exchange (same order on every rank), write-back
-        out: Dict[str, tuple] = {}
+        # ---- phase 2: exchange, write-back.  ONE all-gather per block: every rank packs what it computed (whole
+        # matrices it owns, its row slices of the row-split ones) into one byte buffer whose layout every rank can
+        # derive from the owner map alone (the reference broadcasts five tensors per Linear from rank 0,
+        # gptq.py:287-293: 35 collectives per Llama block, 140 for a Mixtral block).
+        if world > 1:
+            out = self._exchange_block(handles, qtypes, results, world, rank)
+        else:
+            out = {n: results[n] for n in handles}
         for n, h in handles.items():
-            res = h.exchange(results.get(n), qtypes[n])
-            out[n] = res
             if writeback:
                 w = deq.get(n)
                 if w is None:
-                    w = dequantize_linear_weight(qtypes[n], *res, out_dtype=h.layer.weight.data.dtype)
+                    w = dequantize_linear_weight(qtypes[n], *out[n], out_dtype=h.layer.weight.data.dtype)
                 h.layer.weight.data = w
             h.reset()
+        return out
+
+    @staticmethod
+    def _piece_layout(q_type, rows: int, cols: int):
+        """[(dtype, shape, byte offset)] of the five result tensors of `rows` rows, each padded to 256 bytes; total."""
+        bits, clamp, scale_maxq, group_size, supergroup_size, sz_dtype, q_dtype = GGML_QUANT_SIZES[q_type]
+        shapes = ((q_dtype, (rows, cols)), (torch.float16, (rows, cols // supergroup_size)),
+                  (sz_dtype, (rows, cols // group_size)), (torch.float16, (rows, cols // supergroup_size)),
+                  (sz_dtype, (rows, cols // group_size)))
+        lay, off = [], 0
+        for dt, shp in shapes:
+            lay.append((dt, shp, off))
+            n = shp[0] * shp[1] * torch.empty(0, dtype=dt).element_size()
+            off += (n + 255) & ~255
+        return lay, off
+
+    def _exchange_block(self, handles, qtypes, results, world: int, rank: int):
+        per_rank: List[List[Tuple[str, int, int]]] = [[] for _ in range(world)]
+        for n, h in handles.items():  # same order, same owner map on every rank
+            if h._row_split_active():
+                for r in range(world):
+                    r0, r1, _ = dist_utils.row_slice(h.d_row, r, world)
+                    if r1 > r0:
+                        per_rank[r].append((n, r0, r1))
+            else:
+                per_rank[h.owner_rank].append((n, 0, h.d_row))
+        layouts = [[(n, r0, r1) + self._piece_layout(qtypes[n], r1 - r0, handles[n].d_col) for n, r0, r1 in lst]
+                   for lst in per_rank]
+        sizes = [sum(x[4] for x in lst) for lst in layouts]
+        nbytes = max(max(sizes), 256)
+        dev = next(iter(handles.values())).W_device
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        off = 0
+        for n, r0, r1, lay, tot in layouts[rank]:
+            for t, (dt, shp, o) in zip(results[n], lay):
+                k = shp[0] * shp[1] * t.element_size()
+                buf[off + o:off + o + k].view(dt).view(shp).copy_(t)
+            off += tot
+        gathered = dist_utils.all_gather_bytes(buf, nbytes)
+        self.stats["allgather_bytes"] = self.stats.get("allgather_bytes", 0) + nbytes
+        parts: Dict[str, List[List[torch.Tensor]]] = {n: [] for n in handles}
+        for r in range(world):
+            off = 0
+            for n, r0, r1, lay, tot in layouts[r]:
+                views = []
+                for dt, shp, o in lay:
+                    k = shp[0] * shp[1] * torch.empty(0, dtype=dt).element_size()
+                    views.append(gathered[r, off + o:off + o + k].view(dt).view(shp))
+                parts[n].append(views)
+                off += tot
+        out: Dict[str, tuple] = {}
+        for n in handles:
+            ps = parts[n]
+            # a whole matrix: views into the gathered buffer (no copy); row slices: concatenated in rank order
+            out[n] = tuple(ps[0]) if len(ps) == 1 else tuple(torch.cat([p[i] for p in ps], dim=0) for i in range(5))
         return out

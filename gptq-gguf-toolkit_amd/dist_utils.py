@@ -7,6 +7,11 @@ from typing import Dict, List, Sequence, Set, Tuple
 import torch.distributed as dist
 
 
+# data-path collectives issued by this process (tests and bench.py read it: "one all-reduce per distinct Hessian and
+# one all-gather per block" is asserted, not only claimed)
+collective_calls: Dict[str, int] = {"all_reduce": 0, "all_gather": 0, "broadcast": 0}
+
+
 def is_dist_available_and_initialized() -> bool:
     return dist.is_available() and dist.is_initialized()
 
@@ -60,12 +65,13 @@ def allreduce_hessian(H, num_samples=None):
     else:
         payload = H
     total = None
+    collective_calls["all_reduce"] += 1
     if num_samples is None:
         dist.all_reduce(payload, op=dist.ReduceOp.AVG)
     else:
         counts = torch.zeros(get_world_size(), dtype=torch.float64, device=H.device)
         counts[get_rank()] = float(num_samples)
-        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)  # (a few bytes: the sample counts of an MoE expert)
         total = int(counts.sum().item())
         if bool((counts == counts[0]).all()):
             dist.all_reduce(payload, op=dist.ReduceOp.AVG)
@@ -128,10 +134,33 @@ def row_slice(rows: int, rank: int, world_size: int, align: int = 128) -> Tuple[
 
 
 def all_gather_rows(part, rows: int, chunk: int):
-    """Concatenate the ranks' row slices (each padded to `chunk` rows) -> [rows, ...] on every rank."""
+    """Concatenate the ranks' row slices (each padded to `chunk` rows) -> [rows, ...] on every rank.  (The handle-level
+    exchange of a row-split matrix; a BlockSchedule gathers a whole block at once: all_gather_bytes.)"""
     import torch
-    pad = torch.zeros((chunk,) + tuple(part.shape[1:]), dtype=part.dtype, device=part.device)
-    pad[:part.shape[0]] = part
-    pieces = [torch.empty_like(pad) for _ in range(get_world_size())]
-    dist.all_gather(pieces, pad)
-    return torch.cat(pieces, dim=0)[:rows].contiguous()
+    world = get_world_size()
+    pad = part
+    if part.shape[0] != chunk:
+        pad = torch.zeros((chunk,) + tuple(part.shape[1:]), dtype=part.dtype, device=part.device)
+        pad[:part.shape[0]] = part
+    out = torch.empty((world * chunk,) + tuple(part.shape[1:]), dtype=part.dtype, device=part.device)
+    _all_gather_into(out, pad.contiguous())
+    return out[:rows] if world * chunk != rows else out
+
+
+def _all_gather_into(out, inp) -> None:
+    """out[r * n : (r + 1) * n] = rank r's inp (n = inp.numel()), ONE collective, no list of temporaries."""
+    collective_calls["all_gather"] += 1
+    try:
+        dist.all_gather_into_tensor(out.view(-1), inp.view(-1))
+    except (RuntimeError, NotImplementedError):  # a backend without the tensor form: views of `out` as the list
+        dist.all_gather(list(out.view(-1).chunk(get_world_size())), inp.view(-1))
+
+
+def all_gather_bytes(mine, nbytes: int):
+    """Every rank contributes `nbytes` bytes (uint8 tensor `mine`, padded by the caller to the common size); returns
+    uint8 [world, nbytes] on every rank.  The result exchange of one transformer block (block_schedule.py)."""
+    import torch
+    assert mine.dtype == torch.uint8 and mine.numel() == nbytes
+    out = torch.empty((get_world_size(), nbytes), dtype=torch.uint8, device=mine.device)
+    _all_gather_into(out, mine)
+    return out

@@ -338,6 +338,7 @@ class GPTQ:
             result = self._empty_result(q_type)
         if dist_utils.is_dist_available_and_initialized() and dist_utils.get_world_size() > 1:
             for t in result:
+                dist_utils.collective_calls["broadcast"] += 1
                 dist.broadcast(t, src=self.owner_rank)
         return result
 

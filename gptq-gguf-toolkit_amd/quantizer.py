@@ -82,8 +82,15 @@ def _batch_block_inputs(input_args, input_kwargs, batch: int):
     return out_a, out_kw
 
 
+def _own_storage(t):
+    """torch.save writes a tensor's WHOLE storage: a view into a larger buffer (a staging slot, the gathered block
+    buffer of the N > 1 exchange) is copied out first."""
+    return t if t.untyped_storage().nbytes() == t.numel() * t.element_size() else t.clone()
+
+
 def _write_data_pth(save_dir, name, q_type, qweight, d, s, dmin, m):
     os.makedirs(os.path.join(save_dir, name), exist_ok=True)
+    qweight, d, s, dmin, m = (_own_storage(t) for t in (qweight, d, s, dmin, m))
     torch.save({"q_type": int(q_type), "qweight": qweight, "super_group_scale": d, "super_group_zero": dmin,
                 "group_scale_quant": s, "group_zero_quant": m}, os.path.join(save_dir, name, "data.pth"))
 

@@ -208,3 +208,29 @@ def test_conv_handle_golden(ops, name):
     assert np.array_equal(q2.cpu().numpy(), g[f"{name}_q"])
     assert np.array_equal(d2.cpu().view(torch.int16).numpy().view(np.uint16), g[f"{name}_d"])
     assert np.array_equal(s2.cpu().numpy(), g[f"{name}_s"]) and np.array_equal(m2.cpu().numpy(), g[f"{name}_m"])
+
+
+def test_bench_eight_ranks_one_allgather_per_block():
+    """the N > 1 plumbing at the world size the driver will use.  bench.py --gpus 8 through
+    torch.distributed.run (RCCL when the box has 8 GPUs, else eight gloo ranks sharing the one GPU): every rank holds
+    identical results, the line proves 8 ranks took part, and a block costs 4 all-reduces (one per DISTINCT Hessian;
+    the reference: 7) + ONE all-gather of all results (the reference: 35 broadcasts) + no broadcast."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    n = 8
+    backend = "nccl" if torch.cuda.device_count() >= n else "gloo"
+    env = dict(os.environ, GQ_BENCH_VERIFY="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(27000 + os.getpid() % 2000), os.path.join(ROOT, "bench.py"), "--gpus",
+           str(n), "--steps", "1", "--warmup", "1", "--workload", "tinyllama-block-q4k", "--backend", backend,
+           "--no-cpu-baseline", "--no-whole-model", "--no-side-legs"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert "verify: all ranks hold identical results" in p.stderr
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == n and line["ranks_seen"] == n and line["collective_backend"].startswith(backend)
+    assert line["collectives_per_step"] == {"all_reduce": 4.0, "all_gather": 1.0, "broadcast": 0.0}, line["collectives_per_step"]
+    owners = line["config"]["owners"]
+    assert owners["down_proj"] == f"rows/{n}" and len({v for k, v in owners.items() if k != "down_proj"}) == 6, owners
