@@ -364,8 +364,17 @@ def fast_obq_leg(wl, W16, X, n_seq=32, bits=(2, 3, 4, 8)):
 
 
 def cpu_baseline(wl, W16, keep):
-    """Oracle (C restatement of the reference, OpenMP) on the host cores: GPTQ.step of every Linear of the block (218 M
-    params at 8B sizes) with the U the GPU used for each.  ~10 s of CPU on 8 cores."""
+    """The path on the host cores, every stage measured in THIS run on a bounded sample (~15-25 s of CPU):
+      * GPTQ.step (gptq.py:145-276) of every Linear of the block through the oracle's C restatement (OpenMP), with the U
+        the GPU used -- measured in full, ints compared with the GPU's;
+      * dequantize + pack of the same Linears (quant_utils.py:277-310, packing_utils.py:33-326) through the oracle;
+      * GPTQ.update (gptq.py:96-112: `H.addmm_(X.T, X)`, fp32) and GPTQ._prepare's chain (:318-320: cholesky ->
+        cholesky_inverse -> cholesky(upper)) AS THE REFERENCE RUNS THEM ON A CPU: the same torch calls (MKL underneath) on
+        a sample -- 16 384 tokens x 4096 channels in 2048-token updates, one 4096-wide chain -- scaled to the block by
+        flops (the reference accumulates and factorises one Hessian per Linear: sum of 2 T C^2 and of C^3 over the 7
+        Linears).  (The oracle's own h_accumulate / h_prepare are fp64 accuracy anchors with naive loops, not what a CPU
+        user would run.)
+    `value` is the full path; the step-only figure of r01/r02 stays beside it."""
     try:
         from oracle import oracle as O
         shapes = wl["shapes"]
@@ -376,22 +385,57 @@ def cpu_baseline(wl, W16, keep):
                 names.append(n)
                 budget -= cost
         threads = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
-        tot, same, cnt, dt = 0, 0.0, 0, 0.0
+        tot, same, cnt, dt, dt_codec = 0, 0.0, 0, 0.0, 0.0
         for n in names:
             R, C, _ = shapes[n]
+            qt = int(q_of(wl, n))
             W = W16[n].float().cpu().numpy()
             U = keep[n][2].cpu().numpy()
             t0 = time.perf_counter()
-            _, oq, *_ = O.gptq_step(W, U, int(q_of(wl, n)), block_size=128)
-            dt += time.perf_counter() - t0
+            _, oq, od, os_, odm, om = O.gptq_step(W, U, qt, block_size=128)
+            t1 = time.perf_counter()
+            O.dequantize(qt, oq, od, os_, odm, om)
+            O.pack(qt, oq, od, os_, odm, om)
+            dt_codec += time.perf_counter() - t1
+            dt += t1 - t0
             tot += R * C
             same += float((oq == keep[n][0][0].cpu().numpy()).sum())
             cnt += oq.size
-        return {"value": round(tot / dt / 1e6, 3), "unit": "Mparams/s", "cores": threads, "kind": "port",
-                "sample": f"GPTQ.step only (scale search + column loop + trailing update, given the GPU's U; the "
-                          f"Hessian accumulation, the Cholesky chain, dequantize and pack of the GPU step are NOT in "
-                          f"this figure) of {len(names)} of the block's {len(shapes)} Linears ({'/'.join(names)}, "
-                          f"{tot / 1e6:.1f} M params), {dt:.1f} s; ints equal to the GPU's: {same / cnt:.6f}"}
+            del W, U, oq
+        # the reference's own CPU calls for the two tolerance-class stages, on a sample
+        old_threads = torch.get_num_threads()
+        torch.set_num_threads(threads)
+        try:
+            Cs, Ls, ns = 4096, 2048, 8
+            g = torch.Generator().manual_seed(0)
+            Xs = [torch.randn(Ls, Cs, generator=g).half() for _ in range(ns)]
+            H = torch.zeros(Cs, Cs)
+            t0 = time.perf_counter()
+            for i, x in enumerate(Xs):  # gptq.py:96-112 per calibration sample
+                xf = x.float()
+                H.addmm_(xf.T, xf, beta=i / (i + 1), alpha=2.0 / (i + 1))
+            t_h = time.perf_counter() - t0
+            H.diagonal().add_(0.01 * H.diagonal().mean())
+            t0 = time.perf_counter()
+            torch.linalg.cholesky(torch.cholesky_inverse(torch.linalg.cholesky(H)), upper=True)  # :318-320
+            t_c = time.perf_counter() - t0
+        finally:
+            torch.set_num_threads(old_threads)
+        T_full = wl["nseq"] * wl["L"]
+        h_scale = sum(float(T_full) * shapes[n][1] ** 2 for n in names) / (float(ns * Ls) * Cs ** 2)
+        c_scale = sum(float(shapes[n][1]) ** 3 for n in names) / float(Cs) ** 3
+        est = {"update_s": t_h * h_scale, "prepare_chain_s": t_c * c_scale, "step_s": dt, "dequantize_pack_s": dt_codec}
+        total = sum(est.values())
+        return {"value": round(tot / total / 1e6, 4), "unit": "Mparams/s", "cores": threads, "kind": "port",
+                "sample": f"full path of {len(names)} of the block's {len(shapes)} Linears ({'/'.join(names)}, {tot / 1e6:.1f} M "
+                          f"params): GPTQ.step {dt:.1f} s and dequantize + pack {dt_codec:.1f} s measured in full (the oracle's C "
+                          f"restatement; ints equal to the GPU's: {same / cnt:.6f}); GPTQ.update measured as the reference's "
+                          f"own fp32 addmm on {ns} x {Ls} tokens x {Cs} channels ({t_h:.2f} s) and scaled x{h_scale:.0f} by "
+                          f"flops to the block's {len(names)} Hessians of {T_full} tokens; the Cholesky chain measured as "
+                          f"the reference's torch calls at C = {Cs} ({t_c:.2f} s) and scaled x{c_scale:.1f} by C^3",
+                "stages_s_per_block": {k: round(v, 2) for k, v in est.items()},
+                "step_only": {"value": round(tot / dt / 1e6, 3), "unit": "Mparams/s",
+                              "note": "GPTQ.step alone (r01/r02's figure): scale search + column loop + trailing update"}}
     except Exception as e:  # the bench line must still print
         return {"value": None, "unit": "Mparams/s", "cores": 0, "kind": "port", "sample": f"failed: {e!r}"}
 
@@ -627,14 +671,26 @@ def main():
         syrk_sum_ms, syrk_n, syrk_ms = prof.get("syrk", (0.0, 0, 0.0))
         flops = syrk_flops(wl, X) * args.steps
         ach = flops / (syrk_ms * 1e-3) / 1e12 if syrk_ms > 0 else None
+        # roofline.traffic: L2-miss reads per SYRK launch from a SEPARATE rocprofv3 --pmc pass of this command (the
+        # driver's run cannot carry counters: a --pmc run serialises the kernels).  The file names the kernel sources it
+        # was measured on; for any other build the field is null -- a stale constant is not a measurement.
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r02_syrk_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r03_syrk_traffic.json")
         if os.path.exists(tpath) and args.workload == "llama3-8b-block-q4k" and world == 1 and not args.calib_seqs \
                 and not args.seq_len:
-            try:  # L2-miss reads per SYRK launch from a separate rocprofv3 --pmc pass of THIS command
-                tj = json.load(open(tpath))  # written by profiles/pmc_bench_fetch.sh
-                traffic = {"GB_per_launch": tj["GB_per_launch"], "algorithmic_GB_per_launch": tj.get("algorithmic_GB_per_launch"),
-                           "measured_on": tj.get("measured_on"), "launches": tj.get("launches")}
+            try:
+                import glob
+                import hashlib
+                tj = json.load(open(tpath))  # written by profiles/collect_r03.sh
+                hsh = hashlib.sha256()
+                for fn in sorted(glob.glob(os.path.join(ROOT, "gptq-gguf-toolkit_amd", "csrc", "*.h*"))):
+                    hsh.update(open(fn, "rb").read())
+                if tj.get("kernel_sources_sha256") == hsh.hexdigest()[:16]:
+                    traffic = {"GB_per_launch": tj["GB_per_launch"], "algorithmic_GB_per_launch": tj.get("algorithmic_GB_per_launch"),
+                               "measured_on": tj.get("measured_on"), "launches": tj.get("launches")}
+                else:
+                    traffic = {"GB_per_launch": None, "note": "profiles/r03_syrk_traffic.json was measured on other kernel "
+                                                              "sources than this build's: not reported"}
             except Exception:
                 traffic = None
         roof = {"bound": "mfma", "kernel": "syrk16_256n_kernel<f16> (gq_h_accumulate_grouped)",

@@ -326,7 +326,7 @@ def _worker(rank, world, port, tmp, ret):
     data = [([], {"input_ids": ids}) for ids in data]
     model, fake = _run_driver(tmp, data, world)
     sd = {k: v.clone() for k, v in model.state_dict().items()}
-    ret[rank] = (sd, dict(fake.calls))
+    ret[rank] = (sd, dict(fake.calls, **{f"coll_{k}": v for k, v in dist_utils.collective_calls.items()}))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -420,7 +420,7 @@ def test_two_rank_row_split_matches_owner_mode(tmp_path):
 
 
 def test_two_rank_gloo_matches_single_rank(tmp_path):
-    """calib-sharded H (all-reduce AVG) + per-matrix owners + broadcast: every rank ends with the same
+    """calib-sharded H (all-reduce AVG) + per-matrix owners + one all-gather per block: every rank ends with the same
     quantized model, equal to the 1-rank run on the full calibration set up to H rounding order."""
     from make_golden_shim import tiny_calib
     world = 2
@@ -435,6 +435,10 @@ def test_two_rank_gloo_matches_single_rank(tmp_path):
         assert torch.equal(sd0[k], sd1[k]), f"ranks disagree on {k}"
     # owners split the work: each rank ran some, not all, of the 14 column loops
     assert 0 < calls0["gptq_quantize"] < 14 and calls0["gptq_quantize"] + calls1["gptq_quantize"] == 14
+    # the data-path collectives of the two blocks: one all-reduce per DISTINCT Hessian (4 per block; the reference: 7),
+    # ONE all-gather per block for all results (the reference: 5 broadcasts per Linear), no broadcast
+    for c in (calls0, calls1):
+        assert (c["coll_all_reduce"], c["coll_all_gather"], c["coll_broadcast"]) == (8, 2, 0), c
     d1 = str(tmp_path / "w1")
     os.makedirs(d1)
     data = [([], {"input_ids": ids}) for ids in tiny_calib()]
