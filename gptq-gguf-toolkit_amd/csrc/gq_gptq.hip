@@ -463,6 +463,15 @@ static int column_loop(float* W, const float* U, int64_t R, int64_t C, int q_typ
     // block has already updated
     const bool lookahead = (B == LA_B) && getenv("GQ_NO_LOOKAHEAD") == nullptr &&
                            (!uni || uni->group <= 0 || (la * B) % uni->group == 0);
+    // GQ_NEAR_LEFT=1 (r03 experiment, measured and left off): inside a super-block the updates become LEFT-looking --
+    // before block b runs, its columns receive the errors of the super-block's earlier blocks: at an even b the 256
+    // columns of blocks b and b + 1 (the lazy scale search of gptq.py:240-245 reads the whole 256-column group at b's
+    // first column) in ONE chained launch with K = 128 b, at an odd b the block's own 128 columns from block b - 1.
+    // Per element the same subtractions in the same order as the right-looking form (bit-identical: the parity tests
+    // pass either way), a quarter of its traffic on W -- and no faster: the chained 64-tile launches average 39 us
+    // (2.4 us per 32-k chunk against 0.46 us of matrix-pipe time: one or two workgroups per CU cannot cover the
+    // L2 latency of so short a chunk), 2.33 vs 2.30 ms of near updates inside the 4096 x 14336 loop.
+    const bool left_look = lookahead && getenv("GQ_NEAR_LEFT") != nullptr && (!uni || uni->group <= 0 || 256 % uni->group == 0);
     const int64_t ldE = lookahead ? (int64_t)LA * B : B;
     float* Err0 = reinterpret_cast<float*>(((uintptr_t)ws + 255) & ~(uintptr_t)255);
     float* Wblk = Err0 + (size_t)R * B * (B == LA_B ? 2 * LA : 1);
@@ -519,6 +528,18 @@ static int column_loop(float* W, const float* U, int64_t R, int64_t C, int q_typ
         if (far_async && pos == 0 && ev_bulk[sb & 1]) {  // this half of the error buffer: the helper is done with it
             GQ_HIP(hipStreamWaitEvent(st, ev_bulk[sb & 1], 0));
             ev_bulk[sb & 1] = nullptr;
+        }
+        if (left_look && pos > 0) {
+            const int64_t LS0 = sb * la * B, LS1 = (LS0 + la * B < C) ? LS0 + la * B : C;  // this super-block
+            if (pos & 1) {  // the errors of block b - 1 into this block's columns
+                if ((rc = launch_trailing_update(W + c1, C, Err + (pos - 1) * B, ldE, U + (c1 - B) * C + c1, C, R, c2 - c1, B, st)))
+                    return rc;
+            } else {        // the errors of blocks 0 .. b - 1 into the 256-column group that starts here
+                const int64_t n = (c1 + 2 * B < LS1) ? 2 * B : LS1 - c1;
+                ProfScope ps(PT_TRAILING, st);
+                if ((rc = launch_gemm32_ts<false, 0, false, 0, LA_B, 64>(W + c1, C, Err, ldE, U + LS0 * C + c1, C, R, n, pos * B, st)))
+                    return rc;
+            }
         }
         if (uni && uni->group > 0) {  // fast_obq.py:168-171 for every group that starts inside this block
             ProfScope ps(PT_SCALE_SEARCH, st);
@@ -586,7 +607,8 @@ static int column_loop(float* W, const float* U, int64_t R, int64_t C, int q_typ
             // Also dropped: a dedicated K = 128 kernel, one workgroup per CU with the whole K of both operands in LDS
             // (23.5 vs 17.3 us per launch).  A rank-128 update moves 16 B of operands L2 -> LDS per output element for
             // 256 flops at 64 x 64 tiles: it is L2-bandwidth-bound near 50 TFLOP/s whatever the schedule.)
-            if ((rc = launch_trailing_update(W + c2, C, Err + pos * B, ldE, U + c1 * C + c2, C, R, S1 - c2, ncols, st)))
+            if (!left_look &&
+                (rc = launch_trailing_update(W + c2, C, Err + pos * B, ldE, U + c1 * C + c2, C, R, S1 - c2, ncols, st)))
                 return rc;
             continue;
         }

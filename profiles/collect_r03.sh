@@ -46,7 +46,7 @@ if rows:
         h.update(open(fn, "rb").read())
     json.dump({"GB_per_launch": round(per, 2), "algorithmic_GB_per_launch": round(alg, 2), "launches": len(rows),
                "kernel_sources_sha256": h.hexdigest()[:16],
-               "measured_on": "rocprofv3 --pmc FETCH_SIZE x 2 KB (gfx950 correction) of `bench.py --steps 2 --warmup 1`, "
+               "measured_on": "rocprofv3 --pmc FETCH_SIZE x 2 KB (gfx950 correction) of bench.py --steps 2 --warmup 1, "
                               "default workload; per-dispatch values: profiles/r03_syrk_fetch_dispatches.csv"},
               open("$OUT/r03_syrk_traffic.json", "w"))
     print(f"{len(rows)} SYRK launches, {per:.2f} GB per launch (algorithmic {alg:.2f})")

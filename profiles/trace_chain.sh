@@ -2,7 +2,7 @@
 # rocprofv3 kernel trace of profiles/chain_probe.py (events off): every kernel of the critical chain, by total time
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
-mkdir -p $R/gpurun_out/trace_chain
+mkdir -p $R/gpurun_out/trace_chain $R/gpurun_out/r3
 PROF=0 timeout 200 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/trace_chain/p -o p -- python $R/profiles/chain_probe.py > $R/gpurun_out/trace_chain/p.log 2>&1 || echo "pass failed"
 python3 - <<PY
 import csv, glob, collections
