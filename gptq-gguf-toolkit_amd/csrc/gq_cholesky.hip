@@ -664,6 +664,10 @@ __global__ __launch_bounds__(256) void diag_blk_kernel(float* __restrict__ A, in
     }
 }
 
+}  // namespace gq
+#include "gq_diag5.hpp"
+namespace gq {
+
 // ---- the top recursion levels on pre-split operand images (gq_gemm3p.hpp) ----
 // A node (n1 | n2) goes there when both halves are multiples of 256 and at least p3_min() wide.  The schedules of all
 // its GEMMs depend on C only: they are planned once per C (cached), and uploaded with ONE copy per gq_h_prepare
@@ -828,7 +832,9 @@ static int chol_inv_rec(float* A, float* X, float* Tmp, int* flag, int64_t n, in
     if (hi - lo == 1) {
         ProfScope ps(PT_DIAG_POTRF, st);
         const int64_t o = (lo * NB) * n + lo * NB;
-        if (diag_lds == DIAG_BLK_LDS)
+        if (diag_lds == DIAG5_LDS)
+            hipLaunchKernelGGL(diag_blk5_kernel, dim3(1), dim3(320), diag_lds, st, A + o, n, X + o, n, flag);
+        else if (diag_lds == DIAG_BLK_LDS)
             hipLaunchKernelGGL(diag_blk_kernel, dim3(1), dim3(256), diag_lds, st, A + o, n, X + o, n, flag);
         else
             hipLaunchKernelGGL(diag_potrf_inv_kernel, dim3(1), dim3(256), diag_lds, st, A + o, n, X + o, n, flag);
@@ -954,13 +960,16 @@ int h_prepare(float* H, float* W, int64_t R, int64_t C, float rel_damp, float* U
     GQ_LAUNCH_CHECK();
     }
     static std::atomic<bool> attr_set{false};  // guards an idempotent call: a race sets the same value twice
-    static const bool use_ref = getenv("GQ_DIAG_REF") != nullptr;  // A/B: the column-by-column kernel
-    const size_t diag_lds = use_ref ? (2 * NB * LDP + NB) * sizeof(float) : DIAG_BLK_LDS;
+    const bool use_ref = getenv("GQ_DIAG_REF") != nullptr;  // A/B: the column-by-column kernel
+    const bool use_v1 = getenv("GQ_DIAG_V1") != nullptr;    // A/B: the four-wave kernel of r01/r02
+    const size_t diag_lds = use_ref ? (2 * NB * LDP + NB) * sizeof(float) : (use_v1 ? DIAG_BLK_LDS : DIAG5_LDS);
     if (!attr_set) {
         GQ_HIP(hipFuncSetAttribute((const void*)diag_potrf_inv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)((2 * NB * LDP + NB) * sizeof(float))));
         GQ_HIP(hipFuncSetAttribute((const void*)diag_blk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)DIAG_BLK_LDS));
+        GQ_HIP(hipFuncSetAttribute((const void*)diag_blk5_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)DIAG5_LDS));
         attr_set = true;
     }
     if ((rc = chol_inv_rec(A, X, U, not_invertible, n, 0, nblk, diag_lds, st, run))) return rc;

@@ -1,0 +1,399 @@
+// gq_diag5.hpp -- the 128x128 leaf of the blocked Cholesky-with-inverse (K3), five-wave pipelined variant (r03).
+// Included by gq_cholesky.hip only (after rdlane / d_updates / mfma_nt_32 / NB / LDQ / TQ are defined).
+//
+// Same contract as diag_blk_kernel: A_kk (lower) -> L_kk in place, Xout = L_kk^-1 (whole block, zeros above the
+// diagonal), *flag = 1 on a non-positive pivot.  What changes is who waits for whom inside a 32-column sub-block.
+// In diag_blk_kernel the wave that factors the 32x32 diagonal sub-block also inverts it, because the panel below is
+// computed as P = A X^T on the matrix cores: 2 x 496 dependent broadcast-update pairs on ONE wave, 64 % of the kernel.
+// Here
+//   * the wave that owns the diagonal rows runs the same right-looking elimination in registers and PUBLISHES every
+//     finished column of L (column- and row-major), its inverse pivot and a step counter in LDS;
+//   * the waves that own the panel rows below apply the SAME eliminations to their rows, one step behind: column j of
+//     L arrives as wave-uniform 16-byte LDS reads and the update is a VGPR x VGPR fma -- the panel L21 falls out of
+//     the elimination itself: no inverse, no MFMA product, no barrier;
+//   * a fifth wave runs the forward substitution for the inverse of the diagonal sub-block one ROW behind (row R of L
+//     is final once column R is published); only the final assembly of L^-1 needs it.
+// The three are ordered by the step counter alone (LDS executes one wave's operations in order: data read after a
+// counter value that covers it is the published data; the counter only grows).  Critical path per sub-block: one
+// factorisation instead of factor + inverse + panel product.
+#pragma once
+
+namespace gq {
+
+constexpr int D5_ISPLIT = 29;  // rows of the inverse done before the sub-block barrier (the rest: behind it)
+constexpr int LR5 = 36;  // row stride of the row-major copy of the diagonal sub-block (rows 16-byte aligned)
+constexpr size_t DIAG5_LDS = (size_t)(2 * NB * LDQ + 5 * 32 * TQ + 32 * 32 + 32 * LR5 + 32 + 4) * sizeof(float);
+typedef float d5_f4 __attribute__((ext_vector_type(4)));
+
+// (immediate offsets: with the step's offset added to the address in C++ the compiler hoists 3 x 32 address VGPRs out
+// of the sub-block loop and spills them)
+template <int OFF>
+__device__ __forceinline__ void d5_st(unsigned addr, float v) {
+    asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void d5_sti(unsigned addr, int v) { asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
+
+// the diagonal wave.  Per column J only the pivot chain is serial: pivot -> 1/sqrt -> column J of L -> the ONE update
+// the next pivot needs, a[J+1] -= a[J] L[J+1][J] (a v_readlane broadcast).  The other 30 - J updates of the column take
+// their broadcast operands from LDS instead -- the wave reads back the column it has just published, like the panel
+// waves do -- one column LATE, under the next column's pivot chain: a[c] (c >= J + 2) receives column J's update during
+// step J + 1, before pivot J + 2 needs it.  (Measured with cycle stamps, profiles/micro/diag5_stamps.hip: with all
+// 31 - J updates as v_readlane + v_fma pairs on the chain, a 32-column factorisation takes 15.5k cycles -- 480 per
+// column; the sums differ from strict right-looking order only in the order of two subtractions per element.)
+template <int VOFF>
+__device__ __forceinline__ void d5_read_col(unsigned vbase, d5_f4 (&v)[8]) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[0]) : "v"(vbase), "n"(VOFF + 0) : "memory");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[1]) : "v"(vbase), "n"(VOFF + 16) : "memory");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[2]) : "v"(vbase), "n"(VOFF + 32) : "memory");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[3]) : "v"(vbase), "n"(VOFF + 48) : "memory");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[4]) : "v"(vbase), "n"(VOFF + 64) : "memory");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[5]) : "v"(vbase), "n"(VOFF + 80) : "memory");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[6]) : "v"(vbase), "n"(VOFF + 96) : "memory");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[7]) : "v"(vbase), "n"(VOFF + 112) : "memory");
+}
+// chunks Q0..7 only (the columns a step still needs)
+template <int VOFF, int Q0>
+__device__ __forceinline__ void d5_read_col_from(unsigned vbase, d5_f4 (&v)[8]) {
+    if constexpr (Q0 <= 0) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[0]) : "v"(vbase), "n"(VOFF + 0) : "memory");
+    if constexpr (Q0 <= 1) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[1]) : "v"(vbase), "n"(VOFF + 16) : "memory");
+    if constexpr (Q0 <= 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[2]) : "v"(vbase), "n"(VOFF + 32) : "memory");
+    if constexpr (Q0 <= 3) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[3]) : "v"(vbase), "n"(VOFF + 48) : "memory");
+    if constexpr (Q0 <= 4) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[4]) : "v"(vbase), "n"(VOFF + 64) : "memory");
+    if constexpr (Q0 <= 5) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[5]) : "v"(vbase), "n"(VOFF + 80) : "memory");
+    if constexpr (Q0 <= 6) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[6]) : "v"(vbase), "n"(VOFF + 96) : "memory");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[7]) : "v"(vbase), "n"(VOFF + 112) : "memory");
+}
+__device__ __forceinline__ void d5_wait_col(d5_f4 (&v)[8]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])
+                 :: "memory");
+}
+
+typedef float d5_f2 __attribute__((ext_vector_type(2)));
+// a[c] = fma(-p, L[c], a[c]) for c = C0..31, two columns per v_pk_fma_f32 (the diagonal wave is bound by its own
+// instruction count: one wave issues a VALU instruction every ~8 cycles); every result pinned in program order
+template <int C0>
+__device__ __forceinline__ void d5_update_from(float (&a)[32], float p, const d5_f4 (&L)[8]) {
+    if constexpr (C0 < 32 && (C0 & 1)) {
+        a[C0] = fmaf(-p, L[C0 >> 2][C0 & 3], a[C0]);
+        asm volatile("" : "+v"(a[C0]));
+    }
+    const d5_f2 np = {-p, -p};
+#pragma unroll
+    for (int c = (C0 + 1) & ~1; c < 32; c += 2) {
+        d5_f2 t = {a[c], a[c + 1]};
+        const d5_f2 l = {L[c >> 2][c & 3], L[c >> 2][(c & 3) + 1]};
+        t = __builtin_elementwise_fma(np, l, t);
+        asm volatile("" : "+v"(t));
+        a[c] = t.x;
+        a[c + 1] = t.y;
+    }
+}
+
+// Lp: column J - 1 of L as read back from LDS (issued at the end of step J - 1); ap = this lane's a[J - 1]
+template <int J>
+__device__ __forceinline__ void d5_factor(float (&a)[32], int i, bool& bad, unsigned lcol, unsigned lcolb, unsigned lrow,
+                                          unsigned invs, unsigned flag, int base, int lane, d5_f4 (&Lp)[8]) {
+    asm volatile("s_nop 1" : "+v"(a[J]));
+    float pj = rdlane(a[J], J);
+    if (!(pj > 0.0f)) {  // wave-uniform; also NaN
+        bad = true;
+        pj = 1.0f;
+    }
+    float inv = __builtin_amdgcn_rsqf(pj);
+    inv = fmaf(inv, fmaf(-0.5f * pj * inv, inv, 0.5f), inv);  // one Newton step (see d_factor)
+    // L[i][J] = a[J] / sqrt(pivot) for every row -- row J included: its a[J] IS the pivot (no select, no lane compare)
+    a[J] = a[J] * inv;
+    // column J (rows J..31 final) in both layouts, the inverse pivot, THEN the step counter.  `inv` and the counter
+    // are wave-uniform: every lane stores the same value to the same address (no exec masking on the pivot chain)
+    d5_st<J * 32 * 4>(lcol, a[J]);  // lcol already points at this lane's row: Lcol[J][i]
+    d5_st<J * 4>(lrow, a[J]);       // lrow points at this lane's row: Lrow[i][J]
+    d5_st<J * 4>(invs, inv);
+    d5_sti(flag, base + J + 1);
+    if constexpr (J < 31) {
+        // the one update on the pivot chain
+        asm volatile("s_nop 1" : "+v"(a[J]));  // v_readlane of the VGPR just written
+        const float l = rdlane(a[J], J + 1);
+        a[J + 1] = fmaf(-a[J], l, a[J + 1]);
+        asm volatile("" : "+v"(a[J + 1]));
+    }
+    if constexpr (J >= 1 && J < 31) {
+        // column J - 1's updates of a[J + 1 ..]: operands read back from LDS during this step's pivot chain
+        d5_wait_col(Lp);
+        d5_update_from<J + 1>(a, a[J - 1], Lp);
+    }
+    if constexpr (J < 30) {
+        // column J, for the next step's updates of a[J + 2 ..] (LDS is in order: behind the stores above)
+        d5_read_col_from<J * 32 * 4, (J + 2) / 4>(lcolb, Lp);
+        d5_factor<J + 1>(a, i, bad, lcol, lcolb, lrow, invs, flag, base, lane, Lp);
+    } else if constexpr (J == 30) {
+        d5_factor<J + 1>(a, i, bad, lcol, lcolb, lrow, invs, flag, base, lane, Lp);
+    }
+}
+
+// Followers (panel waves, inverse wave) never hammer the LDS: they remember how far the diagonal wave had come when
+// they last looked (`avail`) and poll the step counter -- ONE 4-byte read, then a sleep -- only when they have caught
+// up with it.  (Measured: with every poll fetching the whole column, four spinning waves saturate the LDS pipe and the
+// diagonal wave's own stores queue behind them: its factorisation went from 8.5k to 15.5k cycles.)
+__device__ __forceinline__ void d5_need(unsigned flag, int need, int& avail) {
+    while (avail < need) {
+        int f;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(f) : "v"(flag) : "memory");
+        avail = __builtin_amdgcn_readfirstlane(f);
+        if (avail < need) __builtin_amdgcn_s_sleep(2);
+    }
+}
+template <int OFF>
+__device__ __forceinline__ void d5_read_f32(unsigned base, float& v) {
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(base), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void d5_wait_col1(d5_f4 (&v)[8], float& sc) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(sc), "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])
+                 :: "memory");
+}
+
+// a panel wave (rows below the diagonal sub-block): elimination step J on its rows.  Lc / invj: column J of L and
+// 1 / L[J][J], already fetched; column J + 1 is fetched under this step's updates.
+template <int J>
+__device__ __forceinline__ void d5_panel(float (&a)[32], unsigned lcolb, unsigned invs, unsigned flag, int base, int& avail,
+                                         d5_f4 (&Lc)[8], float invj, d5_f4 (&Ln)[8]) {
+    const float p = a[J] * invj;
+    a[J] = p;
+    float invn = 0.0f;
+    if constexpr (J < 31) {
+        d5_need(flag, base + J + 2, avail);
+        d5_read_f32<(J + 1) * 4>(invs, invn);
+        d5_read_col_from<(J + 1) * 32 * 4, (J + 2) / 4>(lcolb, Ln);  // Lcol[J + 1][c] = L[c][J + 1], c >= J + 2
+    }
+    // (pinned in program order inside: left alone the compiler sinks all updates behind all the fetches of the later
+    // steps, with every fetched column spilled to scratch)
+    d5_update_from<J + 1>(a, p, Lc);
+    if constexpr (J < 31) {
+        d5_wait_col1(Ln, invn);
+        d5_panel<J + 1>(a, lcolb, invs, flag, base, avail, Ln, invn, Lc);
+    }
+}
+
+// the inverse wave: row R of X = L^-1 (lane i = column i), forward substitution; Lc / irr: row R of L and 1 / L[R][R]
+// Rows R .. REND - 1; on return with REND < 32, row REND's data sits in the buffer of its parity and `irr_out`.
+template <int R, int REND>
+__device__ __forceinline__ void d5_inverse(float (&x)[32], int i, unsigned lrowb, unsigned invs, unsigned flag, int base,
+                                           int& avail, d5_f4 (&Lc)[8], float irr, d5_f4 (&Ln)[8], float& irr_out) {
+    float irn = 0.0f;
+    if constexpr (R < 31) {
+        d5_need(flag, base + R + 2, avail);
+        d5_read_f32<(R + 1) * 4>(invs, irn);
+        d5_read_col<(R + 1) * LR5 * 4>(lrowb, Ln);  // Lrow[R + 1][0..31]; entries p > R unused
+    }
+    // sum_{p < R} L[R][p] x[p]: two terms per v_pk_fma_f32, two independent chains
+    d5_f2 acc2[2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
+#pragma unroll
+    for (int p = 0; p + 1 < R; p += 2) {
+        const d5_f2 l = {Lc[p >> 2][p & 3], Lc[p >> 2][(p & 3) + 1]};
+        const d5_f2 xx = {x[p], x[p + 1]};
+        acc2[(p >> 1) & 1] = __builtin_elementwise_fma(l, xx, acc2[(p >> 1) & 1]);
+    }
+    float tail = 0.0f;
+    if constexpr (R & 1) tail = Lc[(R - 1) >> 2][(R - 1) & 3] * x[R - 1];
+    const float dot = ((acc2[0].x + acc2[0].y) + (acc2[1].x + acc2[1].y)) + tail;
+    int ii = i;
+    asm volatile("" : "+v"(ii));
+    x[R] = (R < ii) ? 0.0f : ((R == ii) ? irr : -dot * irr);
+    asm volatile("" : "+v"(x[R]));  // pinned before the next row's fetch (see d5_panel)
+    if constexpr (R < 31) {
+        d5_wait_col1(Ln, irn);
+        if constexpr (R + 1 < REND) d5_inverse<R + 1, REND>(x, i, lrowb, invs, flag, base, avail, Ln, irn, Lc, irr_out);
+        else irr_out = irn;
+    }
+}
+
+#ifdef D5_STAMPS  // profiles/micro/diag5_stamps.hip: cycle stamps of the phases (one workgroup)
+__device__ long long d5_stamps[128];
+#define D5_STAMP(k) do { if (lane == 0) d5_stamps[(k)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define D5_STAMP(k) (void)0
+#endif
+
+__global__ __launch_bounds__(320) void diag_blk5_kernel(float* __restrict__ A, int64_t lda, float* __restrict__ Xout,
+                                                        int64_t ldx, int* __restrict__ flag_out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* S = smem;                       // [NB][LDQ]  A (lower) -> L, zeros above the diagonal
+    float* X = smem + NB * LDQ;            // [NB][LDQ]  L^-1 (lower), zeros above
+    float* Tw0 = X + NB * LDQ;             // [5][32][TQ] wave-private scratch tiles
+    float* Lcol = Tw0 + 5 * 32 * TQ;       // [32][32]   Lcol[j][i] = L[i][j] of the current diagonal sub-block
+    float* Lrow = Lcol + 32 * 32;          // [32][LR5]  Lrow[i][j] = L[i][j]
+    float* Invs = Lrow + 32 * LR5;         // [32]       1 / L[j][j]
+    int* Step = reinterpret_cast<int*>(Invs + 32);  // published steps so far: 32 sb + j + 1
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    float* Tw = Tw0 + wid * 32 * TQ;
+    if (tid == 0) *Step = 0;
+    if (wid == 0) D5_STAMP(0);
+    if (tid < 256) {  // 16-byte global accesses; chunks entirely above the diagonal are not read at all
+        float4 v[NB * NB / 4 / 256];
+#pragma unroll
+        for (int q = 0; q < NB * NB / 4 / 256; ++q) {
+            const int idx = tid + q * 256, r = idx / (NB / 4), c = (idx % (NB / 4)) * 4;
+            v[q] = (c <= r) ? *reinterpret_cast<const float4*>(A + r * lda + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int q = 0; q < NB * NB / 4 / 256; ++q) {
+            const int idx = tid + q * 256, r = idx / (NB / 4), c = (idx % (NB / 4)) * 4;
+            S[r * LDQ + c + 0] = (c + 0 <= r) ? v[q].x : 0.0f;
+            S[r * LDQ + c + 1] = (c + 1 <= r) ? v[q].y : 0.0f;
+            S[r * LDQ + c + 2] = (c + 2 <= r) ? v[q].z : 0.0f;
+            S[r * LDQ + c + 3] = (c + 3 <= r) ? v[q].w : 0.0f;
+        }
+    }
+    __syncthreads();
+    if (wid == 0) D5_STAMP(1);
+    const unsigned lcol_b = (unsigned)(uintptr_t)Lcol, lrow_b = (unsigned)(uintptr_t)Lrow;
+    const unsigned invs_b = (unsigned)(uintptr_t)Invs, step_b = (unsigned)(uintptr_t)Step;
+    const int lc = lane & 31, lh = lane >> 5;  // MFMA D layout: col = lc, row = (e&3) + 8*(e>>2) + 4*lh
+    const int i = lane & 31;                   // lanes 32-63 mirror 0-31 (same addresses, same values)
+    float xinv[32];          // wave 4: the inverse rows, live across the barrier
+    d5_f4 xL0[8], xL1[8];
+    float xirr = 0.0f;
+    for (int sb = 0; sb < 4; ++sb) {
+        const int c0 = 32 * sb, base = 32 * sb;
+        if (wid == sb) {
+            // ---- the diagonal rows: factor in registers, publish column by column
+            float a[32];
+#pragma unroll
+            for (int c = 0; c < 32; ++c) a[c] = S[(c0 + i) * LDQ + c0 + c];
+            bool bad = false;
+            d5_f4 Lp[8];
+            d5_factor<0>(a, i, bad, lcol_b + (unsigned)(i * 4), lcol_b, lrow_b + (unsigned)(i * LR5 * 4), invs_b, step_b, base, lane, Lp);
+            if (lane < 32) {
+#pragma unroll
+                for (int c = 0; c < 32; ++c) {
+                    int ii = i;  // opaque: no 32 precomputed (c <= lane) masks
+                    asm volatile("" : "+v"(ii));
+                    S[(c0 + i) * LDQ + c0 + c] = (c <= ii) ? a[c] : 0.0f;
+                }
+                if (bad && lane == 0) *flag_out = 1;
+            }
+        } else if (wid > sb && wid < 4) {
+            // ---- panel rows 32 wid .. 32 wid + 31: the same eliminations, one step behind
+            float a[32];
+#pragma unroll
+            for (int c = 0; c < 32; ++c) a[c] = S[(32 * wid + i) * LDQ + c0 + c];
+            int avail = 0;
+            d5_f4 L0[8], L1[8];
+            float inv0;
+            d5_need(step_b, base + 1, avail);
+            d5_read_f32<0>(invs_b, inv0);
+            d5_read_col<0>(lcol_b, L0);
+            d5_wait_col1(L0, inv0);
+            d5_panel<0>(a, lcol_b, invs_b, step_b, base, avail, L0, inv0, L1);
+            if (lane < 32) {
+#pragma unroll
+                for (int c = 0; c < 32; ++c) S[(32 * wid + i) * LDQ + c0 + c] = a[c];
+            }
+        } else if (wid == 4) {
+            // ---- the inverse of the diagonal sub-block, one row behind (lane i = column i).  Its last rows and the
+            // write of X_ii run AFTER the barrier, next to the other waves' trailing update (the wave takes no product
+            // there): row R needs column R published, so the wave always ends a row behind the diagonal wave
+            int avail = 0;
+            float inv0;
+            d5_need(step_b, base + 1, avail);
+            d5_read_f32<0>(invs_b, inv0);
+            d5_read_col<0>(lrow_b, xL0);
+            d5_wait_col1(xL0, inv0);
+            d5_inverse<0, D5_ISPLIT>(xinv, i, lrow_b, invs_b, step_b, base, avail, xL0, inv0, xL1, xirr);
+        }
+        D5_STAMP(16 + 8 * sb + wid);  // every wave: its register phase is over
+        __syncthreads();
+        if (wid == 0) D5_STAMP(2 + 2 * sb);
+        if (wid == 4) {
+            int avail = base + 32;  // every column is published: the barrier is behind us
+            d5_inverse<D5_ISPLIT, 32>(xinv, i, lrow_b, invs_b, step_b, base, avail, (D5_ISPLIT & 1) ? xL1 : xL0, xirr,
+                                      (D5_ISPLIT & 1) ? xL0 : xL1, xirr);
+            if (lane < 32) {
+#pragma unroll
+                for (int c = 0; c < 32; ++c) X[(c0 + c) * LDQ + c0 + i] = xinv[c];
+            }
+        }
+        // ---- trailing update of the remaining lower sub-blocks: S_ij -= P_i P_j^T (matrix cores)
+        int t = 0;
+        for (int bi = sb + 1; bi < 4; ++bi)
+            for (int bj = sb + 1; bj <= bi; ++bj, ++t) {
+                if ((t & 3) != wid) continue;  // waves 0-3; wave 4 finishes the inverse
+                f32x16 acc = mfma_nt_32(S + (32 * bi) * LDQ + c0, LDQ, S + (32 * bj) * LDQ + c0, LDQ, lane);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float* p = S + (32 * bi + (e & 3) + 8 * (e >> 2) + 4 * lh) * LDQ + 32 * bj + lc;
+                    *p = *p - acc[e];
+                }
+            }
+        __syncthreads();
+        if (wid == 0) D5_STAMP(3 + 2 * sb);
+    }
+    // ---- L^-1 below the diagonal sub-blocks, by halves: X21 = -X22 (L21 X11) at the 32-level inside each 64-half
+    // (two independent one-tile problems, wave-private scratch: no barrier inside), then the 64x64 block X[2:4][0:2] from
+    // the 64-halves (four tiles on four waves, one barrier between the two products): 2 + 4 products of depth <= 2
+    // chunks on the critical path instead of the 3 + 2 + 1 distance rounds of diag_blk_kernel with two barriers each.
+    {
+        const int li = lane & 31, lk = lane >> 5;
+        // acc += A[32 x 32 at (ar, ak)] B[32 x 32 at (ak-rows, bc)], A from PA (row stride lda_), B from PB
+        auto prod = [&](f32x16& acc, const float* PA, int lda_, int ar, int ak, const float* PB, int ldb_, int bk, int bc) {
+            float av[16], bv[16];
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                av[p] = PA[(ar + li) * lda_ + ak + 2 * p + lk];
+                bv[p] = PB[(bk + 2 * p + lk) * ldb_ + bc + li];
+            }
+#pragma unroll
+            for (int p = 0; p < 16; ++p) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p], bv[p], acc, 0, 0, 0);
+        };
+        auto zero = [](f32x16& acc) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+        };
+        auto put = [&](float* P, int ld_, int r0, int c0_, const f32x16& acc, float sgn) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) P[(r0 + (e & 3) + 8 * (e >> 2) + 4 * lh) * ld_ + c0_ + lc] = sgn * acc[e];
+        };
+        if (wid < 2) {  // X[1][0] and X[3][2]
+            const int bi = 2 * wid + 1, bj = 2 * wid;
+            f32x16 acc;
+            zero(acc);
+            prod(acc, S, LDQ, 32 * bi, 32 * bj, X, LDQ, 32 * bj, 32 * bj);  // T = L[bi][bj] X[bj][bj]
+            put(Tw, TQ, 0, 0, acc, 1.0f);
+            zero(acc);
+            prod(acc, X, LDQ, 32 * bi, 32 * bi, Tw, TQ, 0, 0);              // X[bi][bi] T
+            put(X, LDQ, 32 * bi, 32 * bj, acc, -1.0f);
+        }
+        __syncthreads();
+        const int r = (wid >> 1) & 1, c = wid & 1;  // tile (2 + r, c) of the lower-left 64 x 64 block
+        if (wid < 4) {  // T[r][c] = sum_{k = c..1} L[2 + r][k] X[k][c]   (X[0][1] = 0)
+            f32x16 acc;
+            zero(acc);
+            for (int k = c; k < 2; ++k) prod(acc, S, LDQ, 32 * (2 + r), 32 * k, X, LDQ, 32 * k, 32 * c);
+            put(Tw, TQ, 0, 0, acc, 1.0f);
+        }
+        __syncthreads();
+        if (wid < 4) {  // X[2 + r][c] = -sum_{k = 0..r} X[2 + r][2 + k] T[k][c]
+            f32x16 acc;
+            zero(acc);
+            for (int k = 0; k <= r; ++k) prod(acc, X, LDQ, 32 * (2 + r), 32 * (2 + k), Tw0 + (2 * k + c) * 32 * TQ, TQ, 0, 0);
+            put(X, LDQ, 32 * (2 + r), 32 * c, acc, -1.0f);
+        }
+        __syncthreads();
+    }
+    if (wid == 0) D5_STAMP(10);
+    for (int idx = tid; idx < NB * NB / 4; idx += 320) {
+        const int r = idx / (NB / 4), c = (idx % (NB / 4)) * 4;
+        const float* sr = S + r * LDQ + c;
+        const float* xr = X + r * LDQ + c;
+        // X in LDS holds the lower 32x32 sub-blocks only (diagonal ones whole, with their zeros): above them zeros go out
+        *reinterpret_cast<float4*>(Xout + r * ldx + c) =
+            (c >> 5) > (r >> 5) ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(xr[0], xr[1], xr[2], xr[3]);
+        // L_kk itself is NOT written back: nothing in the chain reads a diagonal block of L after its leaf (the panel
+        // below uses X_kk = L_kk^-1, the factor is not an output of gq_h_prepare) -- diag_blk_kernel still stores it
+        (void)sr;
+    }
+    if (wid == 0) D5_STAMP(11);
+}
+
+}  // namespace gq
