@@ -25,8 +25,9 @@ schedules kernels:
                         have the same all-zero columns (U depends on H, the dead channels and that set only,
                         gptq.py:307-313); the sets are compared on the device when the block's first sample has
                         shown who shares what, and the answer reaches the host long before quantize();
-               phase 2  [N>1] broadcast from the owner / all-gather of row slices, in handle order on every
-                        rank; the dequantized weight is written back (quantizer.py:257-264).
+               phase 2  [N>1] ONE all-gather per block: every rank contributes what it computed (the matrices it
+                        owns, its row slices of the row-split ones) as one packed byte buffer; the dequantized
+                        weight is written back (quantizer.py:257-264).
 quantize() never synchronises the host with the device (dense Linears): everything is ordered by streams and
 events, so the caller's next launches (the block's second forward, or the next block of a benchmark) queue up
 behind the chains.  The device-side flags of the reused factorisations are kept in `BlockSchedule.unverified`,
@@ -57,7 +58,11 @@ def _chain_streams(device, n: int):
         return []
     pool = _stream_pool.setdefault(torch.device(device), [])
     while len(pool) < n:
-        pool.append(torch.cuda.Stream(device))  # (a high-priority stream for the costliest chain: no gain, measured)
+        # (measured and dropped: a high-priority stream for the costliest chain -- no gain; r03: side lanes confined to
+        # 128-224 CUs by hipExtStreamCreateWithCUMask so that the costliest chain always finds free CUs -- its
+        # factorisation takes 25 ms inside a step against 14.5 alone -- 115-121 ms per step against 95: kernels of
+        # CU-masked queues start far slower on this platform, as the far-update helper found in r02)
+        pool.append(torch.cuda.Stream(device))
     return pool[:n]
 
 
