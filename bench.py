@@ -216,7 +216,14 @@ def trailing_update_legs(wl, W16, X, in_region):
         del H, xs
         B, sb = 128, 1024
         far = sum(2.0 * R * (min(s0 + sb, C) - s0) * (C - min(s0 + sb, C)) for s0 in range(0, C, sb))
-        near = sum(2.0 * R * B * (min((c1 // sb + 1) * sb, C) - (c1 + B)) for c1 in range(0, C, B))
+        near_all = sum(2.0 * R * B * (min((c1 // sb + 1) * sb, C) - (c1 + B)) for c1 in range(0, C, B))
+        if os.environ.get("GQ_NEAR_CLASSIC") or os.environ.get("GQ_NEAR_LEFT"):
+            near, fused = near_all, 0.0
+        else:
+            # r03: an even block's errors reach its partner block inside the column-loop kernel (not a GEMM launch: its
+            # flops are NOT counted here); the launches are the chained K = 256 updates after every 256-column group
+            near = sum(2.0 * R * 2 * B * (min((c1 // sb + 1) * sb, C) - (c1 + 2 * B)) for c1 in range(0, C, 2 * B))
+            fused = near_all - near
         best, loop_ms = {}, {}
         helper_was = ops.far_helper_enable(True)
         try:
@@ -249,7 +256,7 @@ def trailing_update_legs(wl, W16, X, in_region):
         nms, nn_, _ = best.get("trailing_gemm32", (0.0, 0, 0.0))
         out = {"bound": "mfma", "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "linear": f"{name} {R}x{C}",
                "U": "gq_h_prepare of this Linear's Hessian (8 calibration sequences)",
-               "kernels": "gemm32_chain_full_kernel<128> (far), gemm32_kernel (near)"}
+               "kernels": "gemm32_chain_full_kernel<128> (far, K = 1024, and near: K = 256 after every 256-column group)"}
         if fn:
             a = far / (fms * 1e-3) / 1e12
             out["far_alone"] = {"achieved": round(a, 2), "frac": round(a / PEAK_F32_MFMA_TFLOPS, 4), "launches": fn,
@@ -257,7 +264,9 @@ def trailing_update_legs(wl, W16, X, in_region):
         if fn and nn_:
             a = (far + near) / ((fms + nms) * 1e-3) / 1e12
             out["whole_alone"] = {"achieved": round(a, 2), "frac": round(a / PEAK_F32_MFMA_TFLOPS, 4),
-                                  "launches": fn + nn_, "ms": round(fms + nms, 3), "near_ms": round(nms, 3)}
+                                  "launches": fn + nn_, "ms": round(fms + nms, 3), "near_ms": round(nms, 3),
+                                  "near_GFLOP": round(near / 1e9, 1), "far_GFLOP": round(far / 1e9, 1),
+                                  "GFLOP_inside_the_column_loop_kernel_not_counted": round(fused / 1e9, 1)}
         out["loop_ms"] = {"one_stream": round(loop_ms["one_stream"], 2), "as_run": round(loop_ms["as_run"], 2),
                           "far_updates_on_helper_stream": bool(ops.uses_helper_stream(R, C, B))}
         if in_region and in_region[1]:

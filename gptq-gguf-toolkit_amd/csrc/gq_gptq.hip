@@ -53,8 +53,9 @@ __global__ __launch_bounds__(SEG_WAVES * 64) void gptq_segment_kernel(
     const uint8_t* __restrict__ m, int G, int is_signed, float qmin, float qmax,
     uint8_t* __restrict__ qweight, float* __restrict__ Err, int64_t ld_err, int64_t err_col0,
     const int32_t* __restrict__ perm, const float* __restrict__ uscale = nullptr,
-    const float* __restrict__ uzero = nullptr) {  // PERM (act_order, gptq.py:211-216): column j takes the parameters of
-                                         // the group of its ORIGINAL column perm[j]
+    const float* __restrict__ uzero = nullptr,  // PERM (act_order, gptq.py:211-216): column j takes the parameters of
+                                                // the group of its ORIGINAL column perm[j]
+    const float* __restrict__ Unext = nullptr) {  // != nullptr: U[a .. a+127][a+128 .. a+255]; epilogue below
     // One workgroup = 64 rows (lane = row) x SEG_WAVES waves.  Wave 0 walks the columns (the dependent chain) one
     // 16-column sub-block ("tile") at a time; the rank-1 updates of the later tiles run UNDER the next chain:
     //   iteration t:  wave 0: chain(t) -> -err of tile t into ne[t & 1]
@@ -202,6 +203,12 @@ __global__ __launch_bounds__(SEG_WAVES * 64) void gptq_segment_kernel(
         // (packed v_pk_mul_f32 / v_pk_add_f32 were measured 35 % SLOWER here)
         if (wid != 0 && t > 0) {
             const float* nep = ne + ((t - 1) & 1) * (SB * 64);
+            if (Unext != nullptr && wid == SEG_WAVES - 1) {
+                // the epilogue wants all 128 (negated) errors of the block: tile t-1's go where its working columns were
+                // (dead since its chain started), off the chain's wave
+#pragma unroll
+                for (int k = 0; k < SB; ++k) wl[(i0 - SB + k) * 64 + lane] = nep[k * 64 + lane];
+            }
             int turn = 0;
             for (int j0 = i0 + SB; j0 < len; j0 += SB, ++turn) {
                 if ((turn % (SEG_WAVES - 1)) + 1 != wid) continue;
@@ -241,6 +248,38 @@ __global__ __launch_bounds__(SEG_WAVES * 64) void gptq_segment_kernel(
         }
 #endif
         __syncthreads();
+    }
+    // ---- epilogue (r03): this block's errors into the NEXT block's 128 columns (its partner in the 256-column
+    // scale-search group), W[rows, a+128 ..] -= E[64 x 128] U[a .., a+128 ..], on the matrix cores: per element a
+    // k-ordered fma chain from 0 and one subtraction, exactly what the separate rank-128 launch (gemm32_kernel, MODE 0)
+    // computed -- here with the negated errors the kernel already keeps, sum' = -sum exactly, w + sum' = w - sum -- so
+    // the launch, its gap and its W round trip disappear.  U's diagonal block in LDS is dead once the chains are through.
+    if (Unext != nullptr) {
+        for (int idx = tid; idx < SEG * (SEG / 4); idx += SEG_WAVES * 64) {
+            const int i = idx / (SEG / 4), j4 = (idx % (SEG / 4)) * 4;
+            *reinterpret_cast<float4*>(Us + i * SEG + j4) = *reinterpret_cast<const float4*>(Unext + (int64_t)i * C + j4);
+        }
+        __syncthreads();
+        const int rb = (wid & 1) * 32, cb = (wid >> 1) * 32;  // 2 x 4 sub-tiles of 32 x 32, one per wave
+        const int li = lane & 31, lk = lane >> 5;
+        const float* nel = ne + ((ntile - 1) & 1) * (SB * 64);  // the last tile's errors never moved
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+#pragma unroll 8
+        for (int k0 = 0; k0 < SEG; k0 += 2) {
+            const int k = k0 + lk;
+            const float ev = (k < SEG - SB) ? wl[k * 64 + rb + li] : nel[(k - (SEG - SB)) * 64 + rb + li];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ev, Us[k * SEG + cb + li], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int64_t rr = (int64_t)blockIdx.x * 64 + rb + (e & 3) + 8 * (e >> 2) + 4 * lk;
+            if (rr < R) {
+                float* p = W + rr * C + a + SEG + cb + li;
+                *p = *p + acc[e];
+            }
+        }
     }
 }
 
@@ -472,6 +511,13 @@ static int column_loop(float* W, const float* U, int64_t R, int64_t C, int q_typ
     // (2.4 us per 32-k chunk against 0.46 us of matrix-pipe time: one or two workgroups per CU cannot cover the
     // L2 latency of so short a chunk), 2.33 vs 2.30 ms of near updates inside the 4096 x 14336 loop.
     const bool left_look = lookahead && getenv("GQ_NEAR_LEFT") != nullptr && (!uni || uni->group <= 0 || 256 % uni->group == 0);
+    // r03, default: near updates at the granularity of the 256-column scale-search groups.  An even block hands its
+    // errors to its partner (the odd block of the group) in the column-loop kernel's epilogue; after the odd block ONE
+    // chained launch (K = 256, chain 128) brings both blocks' errors to the rest of the super-block.  Per element the
+    // same subtractions in the same order as after-every-block updates (bit-identical: the parity tests run both);
+    // 3 launches per super-block instead of 7.  GQ_NEAR_CLASSIC=1: one launch after every block (r02).
+    const bool pair_look = lookahead && !left_look && getenv("GQ_NEAR_CLASSIC") == nullptr && la % 2 == 0 &&
+                           (!uni || uni->group <= 0 || 256 % uni->group == 0);
     const int64_t ldE = lookahead ? (int64_t)LA * B : B;
     float* Err0 = reinterpret_cast<float*>(((uintptr_t)ws + 255) & ~(uintptr_t)255);
     float* Wblk = Err0 + (size_t)R * B * (B == LA_B ? 2 * LA : 1);
@@ -567,6 +613,8 @@ static int column_loop(float* W, const float* U, int64_t R, int64_t C, int q_typ
                                               m + sg * gps, ng, st, panel)))
                     return rc;
             }
+            // an even block of a 256-group: its partner's columns are updated in this kernel's epilogue
+            const float* unext = (pair_look && single && len == SEG && !(pos & 1) && c2 + B <= C) ? U + a * C + a + SEG : nullptr;
             const float* srcp = single ? (W + a) : (Wblk + (a - c1));
             const int64_t ld_src = single ? C : B;
             {
@@ -574,15 +622,15 @@ static int column_loop(float* W, const float* U, int64_t R, int64_t C, int q_typ
                 if (uni)
                     hipLaunchKernelGGL((gptq_segment_kernel<false, true>), seg_grid, seg_block, SEG_LDS_BYTES, st, W, C, srcp,
                                        ld_src, U, a, len, R, d, s, dmin, m, ti.group, 0, 0.0f, (float)ti.qmax, qweight, Err,
-                                       ldE, pos * B + (a - c1), perm, uni->scale, uni->zero);
+                                       ldE, pos * B + (a - c1), perm, uni->scale, uni->zero, unext);
                 else if (perm)
                     hipLaunchKernelGGL(gptq_segment_kernel<true>, seg_grid, seg_block, SEG_LDS_BYTES, st, W, C, srcp, ld_src, U, a,
                                        len, R, d, s, dmin, m, ti.group, ti.is_signed, (float)ti.qmin, (float)ti.qmax, qweight, Err,
-                                       ldE, pos * B + (a - c1), perm, nullptr, nullptr);
+                                       ldE, pos * B + (a - c1), perm, nullptr, nullptr, unext);
                 else
                     hipLaunchKernelGGL(gptq_segment_kernel<false>, seg_grid, seg_block, SEG_LDS_BYTES, st, W, C, srcp, ld_src, U, a,
                                        len, R, d, s, dmin, m, ti.group, ti.is_signed, (float)ti.qmin, (float)ti.qmax, qweight, Err,
-                                       ldE, pos * B + (a - c1), perm, nullptr, nullptr);
+                                       ldE, pos * B + (a - c1), perm, nullptr, nullptr, unext);
                 GQ_LAUNCH_CHECK();
             }
             if (e < c2) {  // push this segment's rank-1 updates into the rest of the block
@@ -607,6 +655,15 @@ static int column_loop(float* W, const float* U, int64_t R, int64_t C, int q_typ
             // Also dropped: a dedicated K = 128 kernel, one workgroup per CU with the whole K of both operands in LDS
             // (23.5 vs 17.3 us per launch).  A rank-128 update moves 16 B of operands L2 -> LDS per output element for
             // 256 flops at 64 x 64 tiles: it is L2-bandwidth-bound near 50 TFLOP/s whatever the schedule.)
+            if (pair_look) {
+                if (pos & 1) {  // end of a 256-group: both blocks' errors, in order, to the rest of the super-block
+                    ProfScope ps(PT_TRAILING, st);
+                    if ((rc = launch_gemm32<false, 0, false, 0, LA_B>(W + c2, C, Err + (pos - 1) * B, ldE, U + (c1 - B) * C + c2, C, R,
+                                                                      S1 - c2, 2 * B, st)))
+                        return rc;
+                }
+                continue;
+            }
             if (!left_look &&
                 (rc = launch_trailing_update(W + c2, C, Err + pos * B, ldE, U + c1 * C + c2, C, R, S1 - c2, ncols, st)))
                 return rc;
