@@ -10,23 +10,23 @@
 // the loop), hand-ordered fragment reads / MFMAs / waits.  A "half-stage" is one (A plane, B plane) pair of one
 // k32 chunk; the product a*b is the sum of NPROD half-stages per chunk:
 //
-//   NP = 3, bf16 (default): x = x1 + x2 + x3 EXACTLY (truncation split, 8 + 8 + 8 significand bits); the six
+//   NP = 2, fp16 (default): every operand ROW is scaled by a power of two so that its largest entry lies in
+//     [2^14, 2^15), then x = x1 + x2 + r with x1 = fp16(x), x2 = fp16(x - x1), |r| <= 2^-22 |x| (or 2^-40 of the row
+//     maximum where x2 is denormal); products a1b2, a2b1, a1b1 (each exact in fp32), a2b2 <= 2^-22 |ab| dropped; the
+//     epilogue undoes the scales.  THREE MFMA products per term.  The error bound is normwise per row, which is why
+//     gq_h_prepare equilibrates the matrix first (gq_cholesky.hip, equil_kernel: all k of a product weigh the same);
+//     measured MORE accurate than the exact bf16 split below (two roundings to nearest beat three truncations).
+//   NP = 3, bf16 (GQ_CHOL_BF16X3=1): x = x1 + x2 + x3 EXACTLY (truncation split, 8 + 8 + 8 significand bits); the six
 //     products of weight >= 2^-16 -- a1b3, a3b1, a2b2, a1b2, a2b1, a1b1, smallest first, each exact in fp32 -- are
 //     accumulated in fp32: the dropped terms are <= 2^-22 |ab|, the size of an fp32 rounding (as gq_gemm3b.hpp).
-//   NP = 2, fp16 (GQ_CHOL_F16X2=1, experimental): every operand ROW is scaled by a power of two so that its
-//     largest entry lies in [2^14, 2^15), then x = x1 + x2 + r with x1 = fp16(x), x2 = fp16(x - x1),
-//     |r| <= 2^-22 |x| (or 2^-40 of the row maximum where x2 is denormal); products a1b2, a2b1, a1b1 (each exact in
-//     fp32), a2b2 <= 2^-22 |ab| dropped; the epilogue undoes the scales.  Half the MFMA work of bf16x3; the error
-//     bound is normwise (row maxima), not componentwise.
 //
 // Triangular operands: k-ranges are skipped per tile (never multiplied), ranges always start at image chunk 0 --
 // operands whose valid range ENDS at K are imaged with their chunks in reverse order (both operands of the product
 // alike), so all tiles of a launch stream the same panels at the same time.
-// Scheduling: work units = (tile, chunk range); 32 consecutive units of the super-tile order (8 x 4 tiles sharing
-// 12 operand panels) form a group, groups are dealt to the 8 XCDs by LPT, the 32 workgroups of an XCD pop units
-// from their XCD's queue with one atomic each (results do not depend on who computes what: a unit's output
-// location is fixed).  Long tiles are cut along k when that shortens the makespan; their raw fp32 sums go to
-// slots of a partial buffer and reduce_kernel adds them in fixed order (deterministic).
+// Scheduling (make_plan): work units = (tile, chunk range), assigned STATICALLY: the tiles in super-tile order (8 x 4
+// tiles share 12 operand panels) form one sequence, cut into 8 equal-work segments (one per XCD); inside an XCD whole
+// rounds of 32, then the wrap-around rule levels the workgroups, cutting a tile along k where it overflows.  Cut tiles
+// store raw fp32 sums into slots of a partial buffer and reduce_kernel adds them in fixed order (deterministic).
 // Tolerance-class like gq_gemm3b.hpp (U = chol(H^-1) is checked against fp64); the GPTQ trailing update -- the
 // bit-exact parity gate -- never comes here.
 #pragma once

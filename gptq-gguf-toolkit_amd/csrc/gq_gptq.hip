@@ -255,10 +255,12 @@ __global__ __launch_bounds__(SEG_WAVES * 64) void gptq_segment_kernel(
     // computed -- here with the negated errors the kernel already keeps, sum' = -sum exactly, w + sum' = w - sum -- so
     // the launch, its gap and its W round trip disappear.  U's diagonal block in LDS is dead once the chains are through.
     if (Unext != nullptr) {
+#ifndef GQ_EPI_NOLOADU  // (timing probes only)
         for (int idx = tid; idx < SEG * (SEG / 4); idx += SEG_WAVES * 64) {
             const int i = idx / (SEG / 4), j4 = (idx % (SEG / 4)) * 4;
             *reinterpret_cast<float4*>(Us + i * SEG + j4) = *reinterpret_cast<const float4*>(Unext + (int64_t)i * C + j4);
         }
+#endif
         __syncthreads();
         const int rb = (wid & 1) * 32, cb = (wid >> 1) * 32;  // 2 x 4 sub-tiles of 32 x 32, one per wave
         const int li = lane & 31, lk = lane >> 5;
@@ -266,20 +268,31 @@ __global__ __launch_bounds__(SEG_WAVES * 64) void gptq_segment_kernel(
         f32x16 acc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+#ifndef GQ_EPI_NOMFMA
 #pragma unroll 8
         for (int k0 = 0; k0 < SEG; k0 += 2) {
             const int k = k0 + lk;
             const float ev = (k < SEG - SB) ? wl[k * 64 + rb + li] : nel[(k - (SEG - SB)) * 64 + rb + li];
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ev, Us[k * SEG + cb + li], acc, 0, 0, 0);
         }
+#endif
+#ifndef GQ_EPI_NOW
+        // all 16 loads in flight before the first store (written as `*p += acc` the compiler must keep every load behind
+        // the previous store: 16 dependent HBM round trips, 12 us per block)
+        const int64_t r0 = (int64_t)blockIdx.x * 64 + rb + 4 * lk;
+        float* wp = W + r0 * C + a + SEG + cb + li;
+        float wv[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const int64_t rr = (int64_t)blockIdx.x * 64 + rb + (e & 3) + 8 * (e >> 2) + 4 * lk;
-            if (rr < R) {
-                float* p = W + rr * C + a + SEG + cb + li;
-                *p = *p + acc[e];
-            }
+            const int ro = (e & 3) + 8 * (e >> 2);
+            wv[e] = (r0 + ro < R) ? wp[(int64_t)ro * C] : 0.0f;
         }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int ro = (e & 3) + 8 * (e >> 2);
+            if (r0 + ro < R) wp[(int64_t)ro * C] = wv[e] + acc[e];
+        }
+#endif
     }
 }
 
