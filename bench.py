@@ -214,7 +214,8 @@ def trailing_update_legs(wl, W16, X, in_region):
         ops.h_accumulate(H, xs, 0.0, 2.0 / 8)
         U, _ = ops.h_prepare(H, W16[name].float(), 0.01)
         del H, xs
-        B, sb = 128, 1024
+        B = 128
+        sb = B * int(os.environ.get("GQ_LA", "8"))  # columns per look-ahead super-block (gq_gptq.hip LA)
         far = sum(2.0 * R * (min(s0 + sb, C) - s0) * (C - min(s0 + sb, C)) for s0 in range(0, C, sb))
         near_all = sum(2.0 * R * B * (min((c1 // sb + 1) * sb, C) - (c1 + B)) for c1 in range(0, C, B))
         if os.environ.get("GQ_NEAR_CLASSIC") or os.environ.get("GQ_NEAR_LEFT"):
@@ -222,6 +223,8 @@ def trailing_update_legs(wl, W16, X, in_region):
         else:
             # r03: an even block's errors reach its partner block inside the column-loop kernel (not a GEMM launch: its
             # flops are NOT counted here); the launches are the chained K = 256 updates after every 256-column group
+            # (a column of a later pair receives the same blocks' errors whether they arrive pair by pair or quad by quad:
+            # the launched flops are those of the pair-wise form)
             near = sum(2.0 * R * 2 * B * (min((c1 // sb + 1) * sb, C) - (c1 + 2 * B)) for c1 in range(0, C, 2 * B))
             fused = near_all - near
         best, loop_ms = {}, {}

@@ -669,10 +669,25 @@ static int column_loop(float* W, const float* U, int64_t R, int64_t C, int q_typ
             // (23.5 vs 17.3 us per launch).  A rank-128 update moves 16 B of operands L2 -> LDS per output element for
             // 256 flops at 64 x 64 tiles: it is L2-bandwidth-bound near 50 TFLOP/s whatever the schedule.)
             if (pair_look) {
-                if (pos & 1) {  // end of a 256-group: both blocks' errors, in order, to the rest of the super-block
+                // GQ_NEAR_QUAD=1 (measured, off): a third level -- pair -> the quad's other pair (K = 256, N = 256), quad -> the
+                // rest of the super-block (K = 512, N = 512): same flops, deeper K on fewer tiles: 1.24 vs 1.05 ms of near
+                // launches for 4096 x 14336
+                static const bool quad = getenv("GQ_NEAR_QUAD") != nullptr;
+                if ((pos & 1) && !quad) {  // end of a 256-group: both blocks' errors, in order, to the rest of the super-block
                     ProfScope ps(PT_TRAILING, st);
                     if ((rc = launch_gemm32<false, 0, false, 0, LA_B>(W + c2, C, Err + (pos - 1) * B, ldE, U + (c1 - B) * C + c2, C, R,
                                                                       S1 - c2, 2 * B, st)))
+                        return rc;
+                } else if ((pos & 3) == 1) {  // first pair of a 512-column quad: its two blocks' errors to the quad's other pair
+                    const int64_t n = (c2 + 2 * B < S1) ? 2 * B : S1 - c2;
+                    ProfScope ps(PT_TRAILING, st);
+                    if ((rc = launch_gemm32<false, 0, false, 0, LA_B>(W + c2, C, Err + (pos - 1) * B, ldE, U + (c1 - B) * C + c2, C, R, n,
+                                                                      2 * B, st)))
+                        return rc;
+                } else if ((pos & 3) == 3) {  // end of a quad: its four blocks' errors, in order, to the rest of the super-block
+                    ProfScope ps(PT_TRAILING, st);
+                    if ((rc = launch_gemm32<false, 0, false, 0, LA_B>(W + c2, C, Err + (pos - 3) * B, ldE, U + (c1 - 3 * B) * C + c2, C, R,
+                                                                      S1 - c2, 4 * B, st)))
                         return rc;
                 }
                 continue;
