@@ -468,7 +468,7 @@ def build_model(cfg_kw, dev, dtype=torch.bfloat16, seed=0):
     return model
 
 
-def whole_model_run(wl, dev, world, rank, save_root=None, nseq=None, L=None, layers=None, calib_batch=1):
+def whole_model_run(wl, dev, world, rank, save_root=None, nseq=None, L=None, layers=None, calib_batch=1, fused=False):
     """Quantizer.quantize on a random-init Llama of the workload's architecture (the reference's timed region,
     quant.py:251-254) -> dict with wall seconds, Mparams/s and the split."""
     from gptq_gguf_toolkit_amd.quantizer import Quantizer
@@ -500,7 +500,7 @@ def whole_model_run(wl, dev, world, rank, save_root=None, nseq=None, L=None, lay
     drv = Quantizer(model, data_loader=data, quantizable_modules=r".*layers.*((q|k|v|o|gate|up|down)_proj)$",
                     quantizer_kwargs=dict(QUANTIZER_KW, verbose=False), pre_block_modules=["model.embed_tokens"],
                     block_modules="model.layers", post_block_modules=["lm_head"], quant_non_block_modules=True,
-                    device=str(dev), save_dir=save_dir, calibration_batch=calib_batch)
+                    device=str(dev), save_dir=save_dir, calibration_batch=calib_batch, fused_forward=fused)
     params = sum(p.numel() for n, p in model.named_parameters() if p.dim() == 2)
     os.environ.setdefault("GQ_TIMING", "gpu")  # HIP-event split per phase next to the host-side one (read once, at the end)
     try:
@@ -522,6 +522,8 @@ def whole_model_run(wl, dev, world, rank, save_root=None, nseq=None, L=None, lay
             shutil.rmtree(save_dir, ignore_errors=True)
     out = {"model": f"random-init LlamaForCausalLM {cfg_kw['num_hidden_layers']} layers, hidden {cfg_kw['hidden_size']}, "
                     f"bf16, attn {os.environ.get('GQ_ATTN', 'sdpa')}; embed + lm_head RTN ({q}), all block Linears GPTQ ({q})",
+           "forward": ("HIP RMSNorm / rotary / SwiGLU kernels (--fused_forward: " + ", ".join(getattr(drv, "_fused_modules", [])[:3]) + ")"
+                       if fused else "HF eager modules (the reference's forward)"),
            "calib": f"{nseq}x{L} synthetic ids ({len(ids)} sequences on this rank), {calib_batch} per block forward"
                     + (" (the reference's cadence)" if calib_batch == 1 else " (--calibration_batch: same Hessian sums, fewer and larger GEMMs)"),
            "params_quantized_M": round(params / 1e6, 1),
@@ -545,6 +547,7 @@ def main():
     ap.add_argument("--seq-len", type=int, default=None)
     ap.add_argument("--layers", type=int, default=None, help="whole-model workloads: number of blocks (default: all)")
     ap.add_argument("--calib-batch", type=int, default=1, help="whole-model workload: calibration samples per block forward")
+    ap.add_argument("--fused-forward", action="store_true", help="whole-model workload: HIP RMSNorm / rotary / SwiGLU kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-whole-model", action="store_true", help="skip the whole-model leg of the block workloads")
     ap.add_argument("--no-side-legs", action="store_true", help="skip trailing_update / tolerance_parity legs")
@@ -584,7 +587,7 @@ def main():
     if "model" in wl:  # a step = the whole model through Quantizer.quantize
         runs = []
         for i in range(args.warmup + args.steps):
-            runs.append(whole_model_run(wl, dev, world, rank, nseq=nseq, L=L, layers=args.layers, calib_batch=args.calib_batch))
+            runs.append(whole_model_run(wl, dev, world, rank, nseq=nseq, L=L, layers=args.layers, calib_batch=args.calib_batch, fused=args.fused_forward))
         timed = runs[args.warmup:]
         dt = sum(r["wall_s_quantizer_region"] for r in timed)
         if rank == 0:
@@ -743,9 +746,11 @@ def main():
         del layers, W16, X
         torch.cuda.empty_cache()
         wm = {}
-        for key, cb in (("whole_model", 1), ("whole_model_batch4", 4)):
+        for key, cb, fused in (("whole_model", 1, False), ("whole_model_fused", 1, True), ("whole_model_batch4", 4, False),
+                               ("whole_model_batch4_fused", 4, True)):
             try:
-                wm[key] = whole_model_run(WORKLOADS["llama3-8b-model-q4k"], dev, world, rank, layers=args.layers, calib_batch=cb)
+                wm[key] = whole_model_run(WORKLOADS["llama3-8b-model-q4k"], dev, world, rank, layers=args.layers, calib_batch=cb,
+                                          fused=fused)
             except Exception as e:  # the bench line must still print
                 wm[key] = {"error": repr(e)}
         if rank == 0:

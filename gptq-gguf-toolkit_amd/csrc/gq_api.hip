@@ -39,6 +39,9 @@ int h_stage(void*, const void*, int64_t, hipStream_t);
 size_t chol_gemm_workspace_bytes(int64_t, int64_t, int64_t);
 int chol_gemm(float*, int64_t, const float*, int64_t, const float*, int64_t, int64_t, int64_t, int64_t, int, int, int, int, int,
               void*, size_t, hipStream_t);
+int fwd_rmsnorm(const void*, const void*, void*, int64_t, int64_t, float, int, hipStream_t);
+int fwd_rope(const void*, const void*, const void*, void*, int64_t, int, int, int, hipStream_t);
+int fwd_silu_mul(const void*, const void*, void*, int64_t, int, hipStream_t);
 }  // namespace gq
 
 #include <algorithm>
@@ -229,6 +232,17 @@ int gq_chol_gemm(float* Cmat, int64_t ldc, const float* A, int64_t lda, const fl
                  int64_t K, int trans_b, int mode, int k_range, int lower, int planes, void* ws, size_t ws_bytes, void* stream) {
     return chol_gemm(Cmat, ldc, A, lda, B, ldb, M, N, K, trans_b, mode, k_range, lower, planes, ws, ws_bytes,
                      (hipStream_t)stream);
+}
+
+int gq_fwd_rmsnorm(const void* x, const void* weight, void* out, int64_t tokens, int64_t C, float eps, int dtype, void* stream) {
+    return fwd_rmsnorm(x, weight, out, tokens, C, eps, dtype, (hipStream_t)stream);
+}
+int gq_fwd_rope(const void* x, const void* cos_, const void* sin_, void* out, int64_t tokens, int heads, int head_dim, int dtype,
+                void* stream) {
+    return fwd_rope(x, cos_, sin_, out, tokens, heads, head_dim, dtype, (hipStream_t)stream);
+}
+int gq_fwd_silu_mul(const void* gate, const void* up, void* out, int64_t n, int dtype, void* stream) {
+    return fwd_silu_mul(gate, up, out, n, dtype, (hipStream_t)stream);
 }
 
 // ---- profiling (bench.py): HIP-event timing of selected kernels on their launch stream ----

@@ -1,0 +1,135 @@
+"""Opt-in HIP kernels for the elementwise part of the calibration forward.
+
+The reference runs every decoder layer through the HF eager modules (reference quantizer.py:293
+`block(inp_batch, **kwargs)`); on an MI355X that forward is 60 % of a whole-model run and a third of
+it is 2-8 torch elementwise kernels per RMSNorm / rotary embedding / SwiGLU.  `fused_forward()` replaces exactly
+those three with one gfx950 kernel each (csrc/gq_forward.hip) for the duration of a `with` block:
+
+    LlamaRMSNorm.forward       -> ops.fwd_rmsnorm   (fp32 statistics, rounded to the dtype where the module rounds)
+    apply_rotary_pos_emb       -> ops.fwd_rope      (per-op rounding of the eager expression)
+    LlamaMLP.forward           -> down_proj(ops.fwd_silu_mul(gate_proj(x), up_proj(x)))
+
+The Linear modules are still called through `nn.Module.__call__`, so the Hessian hooks see the same inputs.  A model
+family is patched only when the source text of its module matches Llama's (Mistral, Qwen2 ... copy it verbatim), and
+every patched function falls back to the original for inputs the kernels do not take (fp32, non-contiguous, odd
+sizes, CPU tensors) -- the originals are torch code, not a CPU restatement of ours.  Off by default: the outputs
+equal HF eager's up to the summation order of the RMSNorm mean (tests/test_gpu_forward.py states the tolerance).
+"""
+from __future__ import annotations
+
+import contextlib
+import importlib
+import inspect
+from typing import List, Tuple
+
+import torch
+
+from . import ops
+
+_FAMILIES = ("llama", "mistral", "qwen2", "qwen3", "mixtral", "gemma")  # candidates; each is checked against Llama's text
+_16BIT = (torch.float16, torch.bfloat16)
+
+
+def _body(fn) -> str:
+    """Source of a function without its signature's class name / decorators / docstring, whitespace-normalised."""
+    src = inspect.getsource(fn)
+    lines = [ln.strip() for ln in src.splitlines()]
+    lines = [ln for ln in lines if ln and not ln.startswith("@") and not ln.startswith("#")]
+    text = "\n".join(lines)
+    doc = inspect.getdoc(fn)
+    if doc:
+        start, end = text.find('"""'), text.find('"""', text.find('"""') + 3)
+        if start >= 0 and end > start:
+            text = text[:start] + text[end + 3:]
+    return "\n".join(ln for ln in text.splitlines() if ln.strip())
+
+
+def _rmsnorm_forward(orig):
+    def forward(self, hidden_states):
+        w = self.weight
+        if (hidden_states.is_cuda and hidden_states.dtype in _16BIT and w.dtype == hidden_states.dtype
+                and hidden_states.is_contiguous() and w.is_contiguous() and hidden_states.shape[-1] % 8 == 0
+                and hidden_states.numel() > 0 and not torch.is_grad_enabled()):
+            return ops.fwd_rmsnorm(hidden_states, w, self.variance_epsilon)
+        return orig(self, hidden_states)
+    return forward
+
+
+def _rope(orig):
+    def apply_rotary_pos_emb(q, k, cos, sin, unsqueeze_dim=1):
+        ok = (unsqueeze_dim == 1 and q.is_cuda and q.dim() == 4 and k.dim() == 4 and cos.dim() == 3 and q.dtype in _16BIT
+              and k.dtype == q.dtype == cos.dtype == sin.dtype and q.shape[-1] % 16 == 0 and q.numel() > 0
+              and not torch.is_grad_enabled())
+        if ok:
+            qt, kt = q.transpose(1, 2), k.transpose(1, 2)  # [B, L, H, D]: the projections' own memory layout
+            B, L, _, D = qt.shape
+            ok = (qt.is_contiguous() and kt.is_contiguous() and cos.shape[-1] == D and cos.shape[1] == L
+                  and cos.shape == sin.shape and cos.shape[0] in (1, B))
+        if not ok:
+            return orig(q, k, cos, sin, unsqueeze_dim)
+        if cos.shape[0] != B:
+            cos, sin = cos.expand(B, L, D), sin.expand(B, L, D)
+        cos, sin = cos.contiguous(), sin.contiguous()
+        return ops.fwd_rope(qt, cos, sin).transpose(1, 2), ops.fwd_rope(kt, cos, sin).transpose(1, 2)
+    return apply_rotary_pos_emb
+
+
+def _mlp_forward(orig):
+    def forward(self, x):
+        act = self.act_fn
+        if (x.is_cuda and x.dtype in _16BIT and not torch.is_grad_enabled()
+                and (isinstance(act, torch.nn.SiLU) or type(act).__name__ == "SiLUActivation")):
+            g, u = self.gate_proj(x), self.up_proj(x)
+            if g.is_contiguous() and u.is_contiguous() and g.numel() % 8 == 0 and g.numel() > 0:
+                return self.down_proj(ops.fwd_silu_mul(g, u))
+            return self.down_proj(act(g) * u)
+        return orig(self, x)
+    return forward
+
+
+def _targets() -> List[Tuple[object, str, object]]:
+    """(owner, attribute, replacement) for every installed family whose module text equals Llama's."""
+    from transformers.models.llama import modeling_llama as ref
+    want_norm, want_rope, want_mlp = _body(ref.LlamaRMSNorm.forward), _body(ref.apply_rotary_pos_emb), _body(ref.LlamaMLP.forward)
+    out = []
+    for fam in _FAMILIES:
+        try:
+            mod = importlib.import_module(f"transformers.models.{fam}.modeling_{fam}")
+        except Exception:
+            continue
+        for name, cls in vars(mod).items():
+            if not inspect.isclass(cls) or getattr(cls, "__module__", None) != mod.__name__:
+                continue
+            try:
+                if name.endswith("RMSNorm") and _body(cls.forward) == want_norm:
+                    out.append((cls, "forward", _rmsnorm_forward(cls.forward)))
+                elif name.endswith("MLP") and _body(cls.forward) == want_mlp:
+                    out.append((cls, "forward", _mlp_forward(cls.forward)))
+            except (OSError, TypeError):
+                continue
+        fn = vars(mod).get("apply_rotary_pos_emb")
+        try:
+            if fn is not None and getattr(fn, "__module__", None) == mod.__name__ and _body(fn) == want_rope:
+                out.append((mod, "apply_rotary_pos_emb", _rope(fn)))
+        except (OSError, TypeError):
+            pass
+    return out
+
+
+@contextlib.contextmanager
+def fused_forward(enabled: bool = True):
+    """Within the block, the matching HF modules run the gfx950 kernels.  Raises (does not fall back) if the HIP
+    library is missing; restores the originals on exit."""
+    if not enabled:
+        yield []
+        return
+    ops.lib()  # fail loudly here, not in the middle of a forward
+    saved = []
+    try:
+        for owner, attr, new in _targets():
+            saved.append((owner, attr, vars(owner)[attr] if attr in vars(owner) else getattr(owner, attr)))
+            setattr(owner, attr, new)
+        yield [f"{getattr(o, '__name__', o)}.{a}" for o, a, _ in saved]
+    finally:
+        for owner, attr, old in reversed(saved):
+            setattr(owner, attr, old)

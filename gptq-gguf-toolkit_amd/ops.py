@@ -374,6 +374,39 @@ def chol_gemm(Cm: torch.Tensor, A: torch.Tensor, B: torch.Tensor, trans_b: bool,
     return Cm
 
 
+def fwd_rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
+    """LlamaRMSNorm.forward in one pass (gq_fwd_rmsnorm); x [..., C] fp16 / bf16 contiguous, weight [C] of the same dtype."""
+    _need_cuda(x, weight)
+    assert x.is_contiguous() and weight.is_contiguous() and weight.dtype == x.dtype and weight.numel() == x.shape[-1]
+    out = torch.empty_like(x)
+    C = x.shape[-1]
+    check(lib().gq_fwd_rmsnorm(_ptr(x), _ptr(weight), _ptr(out), x.numel() // C, C, float(eps), _DT[x.dtype], _stream(x)),
+          "gq_fwd_rmsnorm")
+    return out
+
+
+def fwd_rope(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:
+    """apply_rotary_pos_emb on one projection (gq_fwd_rope): x [B, L, H, D] contiguous (q_proj(h).view(B, L, H, D)),
+    cos / sin [B, L, D] contiguous, same dtype.  Returns [B, L, H, D]."""
+    _need_cuda(x, cos, sin)
+    B, L, H, D = x.shape
+    assert x.is_contiguous() and cos.is_contiguous() and sin.is_contiguous() and cos.dtype == x.dtype == sin.dtype
+    assert cos.shape == (B, L, D) and sin.shape == (B, L, D)
+    out = torch.empty_like(x)
+    check(lib().gq_fwd_rope(_ptr(x), _ptr(cos), _ptr(sin), _ptr(out), B * L, H, D, _DT[x.dtype], _stream(x)), "gq_fwd_rope")
+    return out
+
+
+def fwd_silu_mul(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
+    """silu(gate) * up (gq_fwd_silu_mul), fp16 / bf16 contiguous tensors of one shape."""
+    _need_cuda(gate, up)
+    assert gate.is_contiguous() and up.is_contiguous() and gate.shape == up.shape and gate.dtype == up.dtype
+    out = torch.empty_like(gate)
+    check(lib().gq_fwd_silu_mul(_ptr(gate), _ptr(up), _ptr(out), gate.numel(), _DT[gate.dtype], _stream(gate)),
+          "gq_fwd_silu_mul")
+    return out
+
+
 def group_search(x: torch.Tensor, q_type: int, rmin=-1.0, rdelta=0.1, nstep=20, **mq):
     """make_k_quants / make_quants on a [rows,256] panel (fp32, or fp16/bf16 with per-op rounding).
     Returns (group_scale f32[rows,ng], group_zero f32[rows,ng], d, s, dmin, m)."""

@@ -74,6 +74,9 @@ def parse_args(argv=None):
                    help="calibration samples per block forward (the reference runs 1; the Hessians are the same sums)")
     p.add_argument("--non_block_fp32", action="store_true",
                    help="run the embed/lm_head scale search in fp32 (the reference runs it in the model dtype)")
+    p.add_argument("--fused_forward", action="store_true",
+                   help="run RMSNorm / rotary embedding / SwiGLU of the calibration forward as HIP kernels "
+                        "(the reference runs the HF eager modules)")
     return p.parse_args(argv)
 
 
@@ -157,7 +160,7 @@ def _run(args):
         post_block_modules=args.post_block_modules, quant_non_block_modules=args.quant_non_block_modules,
         cpu_offload_modules=args.cpu_offload_modules, cpu_offload_activations=args.cpu_offload_activations,
         device=device, verbose=args.verbose, save_dir=args.save_dir, non_block_fp32=args.non_block_fp32,
-        calibration_batch=args.calibration_batch)
+        calibration_batch=args.calibration_batch, fused_forward=args.fused_forward)
     if dist_utils.is_main():
         os.makedirs(args.save_dir, exist_ok=True)
     dist_utils.barrier()

@@ -30,6 +30,7 @@ import torch.nn as nn
 from . import dist_utils
 from . import ops as _ops
 from .block_schedule import BlockSchedule
+from .forward_fused import fused_forward
 from .gptq import GPTQ
 from .model_utils import ForwardInterrupt, InputCollector, LINEAR_LAYERS, _to, select_layers
 from .quant_utils import GGML_QUANT_SIZES, GGMLQuantizationType, dequantize_linear_weight
@@ -386,7 +387,7 @@ class Quantizer:
                  block_modules: str, save_dir: str, quant_non_block_modules: bool = False,
                  device: Optional[torch.device] = None, cpu_offload_modules: bool = False,
                  cpu_offload_activations: bool = False, verbose: bool = False, non_block_fp32: bool = False,
-                 calibration_batch: int = 1) -> None:
+                 calibration_batch: int = 1, fused_forward: bool = False) -> None:
         self.model = model
         self.data_loader = data_loader
         self.quantizable_modules = quantizable_modules
@@ -405,6 +406,9 @@ class Quantizer:
         # per block forward.  Same Hessians in exact arithmetic (GPTQ.update weighs a batch by its size,
         # gptq.py:86-112); one Llama-3-8B layer forward takes 0.91 instead of 1.16 ms per sequence at 4.
         self.calibration_batch = max(1, int(calibration_batch))
+        # beyond the reference: RMSNorm / rotary embedding / SwiGLU of the block forward as one HIP kernel each
+        # (forward_fused.py); the reference and the default run the HF eager modules (quantizer.py:293).
+        self.fused_forward = bool(fused_forward)
 
     # ------------------------------------------------------------------ walk
     @torch.no_grad()
@@ -416,7 +420,9 @@ class Quantizer:
             self._saver.warm_up(device)
         self._saved_names: List[str] = []
         try:
-            self._quantize(quant_config, device)
+            with fused_forward(self.fused_forward) as patched:
+                self._fused_modules = patched
+                self._quantize(quant_config, device)
         finally:
             BlockSchedule.discard_checks()  # nothing of this run may leak into the next Quantizer of the process
             t0 = time.perf_counter()

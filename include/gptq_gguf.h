@@ -242,6 +242,19 @@ int gq_trailing_update(float* Cmat, int64_t ldc, const float* A, int64_t lda, co
 int gq_chol_gemm(float* Cmat, int64_t ldc, const float* A, int64_t lda, const float* B, int64_t ldb, int64_t M, int64_t N,
                  int64_t K, int trans_b, int mode, int k_range, int lower, int planes, void* ws, size_t ws_bytes, void* stream);
 
+/* SURVEY 8(f) row 2, opt-in (Quantizer(fused_forward=True)): the elementwise part of the calibration forward the
+   reference leaves to HF eager modules (quantizer.py:293 `block(inp_batch, **kwargs)`), one HBM pass each, fp32
+   arithmetic rounded to `dtype` (GQ_F16 / GQ_BF16) after every torch op of the module it replaces:
+     gq_fwd_rmsnorm   LlamaRMSNorm.forward:  out = weight * dtype(float(x) * rsqrt(mean(float(x)^2) + eps));  x [tokens, C], C % 8 == 0
+     gq_fwd_rope      apply_rotary_pos_emb on one of q / k:  out = dtype(x cos) + dtype(rotate_half(x) sin);
+                      x, out [tokens, heads, head_dim] (the projection's own layout), cos / sin [tokens, head_dim], head_dim % 16 == 0
+     gq_fwd_silu_mul  LlamaMLP.forward's act_fn(gate) * up over n elements, n % 8 == 0
+   All pointers 16-byte aligned, tensors contiguous, out does not overlap an input. */
+int gq_fwd_rmsnorm(const void* x, const void* weight, void* out, int64_t tokens, int64_t C, float eps, int dtype, void* stream);
+int gq_fwd_rope(const void* x, const void* cos_, const void* sin_, void* out, int64_t tokens, int heads, int head_dim, int dtype,
+                void* stream);
+int gq_fwd_silu_mul(const void* gate, const void* up, void* out, int64_t n, int dtype, void* stream);
+
 /* Optional HIP-event timing of the library's own kernels, on the stream they are
    launched on (bench.py's roofline leg).  tag_mask bit t enables tag t; collect()
    synchronises the recorded events and ADDS elapsed ms / launch counts per tag. */

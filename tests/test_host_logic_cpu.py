@@ -948,3 +948,31 @@ def test_fast_obq_act_order_and_layer_dtype():
     U, *_ = O.h_prepare(H0[want][:, want], Wp, 0.01, obq_order=True)
     _, q_ref, s_ref, z_ref = O.obq_step(h.W.numpy(), U, 4, 128, False, 128)
     assert np.array_equal(q[4].numpy(), q_ref) and np.array_equal(s[4].numpy(), s_ref.astype(np.float16))
+
+
+def test_fused_forward_patch_targets_and_restore():
+    """forward_fused.py: patches exactly the HF modules whose text equals Llama's, falls back to the original torch code
+    for tensors the kernels do not take (here: CPU fp32 -> identical logits), and restores everything on exit."""
+    import torch
+    from transformers.models.llama import modeling_llama as M
+    from transformers.models.gemma import modeling_gemma as G
+    from gptq_gguf_toolkit_amd.forward_fused import fused_forward
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from make_golden_shim import tiny_calib, tiny_llama
+    model = tiny_llama()
+    ids = tiny_calib(n=1)[0]
+    orig = (M.LlamaRMSNorm.forward, M.apply_rotary_pos_emb, M.LlamaMLP.forward, G.GemmaRMSNorm.forward)
+    with torch.no_grad():
+        want = model(input_ids=ids).logits
+        with fused_forward() as patched:
+            assert {"LlamaRMSNorm.forward", "LlamaMLP.forward"} <= set(patched)
+            assert any(p.endswith("modeling_llama.apply_rotary_pos_emb") for p in patched)
+            assert "GemmaRMSNorm.forward" not in patched  # (1 + weight) scaling: a different module text
+            assert M.LlamaRMSNorm.forward is not orig[0] and M.apply_rotary_pos_emb is not orig[1]
+            got = model(input_ids=ids).logits
+    assert torch.equal(want, got)
+    assert (M.LlamaRMSNorm.forward, M.apply_rotary_pos_emb, M.LlamaMLP.forward, G.GemmaRMSNorm.forward) == orig
+    with pytest.raises(ZeroDivisionError):
+        with fused_forward():
+            1 / 0
+    assert M.LlamaRMSNorm.forward is orig[0]
