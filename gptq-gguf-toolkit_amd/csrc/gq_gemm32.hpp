@@ -351,6 +351,22 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define GQ_C_WAIT(N, s) \
     asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(fa0[s]), "+v"(fa1[s]), "+v"(fb0[s]), "+v"(fb1[s]) : "n"(N))
 
+// timing probes (results wrong): -DGQ_FAR_NOCOMMIT / -DGQ_FAR_NOFETCH / -DGQ_FAR_NOBARRIER drop a piece of the loop
+#ifdef GQ_FAR_NOCOMMIT
+#define GQ_FAR_AB_COMMIT(x) do {} while (0)
+#else
+#define GQ_FAR_AB_COMMIT(x) x
+#endif
+#ifdef GQ_FAR_NOFETCH
+#define GQ_FAR_AB_FETCH(x) do {} while (0)
+#else
+#define GQ_FAR_AB_FETCH(x) x
+#endif
+#ifdef GQ_FAR_NOBARRIER
+#define GQ_FAR_AB_BARRIER() do {} while (0)
+#else
+#define GQ_FAR_AB_BARRIER() __builtin_amdgcn_s_barrier()
+#endif
 template <int CHAIN>
 __device__ __forceinline__ void g32_chain_full_tile(float* Cmat, int64_t ldc, const float* A, int64_t lda, const float* B,
                                                     int64_t ldb, int64_t K, const int64_t m0, const int64_t n0) {
@@ -419,12 +435,12 @@ __device__ __forceinline__ void g32_chain_full_tile(float* Cmat, int64_t ldc, co
         const unsigned na0 = aoff0 + nbuf * STAGE * 4, na1 = aoff1 + nbuf * STAGE * 4, nb = boff + nbuf * STAGE * 4;
 #define GQ_C_GROUP(g)                                                                                        \
     do {                                                                                                     \
-        if ((g) == 6) __builtin_amdgcn_s_barrier(); /* image nbuf is complete: its writes were waited at g = 4 */ \
+        if ((g) == 6) GQ_FAR_AB_BARRIER(); /* image nbuf is complete: its writes were waited at g = 4 */     \
         if ((g) == 3) {                                                                                      \
             GQ_C_WAIT(4, (g) & 3); /* before 6 more LDS operations: lgkmcnt counts to 15 */                  \
             asm volatile("" ::: "memory");                                                                   \
-            commit(nbuf, va[PAR], vb[PAR]);                                                                  \
-            fetch(t + 3, va[PAR], vb[PAR]);                                                                  \
+            GQ_FAR_AB_COMMIT(commit(nbuf, va[PAR], vb[PAR]));                                                \
+            GQ_FAR_AB_FETCH(fetch(t + 3, va[PAR], vb[PAR]));                                                 \
             asm volatile("" ::: "memory");                                                                   \
         }                                                                                                    \
         if ((g) < 6) GQ_C_READS((g) + 2, ((g) + 2) & 3, ca0, ca1, cb);                                       \
@@ -511,6 +527,154 @@ inline int launch_gemm32_chain_full(float* Cmat, int64_t ldc, const float* A, in
         dim3 grid((unsigned)ntx, (unsigned)(M / 128)), block(512);
         hipLaunchKernelGGL((gemm32_chain_full_kernel<CHAIN>), grid, block, LDS, st, Cmat, ldc, A, lda, B, ldb, K);
     }
+    GQ_LAUNCH_CHECK();
+    return GQ_OK;
+}
+
+// ---- the GPTQ near trailing update: K = 256 (two chains of 128), 64x64 tiles, both operand panels whole in LDS ----
+// C = (C - A_0 B_0) - A_1 B_1 with the arithmetic of gemm32_chain_full_kernel<128> (per element: two k-ordered
+// 128-long MFMA chains from 0, one subtraction after each).  The near launches of the column loop have M = rows of W,
+// N = 256..768 and K = 256: 64..192 tiles of 128x128, each 13.6 us of matrix-pipe time on ONE CU whatever the rest of
+// the chip does (measured: ~25 us per launch).  Here a tile is 64x64 (3.4 us) and the launch has 4x the tiles.  What
+// made 64-tiles slow in the generic kernel -- a 16 KiB chunk every 0.12 us of MFMA time against ~0.7 us of L2
+// latency, one chunk in flight -- is gone: a workgroup asks for its whole A panel [64, 256] and B panel [256, 64] up
+// front with 32 global_load_lds_dwordx4 per wave (128 KiB in flight per CU, no VGPR round trip) in four k-quarters,
+// and starts the MFMAs of a quarter as soon as that quarter has landed (s_waitcnt vmcnt + barrier per quarter).
+//   A in LDS: [quarter][row][16 units of 16 B], unit (row, kq) stored at position kq ^ (row & 15): a lane's
+//   ds_read_b128 of (row, 4 k) is conflict-free, the 16 swizzled addresses of a quarter live in 16 VGPRs and the
+//   quarter is the instruction's immediate offset.  The lane keeps k = 4 kq + lk and 4 kq + 2 + lk of the four
+//   (lk = lane >> 5: the MFMA's k within a step).   B in LDS: [k][64 columns], ds_read_b32 along a row.
+// Tiles of one 64-row band of A go to one XCD (blockIdx % 8) so that band crosses the fabric once.
+constexpr int NEAR_K = 256, NEAR_A_BYTES = 64 * NEAR_K * 4, NEAR_B_BYTES = NEAR_K * 64 * 4;
+constexpr int NEAR_LDS_BYTES = NEAR_A_BYTES + NEAR_B_BYTES;
+typedef uint32_t g32_u32x4 __attribute__((ext_vector_type(4)));
+template <int CHAIN>  // 128 (a template so that every translation unit including this header may instantiate it)
+__global__ __launch_bounds__(256, 1) void gemm32_near256_kernel(float* Cmat, int64_t ldc, const float* A, int64_t lda,
+                                                                const float* B, int64_t ldb, unsigned nbx, unsigned nby) {
+    static_assert(CHAIN == 128, "two chains of 128 k");
+    extern __shared__ __attribute__((aligned(16))) float g32_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned id = blockIdx.x;
+    unsigned bx, by;
+    if (nby % 8 == 0) {
+        const unsigned j = id >> 3;
+        by = (id & 7) * (nby / 8) + j / nbx;
+        bx = j % nbx;
+    } else {
+        by = id / nbx;
+        bx = id % nbx;
+    }
+    const int64_t m0 = (int64_t)by * 64, n0 = (int64_t)bx * 64;
+    const unsigned lds0 = (unsigned)(uintptr_t)g32_smem;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int li = lane & 31, lk = lane >> 5;
+    f32x16 cv;
+    float* cp = Cmat + (m0 + wm * 32 + 4 * lk) * ldc + n0 + wn * 32 + li;
+#define GQ_N_DL(vo, sp, ldsaddr) \
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vo), "s"(sp), "s"(ldsaddr) : "memory")
+    {
+        // per quarter q (64 k) and wave: 4 instructions of B (k rows 64 q + 16 wid + 4 r .. + 3, whole 256-byte rows) and
+        // 4 of A (rows 16 wid + 4 r .. + 3: lane -> row 4 r' + lane / 16, stored position lane % 16 holds unit
+        // (lane % 16) ^ (row & 15))
+        const float* bp = B + n0;
+        const unsigned bvo = (unsigned)(((lane >> 4) * ldb + (lane & 15) * 4) * 4);
+        const int arow = lane >> 4;  // row within the instruction's four
+        const float* ap = A + m0 * lda;
+#define GQ_N_QUARTER(q)                                                                                               \
+    do {                                                                                                              \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                               \
+            const int j = (q) * 16 + wid * 4 + r; /* 1 KiB piece of the B panel: k rows 4 j .. 4 j + 3 */             \
+            const float* sp_ = bp + (int64_t)(4 * j) * ldb;                                                           \
+            GQ_N_DL(bvo, sp_, lds0 + NEAR_A_BYTES + (unsigned)j * 1024u);                                             \
+        }                                                                                                             \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                               \
+            const int row0 = wid * 16 + 4 * r; /* rows row0 .. row0 + 3; row & 15 = 4 r + arow */                     \
+            const unsigned avo = (unsigned)((arow * lda + (q) * 64 + (((lane & 15) ^ (4 * r + arow)) << 2)) * 4);     \
+            const float* sp_ = ap + (int64_t)row0 * lda;                                                              \
+            GQ_N_DL(avo, sp_, lds0 + (unsigned)((q) * 16384 + row0 * 256));                                           \
+        }                                                                                                             \
+    } while (0)
+        GQ_N_QUARTER(0);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) cv[e] = cp[((e & 3) + 8 * (e >> 2)) * ldc];
+        GQ_N_QUARTER(1);
+        GQ_N_QUARTER(2);
+        GQ_N_QUARTER(3);
+#undef GQ_N_QUARTER
+    }
+#undef GQ_N_DL
+    // swizzled LDS addresses of this lane's A row for the 16 units of a quarter
+    unsigned aaddr[16];
+    {
+        const int row = wm * 32 + li;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) aaddr[u] = lds0 + (unsigned)(row * 256 + ((u ^ (row & 15)) << 4));
+    }
+    const unsigned bbase = lds0 + NEAR_A_BYTES + (unsigned)(lk * 64 + wn * 32 + li) * 4u;
+    g32_u32x4 fa[3];
+    float fb0[3], fb1[3];
+#define GQ_N_READS(g, s)                                                                                              \
+    do {                                                                                                              \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[s]) : "v"(aaddr[(g) & 15]), "n"(((g) >> 4) * 16384) : "memory"); \
+        asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(fb0[s]) : "v"(bbase), "n"((g) * 1024) : "memory");         \
+        asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(fb1[s]) : "v"(bbase), "n"((g) * 1024 + 512) : "memory");   \
+    } while (0)
+    // quarter 0 has landed when at most the C loads and quarters 1-3 (16 + 24 operations of this wave) are outstanding
+    asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    GQ_N_READS(0, 0);
+    GQ_N_READS(1, 1);
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x16 acc = zero;
+    // group g = 4 k = two MFMAs; the reads of group g + 2 are issued first, then the wait leaves exactly those and
+    // group g + 1's outstanding (LDS operations return in order).  Two groups before a quarter ends, the next quarter
+    // must have landed: its first reads are issued there.
+#define GQ_N_GROUP(g)                                                                                            \
+    do {                                                                                                         \
+        constexpr int s_ = (g) % 3;                                                                              \
+        if ((g) % 16 == 14 && (g) < 48) {                                                                        \
+            if ((g) == 14) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");                                     \
+            else if ((g) == 30) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                 \
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                \
+            __builtin_amdgcn_s_barrier();                                                                        \
+        }                                                                                                        \
+        if ((g) + 2 < NEAR_K / 4) {                                                                              \
+            GQ_N_READS(((g) + 2 < NEAR_K / 4) ? (g) + 2 : 0, ((g) + 2) % 3);                                     \
+            asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(fa[s_]), "+v"(fb0[s_]), "+v"(fb1[s_])::"memory");         \
+        } else if ((g) + 1 < NEAR_K / 4) {                                                                       \
+            asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(fa[s_]), "+v"(fb0[s_]), "+v"(fb1[s_])::"memory");         \
+        } else {                                                                                                 \
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[s_]), "+v"(fb0[s_]), "+v"(fb1[s_])::"memory");         \
+        }                                                                                                        \
+        const float a0_ = __builtin_bit_cast(float, lk ? fa[s_].y : fa[s_].x);                                   \
+        const float a1_ = __builtin_bit_cast(float, lk ? fa[s_].w : fa[s_].z);                                   \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0_, fb0[s_], ((g) % 32 == 0) ? zero : acc, 0, 0, 0);         \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1_, fb1[s_], acc, 0, 0, 0);                                  \
+        if ((g) % 32 == 31) {                                                                                    \
+            _Pragma("unroll") for (int e = 0; e < 16; ++e) cv[e] = cv[e] - acc[e];                               \
+        }                                                                                                        \
+    } while (0)
+#define GQ_N_G8(g) GQ_N_GROUP(g); GQ_N_GROUP((g) + 1); GQ_N_GROUP((g) + 2); GQ_N_GROUP((g) + 3); \
+                   GQ_N_GROUP((g) + 4); GQ_N_GROUP((g) + 5); GQ_N_GROUP((g) + 6); GQ_N_GROUP((g) + 7)
+    GQ_N_G8(0); GQ_N_G8(8); GQ_N_G8(16); GQ_N_G8(24); GQ_N_G8(32); GQ_N_G8(40); GQ_N_G8(48); GQ_N_G8(56);
+#undef GQ_N_G8
+#undef GQ_N_GROUP
+#undef GQ_N_READS
+#pragma unroll
+    for (int e = 0; e < 16; ++e) cp[((e & 3) + 8 * (e >> 2)) * ldc] = cv[e];
+}
+
+// K = 256, M, N multiples of 64, 16-byte aligned operands with ld % 4 == 0
+inline int launch_gemm32_near256(float* Cmat, int64_t ldc, const float* A, int64_t lda, const float* B, int64_t ldb, int64_t M,
+                                 int64_t N, hipStream_t st) {
+    static std::atomic<bool> attr_set{false};
+    if (!attr_set) {
+        GQ_HIP(hipFuncSetAttribute((const void*)gemm32_near256_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, NEAR_LDS_BYTES));
+        attr_set = true;
+    }
+    const unsigned nbx = (unsigned)(N / 64), nby = (unsigned)(M / 64);
+    hipLaunchKernelGGL(gemm32_near256_kernel<128>, dim3(nbx * nby), dim3(256), NEAR_LDS_BYTES, st, Cmat, ldc, A, lda, B, ldb, nbx, nby);
     GQ_LAUNCH_CHECK();
     return GQ_OK;
 }

@@ -675,8 +675,13 @@ static int column_loop(float* W, const float* U, int64_t R, int64_t C, int q_typ
                 static const bool quad = getenv("GQ_NEAR_QUAD") != nullptr;
                 if ((pos & 1) && !quad) {  // end of a 256-group: both blocks' errors, in order, to the rest of the super-block
                     ProfScope ps(PT_TRAILING, st);
-                    if ((rc = launch_gemm32<false, 0, false, 0, LA_B>(W + c2, C, Err + (pos - 1) * B, ldE, U + (c1 - B) * C + c2, C, R,
-                                                                      S1 - c2, 2 * B, st)))
+                    // up to GQ_NEAR64_MAXN columns: 64x64 tiles with the K = 256 panels whole in LDS (gemm32_near256_kernel)
+                    static const int64_t near64_maxn = getenv("GQ_NEAR64_MAXN") ? atol(getenv("GQ_NEAR64_MAXN")) : 768;
+                    if (S1 - c2 <= near64_maxn && R % 64 == 0) {
+                        if ((rc = launch_gemm32_near256(W + c2, C, Err + (pos - 1) * B, ldE, U + (c1 - B) * C + c2, C, R, S1 - c2, st)))
+                            return rc;
+                    } else if ((rc = launch_gemm32<false, 0, false, 0, LA_B>(W + c2, C, Err + (pos - 1) * B, ldE,
+                                                                             U + (c1 - B) * C + c2, C, R, S1 - c2, 2 * B, st)))
                         return rc;
                 } else if ((pos & 3) == 1) {  // first pair of a 512-column quad: its two blocks' errors to the quad's other pair
                     const int64_t n = (c2 + 2 * B < S1) ? 2 * B : S1 - c2;
