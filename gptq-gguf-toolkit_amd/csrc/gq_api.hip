@@ -35,7 +35,7 @@ int syrk_workgroups(int);
 int w_prepare(const uint8_t*, float*, int64_t, int64_t, int*, hipStream_t);
 int h_pack_upper(const float*, int64_t, float*, hipStream_t);
 int h_unpack_upper(const float*, int64_t, float*, hipStream_t);
-int h_stage(void*, const void*, int64_t, hipStream_t);
+int h_stage(void*, const void*, int64_t, hipStream_t, int max_wgs = 0);
 size_t chol_gemm_workspace_bytes(int64_t, int64_t, int64_t);
 int chol_gemm(float*, int64_t, const float*, int64_t, const float*, int64_t, int64_t, int64_t, int64_t, int, int, int, int, int,
               void*, size_t, hipStream_t);
@@ -232,6 +232,15 @@ int gq_chol_gemm(float* Cmat, int64_t ldc, const float* A, int64_t lda, const fl
                  int64_t K, int trans_b, int mode, int k_range, int lower, int planes, void* ws, size_t ws_bytes, void* stream) {
     return chol_gemm(Cmat, ldc, A, lda, B, ldb, M, N, K, trans_b, mode, k_range, lower, planes, ws, ws_bytes,
                      (hipStream_t)stream);
+}
+
+int gq_stage_to_host(void* host_dst, const void* src, int64_t nbytes, void* stream) {
+    if (nbytes == 0) return GQ_OK;
+    if (!host_dst || !src) GQ_FAIL(GQ_E_NULL, "gq_stage_to_host: null pointer");
+    void* dptr = nullptr;
+    GQ_HIP(hipHostGetDevicePointer(&dptr, host_dst, 0));  // fails unless host_dst is pinned (hipHostRegister / hipHostMalloc)
+    static const int wgs = getenv("GQ_STAGE_HOST_WGS") ? atoi(getenv("GQ_STAGE_HOST_WGS")) : 0;
+    return h_stage(dptr, src, nbytes, (hipStream_t)stream, wgs);
 }
 
 int gq_fwd_rmsnorm(const void* x, const void* weight, void* out, int64_t tokens, int64_t C, float eps, int dtype, void* stream) {

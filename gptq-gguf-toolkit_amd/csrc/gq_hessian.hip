@@ -1250,18 +1250,19 @@ __global__ __launch_bounds__(256) void stage_rows_kernel(uint4* __restrict__ dst
 __global__ __launch_bounds__(256) void stage_bytes_kernel(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
 }
-int h_stage(void* dst, const void* src, int64_t nbytes, hipStream_t st) {
+int h_stage(void* dst, const void* src, int64_t nbytes, hipStream_t st, int max_wgs) {
+    const int64_t cap = max_wgs > 0 ? max_wgs : 4096;
     if (nbytes < 0) GQ_FAIL(GQ_E_BAD_SHAPE, "gq_h_stage: nbytes=%ld", (long)nbytes);
     if (nbytes == 0) return GQ_OK;
     if (!dst || !src) GQ_FAIL(GQ_E_NULL, "gq_h_stage: null pointer");
     if ((((uintptr_t)dst | (uintptr_t)src | (uintptr_t)nbytes) & 15) == 0) {
         const int64_t n16 = nbytes / 16;
         const int64_t wgs = (n16 + 1023) / 1024;
-        hipLaunchKernelGGL(stage_rows_kernel, dim3((unsigned)(wgs < 4096 ? wgs : 4096)), dim3(256), 0, st, (uint4*)dst,
+        hipLaunchKernelGGL(stage_rows_kernel, dim3((unsigned)(wgs < cap ? wgs : cap)), dim3(256), 0, st, (uint4*)dst,
                            (const uint4*)src, n16);
     } else {
         const int64_t wgs = (nbytes + 255) / 256;
-        hipLaunchKernelGGL(stage_bytes_kernel, dim3((unsigned)(wgs < 4096 ? wgs : 4096)), dim3(256), 0, st, (uint8_t*)dst,
+        hipLaunchKernelGGL(stage_bytes_kernel, dim3((unsigned)(wgs < cap ? wgs : cap)), dim3(256), 0, st, (uint8_t*)dst,
                            (const uint8_t*)src, nbytes);
     }
     GQ_LAUNCH_CHECK();

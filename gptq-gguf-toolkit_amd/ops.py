@@ -374,6 +374,16 @@ def chol_gemm(Cm: torch.Tensor, A: torch.Tensor, B: torch.Tensor, trans_b: bool,
     return Cm
 
 
+def stage_to_host(dst: torch.Tensor, src: torch.Tensor, stream: "torch.cuda.Stream") -> None:
+    """src (device, contiguous) -> dst (pinned host memory, same byte size) by a copy kernel on `stream`
+    (gq_stage_to_host: no hipMemcpy, no copy-engine lock shared with the launching thread)."""
+    _need_cuda(src)
+    assert src.is_contiguous() and dst.is_contiguous() and not dst.is_cuda
+    n = src.numel() * src.element_size()
+    assert dst.numel() * dst.element_size() == n
+    check(lib().gq_stage_to_host(_ptr(dst), _ptr(src), n, ctypes.c_void_p(stream.cuda_stream)), "gq_stage_to_host")
+
+
 def fwd_rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
     """LlamaRMSNorm.forward in one pass (gq_fwd_rmsnorm); x [..., C] fp16 / bf16 contiguous, weight [C] of the same dtype."""
     _need_cuda(x, weight)

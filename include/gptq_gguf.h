@@ -242,6 +242,12 @@ int gq_trailing_update(float* Cmat, int64_t ldc, const float* A, int64_t lda, co
 int gq_chol_gemm(float* Cmat, int64_t ldc, const float* A, int64_t lda, const float* B, int64_t ldb, int64_t M, int64_t N,
                  int64_t K, int trans_b, int mode, int k_range, int lower, int planes, void* ws, size_t ws_bytes, void* stream);
 
+/* Device -> pinned host copy by a kernel on `stream` (the data.pth staging slots of quantizer.py's saver; reference
+   quantizer.py:267-275 moves the tensors with .cpu()).  host_dst must be pinned and mapped (hipHostRegister /
+   hipHostMalloc).  Unlike hipMemcpyAsync it takes no runtime copy-engine lock: a side thread staging results does not
+   stall the launches of the thread that runs the forward. */
+int gq_stage_to_host(void* host_dst, const void* src, int64_t nbytes, void* stream);
+
 /* SURVEY 8(f) row 2, opt-in (Quantizer(fused_forward=True)): the elementwise part of the calibration forward the
    reference leaves to HF eager modules (quantizer.py:293 `block(inp_batch, **kwargs)`), one HBM pass each, fp32
    arithmetic rounded to `dtype` (GQ_F16 / GQ_BF16) after every torch op of the module it replaces:

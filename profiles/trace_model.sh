@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 tag=$(echo "model$*" | tr -d ' -')
 mkdir -p $R/gpurun_out/r3/$tag
-timeout 600 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/r3/$tag/p -o p -- python $R/bench.py --workload llama3-8b-model-q4k --layers 3 --steps 1 --warmup 0 "$@" > $R/gpurun_out/r3/$tag/bench.log 2>&1 || echo "pass failed"
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/r3/$tag/p -o p -- python $R/bench.py --workload llama3-8b-model-q4k --layers ${LAYERS:-3} --steps 1 --warmup 0 "$@" > $R/gpurun_out/r3/$tag/bench.log 2>&1 || echo "pass failed"
 f=$(find $R/gpurun_out/r3/$tag/p -name '*kernel_trace.csv' | head -1)
 python3 $R/profiles/trace_model.py $f | tee $R/gpurun_out/r3/$tag/summary.txt
 python3 - $f <<'PY'
@@ -16,4 +16,5 @@ for r in csv.DictReader(open(sys.argv[1])):
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
     print(f"{v[1] / 1e6:9.2f} ms {v[0]:7d} {v[1] / v[0] / 1e3:8.1f} us  {k}")
 PY
+python3 $R/profiles/trace_phases.py $f | tee $R/gpurun_out/r3/$tag/phases.txt
 rm -rf $R/gpurun_out/r3/$tag/p

@@ -243,7 +243,7 @@ def test_data_pth_writer_failure_never_blocks_the_copier(tmp_path):
     th = threading.Thread(target=qz._writer_process, args=(str(bad_dir), slots, inbox, freeq, outbox), daemon=True)
     th.start()
     for i in range(5):  # more items than slots: each slot must come back although every write fails
-        inbox.put(("slot", i % 2, f"m{i}", 12, layout))
+        inbox.put(("slots", i % 2, [(f"m{i}", 12, layout)]))
         assert freeq.get(timeout=20) == i % 2
     status, info = outbox.get(timeout=20)
     assert status == "error" and "m0" in info  # reported with the first failure, not at the end
@@ -256,11 +256,19 @@ def test_data_pth_writer_failure_never_blocks_the_copier(tmp_path):
     good.mkdir()
     th = threading.Thread(target=qz._writer_process, args=(str(good), slots, inbox, freeq, outbox), daemon=True)
     th.start()
-    inbox.put(("slot", 0, "m", 12, layout))
+    inbox.put(("slots", 0, [("m", 12, layout)]))
     assert freeq.get(timeout=20) == 0
+    # one slot carrying two modules (a block's Linears travel together): both files appear
+    layout2 = [(2048 + off, n, dt, shape) for off, n, dt, shape in layout]
+    slots[1][:256] = 7
+    slots[1][2048:2048 + 256] = 9
+    inbox.put(("slots", 1, [("a", 12, layout), ("b", 12, layout2)]))
+    assert freeq.get(timeout=20) == 1
     inbox.put(None)
     th.join(timeout=20)
     assert outbox.get(timeout=5)[0] == "ok" and (good / "m" / "data.pth").is_file()
+    a, b = (torch.load(good / n / "data.pth") for n in ("a", "b"))
+    assert int(a["qweight"][0]) == 7 and int(b["qweight"][0]) == 9 and a["q_type"] == 12
 
 
 def test_missing_data_pth_is_reported(tmp_path):
