@@ -513,7 +513,9 @@ __global__ __launch_bounds__(512, 2) void gemm32_chain_full_persistent_kernel(fl
 // LDS.  There every thread loads 4 float4 into registers two chunks ahead and later writes them out (8 ds_write_b32 for
 // the padded A rows + 2 ds_write_b128): measured with the probe builds above, dropping that commit alone shortens the
 // far launches by 11 %, the loads by another 6 % -- issue slots and LDS write cycles taken from the MFMA stream.  Here
-// a wave issues 4 DMA instructions per chunk (2 KiB of A, 2 KiB of B each) and nothing else.
+// a wave issues 4 DMA instructions per chunk (2 KiB of A, 2 KiB of B each) and nothing else.  OPT-IN (GQ_FAR_DMA=1):
+// bit-identical results, no LDS bank conflicts (SQ_LDS_BANK_CONFLICT = 0), yet 6 % slower than the register-staged
+// kernel on the 4096 x 14336 loop (profiles/far_dma_ab.sh, profiles/pmc_far_lds.sh) -- see launch_gemm32_chain_full.
 //   LDS: A ring [4 slots][128 rows][8 units of 16 B] (64 KiB) then B ring [4 slots][32 k][128 columns] (64 KiB).
 //   A unit (row, kq) sits at position kq ^ ((row >> 1) & 7) of its row: the ds_read_b128 of a 16-lane group (16 rows,
 //   one kq) touches 16 distinct 16-byte columns of the 256-byte LDS line.  A lane keeps k = 4 kq + lk and 4 kq + 2 + lk
@@ -678,9 +680,11 @@ inline int launch_gemm32_chain_full(float* Cmat, int64_t ldc, const float* A, in
         attr_set = true;
     }
     const int64_t ntx = N / 128, ntiles = ntx * (M / 128);
-    // default: the DMA form (GQ_FAR_NO_DMA=1: register-staged chunks, the r02 kernel); needs 32-bit operand offsets
-    static const bool no_dma = getenv("GQ_FAR_NO_DMA") != nullptr;
-    if (!no_dma && K % CHAIN == 0 && 128 * lda * 4 < (int64_t)1 << 31 && 32 * ldb * 4 < (int64_t)1 << 31) {
+    // GQ_FAR_DMA=1: the DMA form above (measured r03, 4096 x 14336 column loop: 14.4 vs 13.6 ms of far launches, matrix
+    // pipe busy 72.5 vs 76.6 % -- slower than the register-staged chunks although it issues a tenth of the staging
+    // instructions: opt-in, kept for the next attempt); needs 32-bit operand offsets
+    static const bool dma = getenv("GQ_FAR_DMA") != nullptr;
+    if (dma && K % CHAIN == 0 && 128 * lda * 4 < (int64_t)1 << 31 && 32 * ldb * 4 < (int64_t)1 << 31) {
         constexpr int DLDS = 128 * 1024;
         static std::atomic<bool> dattr_set{false};
         if (!dattr_set) {

@@ -5,7 +5,7 @@ timeout 900 python -m pytest tests -q -m gpu -x -k "gptq or golden or lookahead 
 cd /tmp && export TMPDIR=/tmp
 for v in 0 1; do
   d=$R/gpurun_out/r3/far_dma_$v; mkdir -p $d
-  if [ $v = 1 ]; then export GQ_FAR_NO_DMA=1; fi
+  if [ $v = 0 ]; then export GQ_FAR_DMA=1; else unset GQ_FAR_DMA; fi
   timeout 300 rocprofv3 --kernel-trace --output-format csv -d $d/p -o p -- python $R/profiles/near_probe.py > $d/log.txt 2>&1 || echo "pass failed"
   python3 - $(find $d/p -name '*kernel_trace.csv' | head -1) "NO_DMA=$v" <<'PY'
 import csv, sys

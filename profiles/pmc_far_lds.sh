@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 for v in 0 1; do
 d=$R/gpurun_out/r3/pmc_far_lds_$v; mkdir -p $d
-if [ $v = 1 ]; then export GQ_FAR_NO_DMA=1; fi
+if [ $v = 0 ]; then export GQ_FAR_DMA=1; else unset GQ_FAR_DMA; fi
 timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $d/p -o p -- python $R/profiles/near_probe.py > $d/p.log 2>&1 || echo "pass failed"
 python3 - $d <<'PY'
 import csv, glob, collections, sys

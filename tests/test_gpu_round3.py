@@ -234,3 +234,66 @@ def test_bench_eight_ranks_one_allgather_per_block():
     assert line["collectives_per_step"] == {"all_reduce": 4.0, "all_gather": 1.0, "broadcast": 0.0}, line["collectives_per_step"]
     owners = line["config"]["owners"]
     assert owners["down_proj"] == f"rows/{n}" and len({v for k, v in owners.items() if k != "down_proj"}) == 6, owners
+
+
+_LOOP_HASH = r"""
+import hashlib, sys, torch
+sys.path.insert(0, {root!r})
+from gptq_gguf_toolkit_amd import ops
+g = torch.Generator(device="cuda").manual_seed(3)
+R, C = 256, 9216  # >= 8 super-blocks of 1024 columns: the far updates take the helper-stream (persistent) form
+X = torch.randn(10240, C, device="cuda", generator=g).half()
+H = torch.zeros(C, C, device="cuda")
+ops.h_accumulate(H, X, 0.0, 0.5)
+W = torch.randn(R, C, device="cuda", generator=g) * 0.02
+U, _ = ops.h_prepare(H, W.clone(), 0.01)
+Wf = W.clone()
+res = ops.gptq_quantize(Wf, U, 12, 128)
+torch.cuda.synchronize()
+h = hashlib.sha256()
+for t in (Wf,) + tuple(res):
+    h.update(t.cpu().contiguous().view(torch.uint8).numpy().tobytes())
+print("HASH", h.hexdigest())
+"""
+
+
+def test_trailing_update_kernel_choices_are_bit_identical():
+    """The column loop's trailing updates have three kernels that are selected per process (environment read once):
+    the 64-tile near kernel with whole K = 256 panels in LDS (default) vs the 128-tile chained kernel
+    (GQ_NEAR64_MAXN=0), and the far update with DMA'd chunks (GQ_FAR_DMA=1, opt-in) vs register-staged chunks.  Every
+    output element is the same k-ordered chain in all of them: W and the quantized tensors hash identically."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    hashes = {}
+    for tag, extra in (("default", {}), ("near128", {"GQ_NEAR64_MAXN": "0"}), ("far_dma", {"GQ_FAR_DMA": "1"}),
+                       ("classic", {"GQ_NEAR_CLASSIC": "1"})):
+        env = dict(os.environ, **extra)
+        p = subprocess.run([sys.executable, "-c", _LOOP_HASH.format(root=ROOT)], env=env, capture_output=True, text=True,
+                           timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        hashes[tag] = [ln for ln in p.stdout.splitlines() if ln.startswith("HASH")][-1]
+    assert len(set(hashes.values())) == 1, hashes
+
+
+def test_stage_to_host_copies_through_the_slot_mapping():
+    """gq_stage_to_host (the saver's staging copy): device tensor -> pinned host memory by a kernel; unpinned memory is
+    refused with an error instead of a fault."""
+    from gptq_gguf_toolkit_amd import _cabi, ops
+    st = torch.cuda.current_stream()
+    for n, dt in ((1 << 20, torch.uint8), (12345, torch.uint8), (4096 * 33, torch.float16)):
+        src = (torch.arange(n, device="cuda") % 251).to(dt)
+        dst = torch.empty(n, dtype=dt).pin_memory()
+        ops.stage_to_host(dst, src, st)
+        torch.cuda.synchronize()
+        assert torch.equal(dst, src.cpu())
+    shm = torch.zeros(4096, dtype=torch.uint8).share_memory_()
+    assert int(torch.cuda.cudart().cudaHostRegister(shm.data_ptr(), shm.numel(), 0)) == 0
+    try:
+        ops.stage_to_host(shm, torch.full((4096,), 7, dtype=torch.uint8, device="cuda"), st)
+        torch.cuda.synchronize()
+        assert int(shm.sum()) == 7 * 4096
+    finally:
+        torch.cuda.cudart().cudaHostUnregister(shm.data_ptr())
+    with pytest.raises(_cabi.GQError):
+        ops.stage_to_host(torch.empty(4096, dtype=torch.uint8), torch.zeros(4096, dtype=torch.uint8, device="cuda"), st)
