@@ -22,6 +22,8 @@ The same JSON line carries, measured AFTER the timed region:
   * `whole_model`: the drop-in pipeline end to end -- a random-init Llama-3-8B-shaped LlamaForCausalLM built on the
     GPU, 128 x 2048 synthetic ids, `Quantizer.quantize` (the region the reference times, quant.py:251-254: capture
     forward, forward #1 + H, solve + column loop, forward #2, RTN of embed/lm_head, data.pth saving) with its split;
+    `whole_model_fused` the same with --fused_forward (HIP RMSNorm / rotary / SwiGLU kernels, opt-in), and both again
+    with --calibration_batch 4 (`whole_model_batch4`, `whole_model_batch4_fused`);
   * `trailing_update`: the north star's GEMM three ways (far launches alone, near + far alone, far launches inside
     the timed region);
   * `tolerance_parity`: GPU H -> U -> ints against the oracle's fp64 H -> fp64 U -> ints on the same inputs;
@@ -259,7 +261,7 @@ def trailing_update_legs(wl, W16, X, in_region):
         nms, nn_, _ = best.get("trailing_gemm32", (0.0, 0, 0.0))
         out = {"bound": "mfma", "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "linear": f"{name} {R}x{C}",
                "U": "gq_h_prepare of this Linear's Hessian (8 calibration sequences)",
-               "kernels": "gemm32_chain_full_kernel<128> (far, K = 1024, and near: K = 256 after every 256-column group)"}
+               "kernels": "gemm32_chain_full_kernel<128> (far, K = 1024); gemm32_near256_kernel (near: K = 256 after every 256-column group)"}
         if fn:
             a = far / (fms * 1e-3) / 1e12
             out["far_alone"] = {"achieved": round(a, 2), "frac": round(a / PEAK_F32_MFMA_TFLOPS, 4), "launches": fn,
