@@ -509,10 +509,16 @@ def whole_model_run(wl, dev, world, rank, save_root=None, nseq=None, L=None, lay
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        wm_prof = os.environ.get("GQ_BENCH_WM_PROF")  # e.g. "syrk,transpose16": HIP-event time of those kernels in the run
+        if wm_prof:
+            _cabi.prof_enable(wm_prof.split(","))
         t1 = time.perf_counter()
         drv.quantize(qc)
         torch.cuda.synchronize()
         wall = time.perf_counter() - t1
+        if wm_prof:
+            prof_got = {k: (round(v[0], 1), v[1]) for k, v in _cabi.prof_collect().items() if v[1]}
+            _cabi.prof_enable([])
         tm = torch.tensor([wall], device=dev, dtype=torch.float64)
         if world > 1:
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
@@ -530,7 +536,7 @@ def whole_model_run(wl, dev, world, rank, save_root=None, nseq=None, L=None, lay
                     + (" (the reference's cadence)" if calib_batch == 1 else " (--calibration_batch: same Hessian sums, fewer and larger GEMMs)"),
            "params_quantized_M": round(params / 1e6, 1),
            "wall_s_quantizer_region": round(wall, 2), "Mparams_per_s": round(params / wall / 1e6, 1),
-           "split": drv.timing, "schedule": getattr(drv, "schedule_stats", None), "model_build_s": round(t_build, 1),
+           "split": dict(drv.timing, **({"kernel_ms_launches": prof_got} if wm_prof else {})), "schedule": getattr(drv, "schedule_stats", None), "model_build_s": round(t_build, 1),
            "data_pth": {"files": files, "GB": round(nbytes / 1e9, 2), "dir": root},
            "region": "Quantizer.quantize (reference quant.py:251-254), model and ids resident on the GPU/host before it"}
     del drv, model

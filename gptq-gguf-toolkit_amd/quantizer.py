@@ -328,7 +328,11 @@ class _Saver:
         for them (on the host) and passes the slot to the writer process.  Measured on Llama-3-8B: a second thread
         launching ANYTHING on a stream of its own while this thread issues the forwards -- one 16-element fill per
         module is enough -- costs 2-3 s of a 12 s run (forward #1 5.8 -> 7.5 s, the chains 1.1 -> 1.6 s); GPU-side the
-        copies are 5 ms per block either way.  (GQ_SAVE_INLINE=0: the copier thread copies on its own stream.)"""
+        copies are 5 ms per block either way.  In that slow mode the large kernels run as fast as ever (SYRK 1.77 vs 1.68 s
+        per run) while the launches that hang on cross-stream events do not: the single-workgroup Cholesky leaves take
+        574 vs 305 ms, the column-loop kernels 793 vs 590 ms (bench.py, GQ_BENCH_WM_PROF) -- dependent dispatch got slower,
+        not the kernels; the cause inside the runtime is not identified (hardware-queue count, copy engine, PCIe and the
+        allocator are ruled out: DESIGN.md 6b).  (GQ_SAVE_INLINE=0: the copier thread copies on its own stream.)"""
         if not items:
             return
         if self.sync or not items[0][2][0].is_cuda:
@@ -526,6 +530,11 @@ class Quantizer:
             if getattr(self, "_phases", None) is not None:
                 self._phases.host["save_tail"] = time.perf_counter() - t0
                 self.timing = self._phases.result()
+                if torch.device(device).type == "cuda":
+                    ms = torch.cuda.memory_stats(device)
+                    self.timing["allocator"] = {"device_allocs": ms["num_device_alloc"], "segments": ms["segment.all.current"],
+                                                "reserved_GiB": round(ms["reserved_bytes.all.peak"] / 2**30, 1),
+                                                "active_peak_GiB": round(ms["active_bytes.all.peak"] / 2**30, 1)}
                 self.timing["saver_copy_thread_busy_s"] = round(self._saver.busy_s, 4)
                 self.timing["saver_writer_process_busy_s"] = round(getattr(self._saver, "writer_busy_s", 0.0), 4)
 
@@ -561,6 +570,15 @@ class Quantizer:
             for _, m in pre_blocks:
                 m.cpu()
         ph.mark("rtn_pre")
+        # GQ_POST_BLOCKS_EARLY=1 (measured, off): quantize the post-block modules (lm_head) here instead of after the last
+        # block (quantizer.py:181-198) -- their RTN reads nothing the block loop writes, same tensors and files -- so that
+        # lm_head's data.pth (657 MB for Llama-3-8B: 0.6 s of torch.save) is written under the block loop: save tail
+        # 0.6 -> 0.3 s, but 2 of 5 runs then fell into the slow mode described at _Saver.put_many (+2.4 s), 0 of 9 without.
+        post_early = self.quant_non_block_modules and os.environ.get("GQ_POST_BLOCKS_EARLY") == "1"
+        if post_early:
+            for name, module in post_blocks:
+                self._quant_and_save_non_block(name, module.to(device), quant_config)
+            ph.mark("rtn_post")
 
         for block_id, block in enumerate(blocks):
             if self.verbose:
@@ -600,11 +618,14 @@ class Quantizer:
             if os.environ.get("GQ_TRACE_BLOCKS") == "1":  # measurement knob: per-block wall time (synchronises)
                 torch.cuda.synchronize()
                 now = time.perf_counter()
+                ms = torch.cuda.memory_stats(device)
                 print(f"[gq] block {block_id}: {1e3 * (now - getattr(self, '_t_block', now)):.1f} ms "
-                      f"(saver queue {self._saver.q.qsize()})", file=sys.stderr)
+                      f"(saver queue {self._saver.q.qsize()}; reserved {ms['reserved_bytes.all.current'] >> 20} MiB in "
+                      f"{ms['segment.all.current']} segments, {ms['num_device_alloc']} device allocs, "
+                      f"active {ms['active_bytes.all.current'] >> 20} MiB)", file=sys.stderr)
                 self._t_block = now
 
-        if self.quant_non_block_modules:
+        if self.quant_non_block_modules and not post_early:
             for name, module in post_blocks:
                 self._quant_and_save_non_block(name, module.to(device), quant_config)
         if use_cache is not None:
