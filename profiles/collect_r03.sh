@@ -8,20 +8,6 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/r03
 mkdir -p $OUT
 WLS=${@:-"llama3-8b-block-q4k llama3-8b-block-mixed tinyllama-block-q4k llama3-70b-block-q4k mixtral-block"}
-for W in $WLS; do
-  EXTRA=""
-  [ "$W" != "llama3-8b-block-q4k" ] && EXTRA="--no-whole-model"
-  cd $R && timeout 900 python bench.py --workload $W --steps 5 --warmup 2 $EXTRA 2>$OUT/r03_bench_$W.err | tail -1 > $OUT/r03_bench_$W.json
-  (cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$W -o p -- \
-     python $R/bench.py --workload $W --steps 5 --warmup 2 --no-cpu-baseline --no-whole-model --no-side-legs > $OUT/prof_$W.log 2>&1 || echo "rocprofv3 failed for $W")
-  cp $(find $OUT/prof_$W -name "*kernel_stats.csv" | head -1) $OUT/r03_bench_${W}_kernel_stats.csv 2>/dev/null
-  rm -rf $OUT/prof_$W
-  python3 -c "
-import json,sys
-d=json.loads(open('$OUT/r03_bench_$W.json').read())
-print('$W', d['ms_per_step'], 'ms/step', d['value'], 'Mparams/s  syrk frac', d['roofline']['frac'], ' trailing whole', (d.get('trailing_update') or {}).get('whole_alone',{}).get('frac'), ' cpu', (d.get('cpu_baseline') or {}).get('value'))
-" 2>&1 | tail -1
-done
 # L2-miss read bytes of the SYRK launches of the default bench command (its own pass: --pmc with --kernel-trace only)
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o p -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-whole-model --no-side-legs > $OUT/pmc_fetch.log 2>&1 || echo "pmc pass failed"
@@ -52,3 +38,18 @@ if rows:
     print(f"{len(rows)} SYRK launches, {per:.2f} GB per launch (algorithmic {alg:.2f})")
 PY
 rm -rf $OUT/pmc_fetch
+cp $OUT/r03_syrk_traffic.json $R/profiles/r03_syrk_traffic.json  # bench.py reads it (and checks the source hash)
+for W in $WLS; do
+  EXTRA=""
+  [ "$W" != "llama3-8b-block-q4k" ] && EXTRA="--no-whole-model"
+  cd $R && timeout 900 python bench.py --workload $W --steps 5 --warmup 2 $EXTRA 2>$OUT/r03_bench_$W.err | tail -1 > $OUT/r03_bench_$W.json
+  (cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$W -o p -- \
+     python $R/bench.py --workload $W --steps 5 --warmup 2 --no-cpu-baseline --no-whole-model --no-side-legs > $OUT/prof_$W.log 2>&1 || echo "rocprofv3 failed for $W")
+  cp $(find $OUT/prof_$W -name "*kernel_stats.csv" | head -1) $OUT/r03_bench_${W}_kernel_stats.csv 2>/dev/null
+  rm -rf $OUT/prof_$W
+  python3 -c "
+import json,sys
+d=json.loads(open('$OUT/r03_bench_$W.json').read())
+print('$W', d['ms_per_step'], 'ms/step', d['value'], 'Mparams/s  syrk frac', d['roofline']['frac'], ' trailing whole', (d.get('trailing_update') or {}).get('whole_alone',{}).get('frac'), ' cpu', (d.get('cpu_baseline') or {}).get('value'))
+" 2>&1 | tail -1
+done
