@@ -176,6 +176,7 @@ class _Saver:
         self.use_process = os.environ.get("GQ_SAVE_MODE", "process") == "process"
         self._kernel_copy = os.environ.get("GQ_SAVE_MEMCPY") != "1"  # (GQ_SAVE_MEMCPY=1: hipMemcpyAsync, the r02 path)
         self._inline = os.environ.get("GQ_SAVE_INLINE", "1") != "0"
+        self.n_slots = max(2, int(os.environ.get("GQ_SAVE_SLOTS", 3)))
         self._ready = threading.Event()
         self._poll_lock = threading.Lock()
         self.slot_bytes = int(os.environ.get("GQ_SAVE_SLOT_MB", 704)) << 20  # embed_tokens of Llama-3 in Q4_K: 657 MB
@@ -185,7 +186,7 @@ class _Saver:
         ctx = tmp.get_context("spawn")
         # the slots are files in /dev/shm: ftruncate succeeds on a small tmpfs (Docker's default is 64 MB) and the
         # first write into the slot then kills the process with SIGBUS -- ask before allocating
-        need = 2 * self.slot_bytes + (64 << 20)
+        need = self.n_slots * self.slot_bytes + (64 << 20)
         try:
             st = os.statvfs("/dev/shm")
             free = st.f_bavail * st.f_frsize
@@ -194,7 +195,7 @@ class _Saver:
         if free < need:
             raise OSError(f"/dev/shm has {free >> 20} MiB free, the writer process needs {need >> 20} MiB "
                           f"(GQ_SAVE_SLOT_MB={self.slot_bytes >> 20})")
-        self.slots = [torch.empty(self.slot_bytes, dtype=torch.uint8).share_memory_() for _ in range(2)]
+        self.slots = [torch.empty(self.slot_bytes, dtype=torch.uint8).share_memory_() for _ in range(self.n_slots)]
         self._registered = []
         for t in self.slots:  # pin the shared pages: device-to-host copies into them are plain DMA
             try:
@@ -231,6 +232,14 @@ class _Saver:
                     finally:
                         if not sent:
                             self.freeq.put(sid)
+                    self.busy_s += time.perf_counter() - t0
+                    continue
+                if item[0] == "host":
+                    _, name, q_type, host = item
+                    if self.proc is not None and not self._writer_dead:
+                        self.inbox.put(("host", name, int(q_type), host))
+                    else:
+                        _write_data_pth(self.save_dir, name, q_type, *host)
                     self.busy_s += time.perf_counter() - t0
                     continue
                 _, name, q_type, tensors, ev, dev = item
@@ -353,8 +362,12 @@ class _Saver:
             nonlocal group, size
             if not group:
                 return
-            sid = self._get_slot()  # may wait for the writer (which needs only work that is already queued)
-            if sid is None:  # the writer is gone: the copier thread writes
+            # May wait for the writer to hand a slot back (that needs only work which is already queued: the copy kernels,
+            # the copier's host-side wait, the writer's clone).  Waiting is the lesser evil: sending the group down the
+            # copier thread's own-stream path instead was tried -- one early miss and the rest of the run is in the slow
+            # mode (13.4 vs 12.1 s).  Three slots: a Llama block needs one per 350 ms, the writer frees one in 130 ms.
+            sid = self._get_slot()
+            if sid is None:
                 for name, q_type, tensors in group:
                     self._put_one(name, q_type, tensors, cur, dev)
             else:
@@ -377,7 +390,13 @@ class _Saver:
 
         for name, q_type, tensors in items:
             n = _layout_of(tensors, 0)[1]
-            if not inline or n > self.slot_bytes:
+            if inline and n > self.slot_bytes:
+                # larger than a slot (a 70B model's embed_tokens): copied out by THIS thread, synchronously -- twice per
+                # model -- rather than by the copier on a stream of its own
+                flush()
+                self.q.put(("host", name, q_type, [t.cpu() for t in tensors]))
+                continue
+            if not inline:
                 flush()
                 self._put_one(name, q_type, tensors, cur, dev)
                 continue

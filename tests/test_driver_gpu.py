@@ -170,3 +170,36 @@ def test_unwritable_save_dir_raises_instead_of_hanging(tmp_path):
         drv.quantize({"q_proj": T.Q4_K})
     from gptq_gguf_toolkit_amd.block_schedule import BlockSchedule
     assert BlockSchedule.unverified == [] and BlockSchedule._staged_checks == []
+
+
+@pytest.mark.timeout(600)
+def test_saver_groups_oversize_and_slot_waits(tmp_path, monkeypatch):
+    """_Saver.put_many with 1 MiB slots: several modules per slot, a module larger than a slot (copied out by the calling
+    thread), more groups than slots (the caller waits for the writer) -- every data.pth holds exactly what was put."""
+    from gptq_gguf_toolkit_amd import quantizer as qz
+    monkeypatch.setenv("GQ_SAVE_SLOT_MB", "1")
+    monkeypatch.setenv("GQ_SAVE_SLOTS", "2")
+    sv = qz._Saver(str(tmp_path), sync=False)
+    sv.warm_up(torch.device("cuda:0"))
+    g = torch.Generator(device="cuda").manual_seed(11)
+    want = {}
+
+    def module(name, rows):
+        q = torch.randint(0, 255, (rows, 256), device="cuda", dtype=torch.uint8, generator=g)
+        d = torch.randn(rows, 1, device="cuda", generator=g).half()
+        s_ = torch.randint(0, 63, (rows, 8), device="cuda", dtype=torch.uint8, generator=g)
+        dm = torch.randn(rows, 1, device="cuda", generator=g).half()
+        m = torch.randint(0, 63, (rows, 8), device="cuda", dtype=torch.uint8, generator=g)
+        want[name] = [t.cpu() for t in (q, d, s_, dm, m)]
+        return (name, 12, (q, d, s_, dm, m))
+
+    for blk in range(4):  # 3 x 0.27 MiB + 0.8 MiB per block: two groups per block, eight groups over two slots
+        sv.put_many([module(f"b{blk}.m{i}", 1024) for i in range(3)] + [module(f"b{blk}.wide", 3000)])
+    sv.put(*module("huge", 6000))  # 1.6 MiB: larger than a slot
+    sv.close()
+    assert sv.err is None and len(want) == 17
+    for name, (q, d, s_, dm, m) in want.items():
+        got = torch.load(tmp_path / name / "data.pth")
+        assert got["q_type"] == 12 and torch.equal(got["qweight"], q) and torch.equal(got["super_group_scale"], d)
+        assert torch.equal(got["group_scale_quant"], s_) and torch.equal(got["super_group_zero"], dm)
+        assert torch.equal(got["group_zero_quant"], m)
