@@ -187,3 +187,29 @@ def test_quantizer_with_fused_forward(tmp_path):
             assert float((a != b).float().mean()) < 0.02, n
         checked += 1
     assert checked == 14
+
+
+@pytest.mark.parametrize("family", ["mistral", "qwen2", "qwen3"])
+def test_other_families_under_the_patch(family):
+    """Families whose module text equals Llama's are patched too (forward_fused._targets): logits of a tiny random model
+    agree with HF eager to bf16 rounding, and the patch list names the family's classes."""
+    import transformers
+    from gptq_gguf_toolkit_amd.forward_fused import fused_forward
+    cfg_cls, model_cls = {"mistral": ("MistralConfig", "MistralForCausalLM"), "qwen2": ("Qwen2Config", "Qwen2ForCausalLM"),
+                          "qwen3": ("Qwen3Config", "Qwen3ForCausalLM")}[family]
+    kw = dict(hidden_size=256, intermediate_size=704, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
+              vocab_size=512, max_position_embeddings=256, rms_norm_eps=1e-5, tie_word_embeddings=False,
+              attn_implementation="sdpa")
+    if family == "qwen3":
+        kw["head_dim"] = 64
+    cfg = getattr(transformers, cfg_cls)(**kw)
+    torch.manual_seed(1)
+    model = getattr(transformers, model_cls)(cfg).to(torch.bfloat16).cuda().eval()
+    ids = torch.randint(0, 512, (2, 96), device="cuda")
+    with torch.no_grad():
+        want = model(input_ids=ids, use_cache=False).logits.float()
+        with fused_forward() as patched:
+            assert any(family in p.lower() for p in patched), patched
+            got = model(input_ids=ids, use_cache=False).logits.float()
+    assert float((want - got).abs().max()) <= 0.03 * float(want.abs().max())
+    assert float(((want - got) ** 2).mean().sqrt()) <= 3e-3 * float((want ** 2).mean().sqrt())
