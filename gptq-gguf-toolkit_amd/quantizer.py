@@ -154,14 +154,14 @@ def _writer_process(save_dir, slots, inbox, freeq, outbox):
 
 
 class _Saver:
-    """data.pth writer (quantizer.py:267-275) off the critical path.  A thread of this process copies a module's
-    five device tensors into a pinned staging slot on a side stream (behind an event that marks them complete); the
-    slots live in shared memory and a separate PROCESS copies them out and runs torch.save.  Why a process:
-    torch.save holds the interpreter lock for much of its 0.7 s per GB and Llama-3-8B leaves 8.7 GB of data.pth
-    behind -- written from a thread of this process, the launches of the next block's forwards stall (+1.2 s of
-    15.5 s; three writer threads: worse); why pinned slots: fresh pageable host tensors cost the copy thread 6-9 s
-    in page faults.  GQ_SAVE_MODE=thread keeps everything in-process; `sync=True` (CPU tensors, or GQ_SYNC_SAVE=1)
-    writes in line like the reference."""
+    """data.pth writer (quantizer.py:267-275) off the critical path.  The calling thread copies a block's result
+    tensors into a pinned staging slot with copy kernels on its own stream (put_many: why not a side thread's stream);
+    the slots live in shared memory; a copier thread waits for the copies on the host and a separate PROCESS copies the
+    slot out and runs torch.save.  Why a process: torch.save holds the interpreter lock for much of its 0.7 s per GB and
+    Llama-3-8B leaves 8.7 GB of data.pth behind -- written from a thread of this process, the launches of the next
+    block's forwards stall; why pinned slots: fresh pageable host tensors cost 6-9 s in page faults.
+    GQ_SAVE_MODE=thread keeps everything in-process; `sync=True` (CPU tensors, or GQ_SYNC_SAVE=1) writes in line like
+    the reference."""
 
     def __init__(self, save_dir: str, sync: bool):
         self.save_dir, self.sync = save_dir, sync
