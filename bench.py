@@ -22,7 +22,8 @@ The same JSON line carries, measured AFTER the timed region:
   * `whole_model`: the drop-in pipeline end to end -- a random-init Llama-3-8B-shaped LlamaForCausalLM built on the
     GPU, 128 x 2048 synthetic ids, `Quantizer.quantize` (the region the reference times, quant.py:251-254: capture
     forward, forward #1 + H, solve + column loop, forward #2, RTN of embed/lm_head, data.pth saving) with its split;
-    `whole_model_fused` the same with --fused_forward (HIP RMSNorm / rotary / SwiGLU kernels, opt-in), and both again
+    (the Quantizer's default forward: HF modules with the two bit-exact HIP kernels, rotary embedding and SwiGLU);
+    `whole_model_fused` the same with --fused_forward (RMSNorm as a HIP kernel too, <= 2 ulp, opt-in), and both again
     with --calibration_batch 4 (`whole_model_batch4`, `whole_model_batch4_fused`);
   * `trailing_update`: the north star's GEMM three ways (far launches alone, near + far alone, far launches inside
     the timed region);
@@ -470,7 +471,7 @@ def build_model(cfg_kw, dev, dtype=torch.bfloat16, seed=0):
     return model
 
 
-def whole_model_run(wl, dev, world, rank, save_root=None, nseq=None, L=None, layers=None, calib_batch=1, fused=False):
+def whole_model_run(wl, dev, world, rank, save_root=None, nseq=None, L=None, layers=None, calib_batch=1, fused="exact"):
     """Quantizer.quantize on a random-init Llama of the workload's architecture (the reference's timed region,
     quant.py:251-254) -> dict with wall seconds, Mparams/s and the split."""
     from gptq_gguf_toolkit_amd.quantizer import Quantizer
@@ -530,8 +531,9 @@ def whole_model_run(wl, dev, world, rank, save_root=None, nseq=None, L=None, lay
             shutil.rmtree(save_dir, ignore_errors=True)
     out = {"model": f"random-init LlamaForCausalLM {cfg_kw['num_hidden_layers']} layers, hidden {cfg_kw['hidden_size']}, "
                     f"bf16, attn {os.environ.get('GQ_ATTN', 'sdpa')}; embed + lm_head RTN ({q}), all block Linears GPTQ ({q})",
-           "forward": ("HIP RMSNorm / rotary / SwiGLU kernels (--fused_forward: " + ", ".join(getattr(drv, "_fused_modules", [])[:3]) + ")"
-                       if fused else "HF eager modules (the reference's forward)"),
+           "forward": {"off": "HF eager modules (the reference's forward)",
+                       "exact": "HF modules with the bit-exact HIP kernels (rotary embedding, SwiGLU): same saved bytes as HF eager",
+                       "all": "HIP RMSNorm / rotary / SwiGLU kernels (--fused_forward; RMSNorm <= 2 ulp)"}[drv.fused_forward],
            "calib": f"{nseq}x{L} synthetic ids ({len(ids)} sequences on this rank), {calib_batch} per block forward"
                     + (" (the reference's cadence)" if calib_batch == 1 else " (--calibration_batch: same Hessian sums, fewer and larger GEMMs)"),
            "params_quantized_M": round(params / 1e6, 1),
@@ -555,7 +557,8 @@ def main():
     ap.add_argument("--seq-len", type=int, default=None)
     ap.add_argument("--layers", type=int, default=None, help="whole-model workloads: number of blocks (default: all)")
     ap.add_argument("--calib-batch", type=int, default=1, help="whole-model workload: calibration samples per block forward")
-    ap.add_argument("--fused-forward", action="store_true", help="whole-model workload: HIP RMSNorm / rotary / SwiGLU kernels")
+    ap.add_argument("--fused-forward", nargs="?", const="all", default="exact", choices=["off", "exact", "all"],
+                    help="whole-model workload: forward kernels (exact = the Quantizer's default; bare flag = all)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-whole-model", action="store_true", help="skip the whole-model leg of the block workloads")
     ap.add_argument("--no-side-legs", action="store_true", help="skip trailing_update / tolerance_parity legs")
@@ -754,8 +757,8 @@ def main():
         del layers, W16, X
         torch.cuda.empty_cache()
         wm = {}
-        for key, cb, fused in (("whole_model", 1, False), ("whole_model_fused", 1, True), ("whole_model_batch4", 4, False),
-                               ("whole_model_batch4_fused", 4, True)):
+        for key, cb, fused in (("whole_model", 1, "exact"), ("whole_model_fused", 1, "all"), ("whole_model_batch4", 4, "exact"),
+                               ("whole_model_batch4_fused", 4, "all")):
             try:
                 wm[key] = whole_model_run(WORKLOADS["llama3-8b-model-q4k"], dev, world, rank, layers=args.layers, calib_batch=cb,
                                           fused=fused)

@@ -1,4 +1,4 @@
-"""Opt-in HIP kernels for the elementwise part of the calibration forward.
+"""HIP kernels for the elementwise part of the calibration forward.
 
 The reference runs every decoder layer through the HF eager modules (reference quantizer.py:293
 `block(inp_batch, **kwargs)`); on an MI355X that forward is 60 % of a whole-model run and a third of
@@ -12,8 +12,11 @@ those three with one gfx950 kernel each (csrc/gq_forward.hip) for the duration o
 The Linear modules are still called through `nn.Module.__call__`, so the Hessian hooks see the same inputs.  A model
 family is patched only when the source text of its module matches Llama's (Mistral, Qwen2 ... copy it verbatim), and
 every patched function falls back to the original for inputs the kernels do not take (fp32, non-contiguous, odd
-sizes, CPU tensors) -- the originals are torch code, not a CPU restatement of ours.  Off by default: the outputs
-equal HF eager's up to the summation order of the RMSNorm mean (tests/test_gpu_forward.py states the tolerance).
+sizes, CPU tensors) -- the originals are torch code, not a CPU restatement of ours.  Levels (`level_of`): "exact"
+-- the Quantizer's default -- installs only the rotary embedding and SwiGLU kernels, which are bit-identical to HF
+eager (tests/test_gpu_forward.py: torch.equal, every finite 16-bit gate value included; a Quantizer run with them
+saves the same bytes as one without); "all" adds RMSNorm, whose outputs equal HF eager's up to the summation order
+of the mean (<= 2 ulp on < 0.1 % of the elements) and is therefore opt-in (`--fused_forward`); "off" patches nothing.
 """
 from __future__ import annotations
 
@@ -87,8 +90,9 @@ def _mlp_forward(orig):
     return forward
 
 
-def _targets() -> List[Tuple[object, str, object]]:
-    """(owner, attribute, replacement) for every installed family whose module text equals Llama's."""
+def _targets(with_norm: bool = True) -> List[Tuple[object, str, object]]:
+    """(owner, attribute, replacement) for every installed family whose module text equals Llama's.  with_norm=False:
+    only the two replacements that are bit-exact against HF eager (rotary embedding, SwiGLU)."""
     from transformers.models.llama import modeling_llama as ref
     want_norm, want_rope, want_mlp = _body(ref.LlamaRMSNorm.forward), _body(ref.apply_rotary_pos_emb), _body(ref.LlamaMLP.forward)
     out = []
@@ -101,7 +105,7 @@ def _targets() -> List[Tuple[object, str, object]]:
             if not inspect.isclass(cls) or getattr(cls, "__module__", None) != mod.__name__:
                 continue
             try:
-                if name.endswith("RMSNorm") and _body(cls.forward) == want_norm:
+                if with_norm and name.endswith("RMSNorm") and _body(cls.forward) == want_norm:
                     out.append((cls, "forward", _rmsnorm_forward(cls.forward)))
                 elif name.endswith("MLP") and _body(cls.forward) == want_mlp:
                     out.append((cls, "forward", _mlp_forward(cls.forward)))
@@ -116,17 +120,35 @@ def _targets() -> List[Tuple[object, str, object]]:
     return out
 
 
+def level_of(flag) -> str:
+    """Normalise the Quantizer's `fused_forward` argument: "off" (False / None / "off" / "0"), "exact" (only the
+    bit-exact kernels: rotary embedding and SwiGLU) or "all" (True / "all" / "1": RMSNorm as well, <= 2 ulp)."""
+    if flag is None or flag is False:
+        return "off"
+    if flag is True:
+        return "all"
+    f = str(flag).lower()
+    if f in ("off", "0", "false", "no", "none", ""):
+        return "off"
+    if f in ("all", "1", "true", "yes"):
+        return "all"
+    if f == "exact":
+        return "exact"
+    raise ValueError(f"fused_forward={flag!r}: expected off / exact / all")
+
+
 @contextlib.contextmanager
-def fused_forward(enabled: bool = True):
-    """Within the block, the matching HF modules run the gfx950 kernels.  Raises (does not fall back) if the HIP
-    library is missing; restores the originals on exit."""
-    if not enabled:
+def fused_forward(enabled=True):
+    """Within the block, the matching HF modules run the gfx950 kernels (`enabled`: see level_of).  Raises (does not
+    fall back) if the HIP library is missing; restores the originals on exit."""
+    level = level_of(enabled)
+    if level == "off":
         yield []
         return
     ops.lib()  # fail loudly here, not in the middle of a forward
     saved = []
     try:
-        for owner, attr, new in _targets():
+        for owner, attr, new in _targets(with_norm=(level == "all")):
             saved.append((owner, attr, vars(owner)[attr] if attr in vars(owner) else getattr(owner, attr)))
             setattr(owner, attr, new)
         yield [f"{getattr(o, '__name__', o)}.{a}" for o, a, _ in saved]

@@ -74,9 +74,10 @@ def parse_args(argv=None):
                    help="calibration samples per block forward (the reference runs 1; the Hessians are the same sums)")
     p.add_argument("--non_block_fp32", action="store_true",
                    help="run the embed/lm_head scale search in fp32 (the reference runs it in the model dtype)")
-    p.add_argument("--fused_forward", action="store_true",
-                   help="run RMSNorm / rotary embedding / SwiGLU of the calibration forward as HIP kernels "
-                        "(the reference runs the HF eager modules)")
+    p.add_argument("--fused_forward", nargs="?", const="all", default="exact", choices=["off", "exact", "all"],
+                   help="HIP kernels for the elementwise modules of the calibration forward (the reference runs the HF "
+                        "eager modules): exact (default) = rotary embedding + SwiGLU, bit-identical to HF eager; all (or "
+                        "the bare flag) = RMSNorm too, <= 2 ulp; off = none")
     return p.parse_args(argv)
 
 

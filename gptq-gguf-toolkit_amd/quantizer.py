@@ -30,7 +30,7 @@ import torch.nn as nn
 from . import dist_utils
 from . import ops as _ops
 from .block_schedule import BlockSchedule
-from .forward_fused import fused_forward
+from .forward_fused import fused_forward, level_of
 from .gptq import GPTQ
 from .model_utils import ForwardInterrupt, InputCollector, LINEAR_LAYERS, _to, select_layers
 from .quant_utils import GGML_QUANT_SIZES, GGMLQuantizationType, dequantize_linear_weight
@@ -504,7 +504,7 @@ class Quantizer:
                  block_modules: str, save_dir: str, quant_non_block_modules: bool = False,
                  device: Optional[torch.device] = None, cpu_offload_modules: bool = False,
                  cpu_offload_activations: bool = False, verbose: bool = False, non_block_fp32: bool = False,
-                 calibration_batch: int = 1, fused_forward: bool = False) -> None:
+                 calibration_batch: int = 1, fused_forward="exact") -> None:
         self.model = model
         self.data_loader = data_loader
         self.quantizable_modules = quantizable_modules
@@ -523,9 +523,11 @@ class Quantizer:
         # per block forward.  Same Hessians in exact arithmetic (GPTQ.update weighs a batch by its size,
         # gptq.py:86-112); one Llama-3-8B layer forward takes 0.91 instead of 1.16 ms per sequence at 4.
         self.calibration_batch = max(1, int(calibration_batch))
-        # beyond the reference: RMSNorm / rotary embedding / SwiGLU of the block forward as one HIP kernel each
-        # (forward_fused.py); the reference and the default run the HF eager modules (quantizer.py:293).
-        self.fused_forward = bool(fused_forward)
+        # beyond the reference (which runs the HF eager modules, quantizer.py:293): HIP kernels for the elementwise
+        # modules of the block forward (forward_fused.py).  "exact" (default): rotary embedding and SwiGLU, bit-identical
+        # to HF eager -- the saved tensors do not change; "all" / True: RMSNorm too (<= 2 ulp); "off" / False: none.
+        # GQ_FUSED_FORWARD=off|exact|all overrides (A/B runs).
+        self.fused_forward = level_of(os.environ.get("GQ_FUSED_FORWARD", fused_forward))
 
     # ------------------------------------------------------------------ walk
     @torch.no_grad()
@@ -537,7 +539,7 @@ class Quantizer:
             self._saver.warm_up(device)
         self._saved_names: List[str] = []
         try:
-            with fused_forward(self.fused_forward) as patched:
+            with fused_forward(self.fused_forward if torch.device(device).type == "cuda" else "off") as patched:
                 self._fused_modules = patched
                 self._quantize(quant_config, device)
         finally:

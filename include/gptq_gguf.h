@@ -248,7 +248,7 @@ int gq_chol_gemm(float* Cmat, int64_t ldc, const float* A, int64_t lda, const fl
    stall the launches of the thread that runs the forward. */
 int gq_stage_to_host(void* host_dst, const void* src, int64_t nbytes, void* stream);
 
-/* SURVEY 8(f) row 2, opt-in (Quantizer(fused_forward=True)): the elementwise part of the calibration forward the
+/* SURVEY 8(f) row 2 (Quantizer(fused_forward="exact" | "all")): the elementwise part of the calibration forward the
    reference leaves to HF eager modules (quantizer.py:293 `block(inp_batch, **kwargs)`), one HBM pass each, fp32
    arithmetic rounded to `dtype` (GQ_F16 / GQ_BF16) after every torch op of the module it replaces:
      gq_fwd_rmsnorm   LlamaRMSNorm.forward:  out = weight * dtype(float(x) * rsqrt(mean(float(x)^2) + eps));  x [tokens, C], C % 8 == 0

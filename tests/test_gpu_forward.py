@@ -168,7 +168,7 @@ def test_quantizer_with_fused_forward(tmp_path):
                         fused_forward=fused)
         drv.quantize({k: T.Q4_K for k in ("q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj")})
         torch.cuda.synchronize()
-        assert bool(drv._fused_modules) == fused
+        assert bool(drv._fused_modules) == fused and drv.fused_forward == ("all" if fused else "off")
         trees[fused] = {n: p.detach().float().cpu() for n, p in model.named_parameters() if p.dim() == 2}
         files = sorted(os.path.relpath(os.path.join(d, f), save_dir) for d, _, fs in os.walk(save_dir) for f in fs)
         trees[(fused, "files")] = files
@@ -213,3 +213,41 @@ def test_other_families_under_the_patch(family):
             got = model(input_ids=ids, use_cache=False).logits.float()
     assert float((want - got).abs().max()) <= 0.03 * float(want.abs().max())
     assert float(((want - got) ** 2).mean().sqrt()) <= 3e-3 * float((want ** 2).mean().sqrt())
+
+
+def test_default_forward_level_saves_the_same_bytes_as_hf_eager(tmp_path):
+    """The Quantizer's default (fused_forward="exact": rotary embedding + SwiGLU kernels) against fused_forward=False on a
+    bf16 model: every saved tensor and every written-back weight is bit-identical -- the default changes no result."""
+    import hashlib
+    from make_golden_shim import tiny_calib, tiny_llama
+    from gptq_gguf_toolkit_amd.quant_utils import GGMLQuantizationType as T
+    from gptq_gguf_toolkit_amd.quantizer import Quantizer
+    digests = {}
+    for level in ("off", "exact"):
+        save_dir = str(tmp_path / level)
+        os.makedirs(save_dir)
+        model = tiny_llama(dtype=torch.bfloat16).cuda()
+        data = [([], {"input_ids": ids}) for ids in tiny_calib()]
+        kw = {} if level == "exact" else {"fused_forward": False}  # "exact" through the constructor's default
+        drv = Quantizer(model, data_loader=data, quantizable_modules=r".*layers.*((q|k|v|o|gate|up|down)_proj)$",
+                        quantizer_kwargs=dict(rel_damp=0.01, block_size=128, act_order=False, quant_scale="absmax",
+                                              static_groups=False, rmin=-1.0, rdelta=0.1, nstep=20, verbose=False),
+                        pre_block_modules=["model.embed_tokens"], block_modules="model.layers",
+                        post_block_modules=["lm_head"], quant_non_block_modules=True, device="cuda:0", save_dir=save_dir, **kw)
+        drv.quantize({k: T.Q4_K for k in ("q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj",
+                                          "embed_tokens", "lm_head")})
+        torch.cuda.synchronize()
+        assert drv.fused_forward == level
+        names = " ".join(drv._fused_modules)
+        assert (level == "off" and not names) or ("apply_rotary_pos_emb" in names and "LlamaMLP" in names and "RMSNorm" not in names)
+        h = hashlib.sha256()
+        for n, p in sorted(model.named_parameters()):
+            h.update(p.detach().cpu().contiguous().view(torch.uint8).numpy().tobytes())
+        for d, _, fs in sorted(os.walk(save_dir)):
+            for f in sorted(fs):
+                obj = torch.load(os.path.join(d, f))
+                for k in sorted(obj):
+                    v = obj[k]
+                    h.update(v.contiguous().view(torch.uint8).numpy().tobytes() if torch.is_tensor(v) else str(v).encode())
+        digests[level] = h.hexdigest()
+    assert digests["off"] == digests["exact"]

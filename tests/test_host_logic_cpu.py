@@ -984,3 +984,12 @@ def test_fused_forward_patch_targets_and_restore():
         with fused_forward():
             1 / 0
     assert M.LlamaRMSNorm.forward is orig[0]
+    # levels: "exact" (the Quantizer's default) leaves RMSNorm alone
+    from gptq_gguf_toolkit_amd.forward_fused import level_of
+    assert [level_of(v) for v in (None, False, "off", "0", True, "all", "exact")] == ["off"] * 4 + ["all"] * 2 + ["exact"]
+    with pytest.raises(ValueError):
+        level_of("fast")
+    with fused_forward("exact") as patched:
+        assert "LlamaMLP.forward" in patched and not any("RMSNorm" in p for p in patched)
+        assert M.LlamaRMSNorm.forward is orig[0] and M.apply_rotary_pos_emb is not orig[1]
+    assert (M.apply_rotary_pos_emb, M.LlamaMLP.forward) == orig[1:3]
