@@ -22,9 +22,9 @@ The same JSON line carries, measured AFTER the timed region:
   * `whole_model`: the drop-in pipeline end to end -- a random-init Llama-3-8B-shaped LlamaForCausalLM built on the
     GPU, 128 x 2048 synthetic ids, `Quantizer.quantize` (the region the reference times, quant.py:251-254: capture
     forward, forward #1 + H, solve + column loop, forward #2, RTN of embed/lm_head, data.pth saving) with its split;
-    (the Quantizer's default forward: HF modules with the two bit-exact HIP kernels, rotary embedding and SwiGLU);
-    `whole_model_fused` the same with --fused_forward (RMSNorm as a HIP kernel too, <= 2 ulp, opt-in), and both again
-    with --calibration_batch 4 (`whole_model_batch4`, `whole_model_batch4_fused`);
+    (the Quantizer's default forward: HF modules with the bit-exact HIP kernels -- rotary embedding, SwiGLU, RMSNorm in
+    ATen's summation order -- same saved bytes as plain HF eager); `whole_model_hf_eager` the same on plain HF eager
+    (--fused_forward off: the reference's forward); `whole_model_batch4` the default with --calibration_batch 4;
   * `trailing_update`: the north star's GEMM three ways (far launches alone, near + far alone, far launches inside
     the timed region);
   * `tolerance_parity`: GPU H -> U -> ints against the oracle's fp64 H -> fp64 U -> ints on the same inputs;
@@ -532,8 +532,9 @@ def whole_model_run(wl, dev, world, rank, save_root=None, nseq=None, L=None, lay
     out = {"model": f"random-init LlamaForCausalLM {cfg_kw['num_hidden_layers']} layers, hidden {cfg_kw['hidden_size']}, "
                     f"bf16, attn {os.environ.get('GQ_ATTN', 'sdpa')}; embed + lm_head RTN ({q}), all block Linears GPTQ ({q})",
            "forward": {"off": "HF eager modules (the reference's forward)",
-                       "exact": "HF modules with the bit-exact HIP kernels (rotary embedding, SwiGLU): same saved bytes as HF eager",
-                       "all": "HIP RMSNorm / rotary / SwiGLU kernels (--fused_forward; RMSNorm <= 2 ulp)"}[drv.fused_forward],
+                       "exact": "HF modules with the bit-exact HIP kernels (rotary embedding, SwiGLU, RMSNorm in ATen's "
+                                "summation order, verified at run time): same saved bytes as HF eager",
+                       "all": "as exact; RMSNorm through the free-order kernel (<= 2 ulp) where the ordered one is not verified"}[drv.fused_forward],
            "calib": f"{nseq}x{L} synthetic ids ({len(ids)} sequences on this rank), {calib_batch} per block forward"
                     + (" (the reference's cadence)" if calib_batch == 1 else " (--calibration_batch: same Hessian sums, fewer and larger GEMMs)"),
            "params_quantized_M": round(params / 1e6, 1),
@@ -757,8 +758,7 @@ def main():
         del layers, W16, X
         torch.cuda.empty_cache()
         wm = {}
-        for key, cb, fused in (("whole_model", 1, "exact"), ("whole_model_fused", 1, "all"), ("whole_model_batch4", 4, "exact"),
-                               ("whole_model_batch4_fused", 4, "all")):
+        for key, cb, fused in (("whole_model", 1, "exact"), ("whole_model_hf_eager", 1, "off"), ("whole_model_batch4", 4, "exact")):
             try:
                 wm[key] = whole_model_run(WORKLOADS["llama3-8b-model-q4k"], dev, world, rank, layers=args.layers, calib_batch=cb,
                                           fused=fused)

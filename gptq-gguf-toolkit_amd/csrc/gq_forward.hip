@@ -58,6 +58,112 @@ __global__ __launch_bounds__(256) void fwd_rmsnorm_kernel(const uint16_t* __rest
     }
 }
 
+// Correctly rounded 1 / sqrt(x) in fp32 (what torch.rsqrt returns on this stack: 0 differences in 4 M samples against the
+// double-precision value rounded once; v_rsq_f32 alone is a 1-ulp approximation).  The double-precision estimate rounded to
+// fp32 is right unless 1 / sqrt(x) lies within 2^-53 of a rounding boundary; the boundaries y -+ ulp / 2 are tested exactly:
+// (y +- h)^2 has <= 50 significant bits (exact in double), its product with x is taken as an unevaluated sum t + e (fma).
+__device__ __forceinline__ float rsqrt_rn(float x) {
+    float y = (float)(1.0 / sqrt((double)x));
+    if (!(x > 0.0f) || !(y > 0.0f) || y > 3.0e38f) return y;  // zero / negative / nan / overflow: nothing to repair
+    // product (m * m) * x compared with 1, exactly
+    auto above_one = [](double m, double xd) {  // m^2 x > 1 ?
+        const double p = m * m;                 // exact
+        const double t = p * xd, e = fma(p, xd, -t);
+        return t > 1.0 || (t == 1.0 && e > 0.0);
+    };
+    auto below_one = [](double m, double xd) {  // m^2 x < 1 ?
+        const double p = m * m;
+        const double t = p * xd, e = fma(p, xd, -t);
+        return t < 1.0 || (t == 1.0 && e < 0.0);
+    };
+    const float up = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, y) + 1u);
+    const float dn = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, y) - 1u);
+    const double hi = 0.5 * ((double)y + (double)up), lo = 0.5 * ((double)y + (double)dn);  // the rounding boundaries
+    // 1 / sqrt(x) > hi  <=>  hi^2 x < 1: the neighbour above is closer; 1 / sqrt(x) < lo  <=>  lo^2 x > 1: the one below
+    // (on a boundary exactly -- impossible for 1 / sqrt of a float other than a power of four -- y stays)
+    if (below_one(hi, (double)x)) return up;
+    if (above_one(lo, (double)x)) return dn;
+    return y;
+}
+
+// The same module with the statistics summed in the order ATen's reduce kernel uses for mean(-1) of a contiguous fp32
+// [rows >= 8, C] tensor on a 64-wide wavefront (aten/src/ATen/native/cuda/Reduce.cuh; confirmed by emulating the order
+// with torch ops, profiles/aten_mean_order_probe.py):
+//   C / 64 < 128 (C <= 5120 ...): 64 lanes per row; lane x adds the squares of elements (x + 64 it) 4 + j, it = 0, 1, ...,
+//     into FOUR accumulators j = 0..3 (vectorised loads), folds them as ((a0 + a1) + a2) + a3, then the lanes are folded
+//     with shuffle-down offsets 1, 2, 4, ..., 32;
+//   C / 64 >= 128 (C >= 8192): the row is also split over 8 wavefronts: thread (x, y) takes elements
+//     (x + 64 y + 512 it) 4 + j; every wavefront folds its lanes as above, then the eight wavefront sums are combined with
+//     offsets 4, 2, 1 (y += y + offset) -- found by searching the order space (profiles/aten_mean_order_probe2.py).
+// The mean is the sum times fl(rows / (rows C)).  With that order and rsqrt_rn the output is bit-identical to HF eager's
+// -- which the Python side VERIFIES on the first call of every (C, dtype) before it trusts this kernel
+// (forward_fused.py); a PyTorch that reduces in another order simply keeps the eager module.  C % 512 == 0.
+template <bool BF16>
+__device__ __forceinline__ void rmsnorm_apply_row(const uint16_t* __restrict__ xr, const uint16_t* __restrict__ w,
+                                                  uint16_t* __restrict__ outr, int64_t C, float r, int t0, int nt) {
+    for (int64_t c = 8 * (int64_t)t0; c < C; c += 8 * (int64_t)nt) {
+        const uint4 v = *reinterpret_cast<const uint4*>(xr + c), wv = *reinterpret_cast<const uint4*>(w + c);
+        const uint32_t u[4] = {v.x, v.y, v.z, v.w}, ww[4] = {wv.x, wv.y, wv.z, wv.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float h0 = ld16<BF16>(st16<BF16>(ld16<BF16>((uint16_t)(u[e] & 0xffff)) * r));
+            const float h1 = ld16<BF16>(st16<BF16>(ld16<BF16>((uint16_t)(u[e] >> 16)) * r));
+            const uint16_t o0 = st16<BF16>(ld16<BF16>((uint16_t)(ww[e] & 0xffff)) * h0);
+            const uint16_t o1 = st16<BF16>(ld16<BF16>((uint16_t)(ww[e] >> 16)) * h1);
+            o[e] = (uint32_t)o0 | ((uint32_t)o1 << 16);
+        }
+        *reinterpret_cast<uint4*>(outr + c) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+template <bool BF16>
+__device__ __forceinline__ float rmsnorm_thread_sum(const uint16_t* __restrict__ xr, int64_t C, int t0, int nt) {
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    for (int64_t c = 4 * (int64_t)t0; c < C; c += 4 * (int64_t)nt) {
+        const uint2 v = *reinterpret_cast<const uint2*>(xr + c);
+        const float f0 = ld16<BF16>((uint16_t)(v.x & 0xffff)), f1 = ld16<BF16>((uint16_t)(v.x >> 16));
+        const float f2 = ld16<BF16>((uint16_t)(v.y & 0xffff)), f3 = ld16<BF16>((uint16_t)(v.y >> 16));
+        a0 = a0 + f0 * f0;  // pow(2) rounds the square to fp32, the reduction adds it: two roundings (-ffp-contract=off)
+        a1 = a1 + f1 * f1;
+        a2 = a2 + f2 * f2;
+        a3 = a3 + f3 * f3;
+    }
+    return ((a0 + a1) + a2) + a3;
+}
+// SPLIT = false: one wavefront per row, four rows per workgroup of 256;  true: one row per workgroup of 512
+template <bool BF16, bool SPLIT>
+__global__ __launch_bounds__(SPLIT ? 512 : 256) void fwd_rmsnorm_ordered_kernel(const uint16_t* __restrict__ x,
+                                                                                const uint16_t* __restrict__ w,
+                                                                                uint16_t* __restrict__ out, int64_t rows,
+                                                                                int64_t C, float eps, float factor) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    __shared__ float part[8];
+    __shared__ float rr;
+    if constexpr (!SPLIT) {
+        const int64_t row = (int64_t)blockIdx.x * 4 + wid;
+        if (row >= rows) return;
+        float s = rmsnorm_thread_sum<BF16>(x + row * C, C, lane, 64);
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) s = s + __shfl_down(s, o);
+        const float r = rsqrt_rn(__shfl(s, 0) * factor + eps);
+        rmsnorm_apply_row<BF16>(x + row * C, w, out + row * C, C, r, lane, 64);
+    } else {
+        const int64_t row = blockIdx.x;
+        float s = rmsnorm_thread_sum<BF16>(x + row * C, C, (int)threadIdx.x, 512);
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) s = s + __shfl_down(s, o);
+        if (lane == 0) part[wid] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {  // the eight wavefront sums: offsets 4, 2, 1
+            const float v0 = part[0] + part[4], v1 = part[1] + part[5], v2 = part[2] + part[6], v3 = part[3] + part[7];
+            const float u0 = v0 + v2, u1 = v1 + v3;
+            rr = rsqrt_rn((u0 + u1) * factor + eps);
+        }
+        __syncthreads();
+        rmsnorm_apply_row<BF16>(x + row * C, w, out + row * C, C, rr, (int)threadIdx.x, 512);
+    }
+}
+
 // x: [tokens, heads, D] (the memory layout of q_proj(x).view(B, L, H, D)); cos / sin: [tokens, D]; D % 16 == 0.
 // thread = 8 consecutive d of the first half of one (token, head) and their partners in the second half
 template <bool BF16>
@@ -131,6 +237,22 @@ int fwd_rmsnorm(const void* x, const void* w, void* out, int64_t T, int64_t C, f
     if (dtype != GQ_F16 && dtype != GQ_BF16) GQ_FAIL(GQ_E_BAD_TYPE, "gq_fwd_rmsnorm: dtype %d (fp16 / bf16)", dtype);
     if (dtype == GQ_BF16) hipLaunchKernelGGL(fwd_rmsnorm_kernel<true>, dim3((unsigned)T), dim3(256), 0, st, (const uint16_t*)x, (const uint16_t*)w, (uint16_t*)out, C, eps);
     else hipLaunchKernelGGL(fwd_rmsnorm_kernel<false>, dim3((unsigned)T), dim3(256), 0, st, (const uint16_t*)x, (const uint16_t*)w, (uint16_t*)out, C, eps);
+    GQ_LAUNCH_CHECK();
+    return GQ_OK;
+}
+int fwd_rmsnorm_ordered(const void* x, const void* w, void* out, int64_t T, int64_t C, float eps, int dtype, hipStream_t st) {
+    if (!x || !w || !out) GQ_FAIL(GQ_E_NULL, "gq_fwd_rmsnorm_ordered: null pointer");
+    if (T <= 0 || C <= 0 || C % 512 || !al16(x) || !al16(w) || !al16(out))
+        GQ_FAIL(GQ_E_BAD_SHAPE, "gq_fwd_rmsnorm_ordered: T=%ld C=%ld (C %% 512, 16-byte alignment)", (long)T, (long)C);
+    if (dtype != GQ_F16 && dtype != GQ_BF16) GQ_FAIL(GQ_E_BAD_TYPE, "gq_fwd_rmsnorm_ordered: dtype %d (fp16 / bf16)", dtype);
+    const float factor = (float)T / (float)(T * C);  // ATen's mean: float(outputs) / inputs
+    const bool split = C / 64 >= 128;                 // Reduce.cuh: values per thread >= block height (8) x 16
+    const dim3 grid((unsigned)(split ? T : (T + 3) / 4)), block(split ? 512 : 256);
+#define GQ_RN_LAUNCH(B16, SP) \
+    hipLaunchKernelGGL((fwd_rmsnorm_ordered_kernel<B16, SP>), grid, block, 0, st, (const uint16_t*)x, (const uint16_t*)w, (uint16_t*)out, T, C, eps, factor)
+    if (dtype == GQ_BF16) { if (split) GQ_RN_LAUNCH(true, true); else GQ_RN_LAUNCH(true, false); }
+    else { if (split) GQ_RN_LAUNCH(false, true); else GQ_RN_LAUNCH(false, false); }
+#undef GQ_RN_LAUNCH
     GQ_LAUNCH_CHECK();
     return GQ_OK;
 }

@@ -13,10 +13,13 @@ The Linear modules are still called through `nn.Module.__call__`, so the Hessian
 family is patched only when the source text of its module matches Llama's (Mistral, Qwen2 ... copy it verbatim), and
 every patched function falls back to the original for inputs the kernels do not take (fp32, non-contiguous, odd
 sizes, CPU tensors) -- the originals are torch code, not a CPU restatement of ours.  Levels (`level_of`): "exact"
--- the Quantizer's default -- installs only the rotary embedding and SwiGLU kernels, which are bit-identical to HF
-eager (tests/test_gpu_forward.py: torch.equal, every finite 16-bit gate value included; a Quantizer run with them
-saves the same bytes as one without); "all" adds RMSNorm, whose outputs equal HF eager's up to the summation order
-of the mean (<= 2 ulp on < 0.1 % of the elements) and is therefore opt-in (`--fused_forward`); "off" patches nothing.
+-- the Quantizer's default -- installs only kernels that are bit-identical to HF eager: the rotary embedding and SwiGLU
+(tests/test_gpu_forward.py: torch.equal, every finite 16-bit gate value included), and RMSNorm through
+gq_fwd_rmsnorm_ordered, which sums mean(x^2) in the order of ATen's reduce kernel and rounds rsqrt the way torch.rsqrt
+does -- trusted only after it has reproduced the eager module bit for bit on the first real input of each
+(hidden size, dtype); a Quantizer run at this level saves the same bytes as one on plain HF eager.  "all" also uses
+the free-order RMSNorm kernel (<= 2 ulp on < 0.1 % of the elements) where the ordered one is not verified; "off"
+patches nothing.
 """
 from __future__ import annotations
 
@@ -47,14 +50,35 @@ def _body(fn) -> str:
     return "\n".join(ln for ln in text.splitlines() if ln.strip())
 
 
-def _rmsnorm_forward(orig):
+_norm_verdict = {}  # (C, dtype) -> True: the ordered kernel reproduced the eager module bit for bit on first use
+
+
+def _rmsnorm_forward(orig, allow_free_order: bool):
+    """LlamaRMSNorm.forward through gq_fwd_rmsnorm_ordered -- mean(x^2) summed in ATen's order, torch.rsqrt's rounding --
+    once that kernel has reproduced the eager module BIT FOR BIT on the first real input of its (hidden size, dtype)
+    (a whole [tokens, C] tensor: a different summation order would show on the first few rows).  Not verified (another
+    PyTorch build, an unusual shape): the eager module stays -- or, with allow_free_order (level "all"), the
+    free-order kernel (<= 2 ulp)."""
     def forward(self, hidden_states):
         w = self.weight
-        if (hidden_states.is_cuda and hidden_states.dtype in _16BIT and w.dtype == hidden_states.dtype
-                and hidden_states.is_contiguous() and w.is_contiguous() and hidden_states.shape[-1] % 8 == 0
-                and hidden_states.numel() > 0 and not torch.is_grad_enabled()):
-            return ops.fwd_rmsnorm(hidden_states, w, self.variance_epsilon)
-        return orig(self, hidden_states)
+        x = hidden_states
+        if not (x.is_cuda and x.dtype in _16BIT and w.dtype == x.dtype and x.is_contiguous() and w.is_contiguous()
+                and x.numel() > 0 and not torch.is_grad_enabled()):
+            return orig(self, x)
+        C = x.shape[-1]
+        key = (C, x.dtype)
+        if C % 512 == 0 and x.numel() // C >= 8:
+            ok = _norm_verdict.get(key)
+            if ok is None:
+                want = orig(self, x)
+                got = ops.fwd_rmsnorm_ordered(x, w, self.variance_epsilon)
+                _norm_verdict[key] = bool(torch.equal(want, got))
+                return want
+            if ok:
+                return ops.fwd_rmsnorm_ordered(x, w, self.variance_epsilon)
+        if allow_free_order and C % 8 == 0:
+            return ops.fwd_rmsnorm(x, w, self.variance_epsilon)
+        return orig(self, x)
     return forward
 
 
@@ -90,9 +114,9 @@ def _mlp_forward(orig):
     return forward
 
 
-def _targets(with_norm: bool = True) -> List[Tuple[object, str, object]]:
-    """(owner, attribute, replacement) for every installed family whose module text equals Llama's.  with_norm=False:
-    only the two replacements that are bit-exact against HF eager (rotary embedding, SwiGLU)."""
+def _targets(free_order_norm: bool = True) -> List[Tuple[object, str, object]]:
+    """(owner, attribute, replacement) for every installed family whose module text equals Llama's.  free_order_norm:
+    RMSNorm may fall back to the free-order kernel where the ordered one is not verified (level "all")."""
     from transformers.models.llama import modeling_llama as ref
     want_norm, want_rope, want_mlp = _body(ref.LlamaRMSNorm.forward), _body(ref.apply_rotary_pos_emb), _body(ref.LlamaMLP.forward)
     out = []
@@ -105,8 +129,8 @@ def _targets(with_norm: bool = True) -> List[Tuple[object, str, object]]:
             if not inspect.isclass(cls) or getattr(cls, "__module__", None) != mod.__name__:
                 continue
             try:
-                if with_norm and name.endswith("RMSNorm") and _body(cls.forward) == want_norm:
-                    out.append((cls, "forward", _rmsnorm_forward(cls.forward)))
+                if name.endswith("RMSNorm") and _body(cls.forward) == want_norm:
+                    out.append((cls, "forward", _rmsnorm_forward(cls.forward, free_order_norm)))
                 elif name.endswith("MLP") and _body(cls.forward) == want_mlp:
                     out.append((cls, "forward", _mlp_forward(cls.forward)))
             except (OSError, TypeError):
@@ -121,8 +145,9 @@ def _targets(with_norm: bool = True) -> List[Tuple[object, str, object]]:
 
 
 def level_of(flag) -> str:
-    """Normalise the Quantizer's `fused_forward` argument: "off" (False / None / "off" / "0"), "exact" (only the
-    bit-exact kernels: rotary embedding and SwiGLU) or "all" (True / "all" / "1": RMSNorm as well, <= 2 ulp)."""
+    """Normalise the Quantizer's `fused_forward` argument: "off" (False / None / "off" / "0"), "exact" (bit-exact
+    kernels only: rotary embedding, SwiGLU, and RMSNorm once verified on this PyTorch) or "all" (True / "all" / "1":
+    RMSNorm through the free-order kernel, <= 2 ulp, wherever the exact one is not verified)."""
     if flag is None or flag is False:
         return "off"
     if flag is True:
@@ -148,7 +173,7 @@ def fused_forward(enabled=True):
     ops.lib()  # fail loudly here, not in the middle of a forward
     saved = []
     try:
-        for owner, attr, new in _targets(with_norm=(level == "all")):
+        for owner, attr, new in _targets(free_order_norm=(level == "all")):
             saved.append((owner, attr, vars(owner)[attr] if attr in vars(owner) else getattr(owner, attr)))
             setattr(owner, attr, new)
         yield [f"{getattr(o, '__name__', o)}.{a}" for o, a, _ in saved]

@@ -395,6 +395,17 @@ def fwd_rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tens
     return out
 
 
+def fwd_rmsnorm_ordered(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
+    """fwd_rmsnorm with the statistics summed in ATen's order (gq_fwd_rmsnorm_ordered; C % 512 == 0)."""
+    _need_cuda(x, weight)
+    assert x.is_contiguous() and weight.is_contiguous() and weight.dtype == x.dtype and weight.numel() == x.shape[-1]
+    out = torch.empty_like(x)
+    C = x.shape[-1]
+    check(lib().gq_fwd_rmsnorm_ordered(_ptr(x), _ptr(weight), _ptr(out), x.numel() // C, C, float(eps), _DT[x.dtype],
+                                       _stream(x)), "gq_fwd_rmsnorm_ordered")
+    return out
+
+
 def fwd_rope(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:
     """apply_rotary_pos_emb on one projection (gq_fwd_rope): x [B, L, H, D] contiguous (q_proj(h).view(B, L, H, D)),
     cos / sin [B, L, D] contiguous, same dtype.  Returns [B, L, H, D]."""

@@ -76,8 +76,9 @@ def parse_args(argv=None):
                    help="run the embed/lm_head scale search in fp32 (the reference runs it in the model dtype)")
     p.add_argument("--fused_forward", nargs="?", const="all", default="exact", choices=["off", "exact", "all"],
                    help="HIP kernels for the elementwise modules of the calibration forward (the reference runs the HF "
-                        "eager modules): exact (default) = rotary embedding + SwiGLU, bit-identical to HF eager; all (or "
-                        "the bare flag) = RMSNorm too, <= 2 ulp; off = none")
+                        "eager modules): exact (default) = rotary embedding, SwiGLU and RMSNorm, bit-identical to HF eager "
+                        "(RMSNorm checked at run time); all (or the bare flag) = also the free-order RMSNorm kernel, "
+                        "<= 2 ulp, where the exact one is not verified; off = none")
     return p.parse_args(argv)
 
 

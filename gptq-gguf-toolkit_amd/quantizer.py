@@ -524,9 +524,10 @@ class Quantizer:
         # gptq.py:86-112); one Llama-3-8B layer forward takes 0.91 instead of 1.16 ms per sequence at 4.
         self.calibration_batch = max(1, int(calibration_batch))
         # beyond the reference (which runs the HF eager modules, quantizer.py:293): HIP kernels for the elementwise
-        # modules of the block forward (forward_fused.py).  "exact" (default): rotary embedding and SwiGLU, bit-identical
-        # to HF eager -- the saved tensors do not change; "all" / True: RMSNorm too (<= 2 ulp); "off" / False: none.
-        # GQ_FUSED_FORWARD=off|exact|all overrides (A/B runs).
+        # modules of the block forward (forward_fused.py).  "exact" (default): rotary embedding, SwiGLU and RMSNorm, each
+        # bit-identical to HF eager (RMSNorm verified at run time on this PyTorch before it is trusted) -- the saved
+        # tensors do not change; "all" / True: RMSNorm's free-order kernel (<= 2 ulp) where the exact one is not
+        # verified; "off" / False: none.  GQ_FUSED_FORWARD=off|exact|all overrides (A/B runs).
         self.fused_forward = level_of(os.environ.get("GQ_FUSED_FORWARD", fused_forward))
 
     # ------------------------------------------------------------------ walk

@@ -257,6 +257,11 @@ int gq_stage_to_host(void* host_dst, const void* src, int64_t nbytes, void* stre
      gq_fwd_silu_mul  LlamaMLP.forward's act_fn(gate) * up over n elements, n % 8 == 0
    All pointers 16-byte aligned, tensors contiguous, out does not overlap an input. */
 int gq_fwd_rmsnorm(const void* x, const void* weight, void* out, int64_t tokens, int64_t C, float eps, int dtype, void* stream);
+/* gq_fwd_rmsnorm with mean(x^2) summed in the order of ATen's reduce kernel on a 64-wide wavefront (C % 512 == 0): bit-identical
+   to the eager module on the PyTorch this was written against; the Python host verifies that on first use per (C, dtype)
+   and keeps the eager module otherwise. */
+int gq_fwd_rmsnorm_ordered(const void* x, const void* weight, void* out, int64_t tokens, int64_t C, float eps, int dtype,
+                           void* stream);
 int gq_fwd_rope(const void* x, const void* cos_, const void* sin_, void* out, int64_t tokens, int heads, int head_dim, int dtype,
                 void* stream);
 int gq_fwd_silu_mul(const void* gate, const void* up, void* out, int64_t n, int dtype, void* stream);

@@ -215,18 +215,31 @@ def test_other_families_under_the_patch(family):
     assert float(((want - got) ** 2).mean().sqrt()) <= 3e-3 * float((want ** 2).mean().sqrt())
 
 
-def test_default_forward_level_saves_the_same_bytes_as_hf_eager(tmp_path):
-    """The Quantizer's default (fused_forward="exact": rotary embedding + SwiGLU kernels) against fused_forward=False on a
-    bf16 model: every saved tensor and every written-back weight is bit-identical -- the default changes no result."""
+def _llama512(dtype):
+    from transformers import LlamaConfig, LlamaForCausalLM
+    cfg = LlamaConfig(hidden_size=512, intermediate_size=1024, num_hidden_layers=2, num_attention_heads=4,
+                      num_key_value_heads=2, vocab_size=512, max_position_embeddings=128, rms_norm_eps=1e-5,
+                      tie_word_embeddings=False, attn_implementation="sdpa")
+    torch.manual_seed(0)
+    return LlamaForCausalLM(cfg).to(dtype).eval()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_default_forward_level_saves_the_same_bytes_as_hf_eager(tmp_path, dtype):
+    """The Quantizer's default (fused_forward="exact": rotary embedding, SwiGLU and the order-matched RMSNorm kernel) against
+    fused_forward=False on a 16-bit model: every saved tensor and every written-back weight is bit-identical -- the default
+    changes no result.  The RMSNorm kernel must have been verified and used (hidden size 512)."""
     import hashlib
-    from make_golden_shim import tiny_calib, tiny_llama
+    from make_golden_shim import tiny_calib
+    from gptq_gguf_toolkit_amd import forward_fused
     from gptq_gguf_toolkit_amd.quant_utils import GGMLQuantizationType as T
     from gptq_gguf_toolkit_amd.quantizer import Quantizer
+    forward_fused._norm_verdict.clear()
     digests = {}
     for level in ("off", "exact"):
         save_dir = str(tmp_path / level)
         os.makedirs(save_dir)
-        model = tiny_llama(dtype=torch.bfloat16).cuda()
+        model = _llama512(dtype).cuda()
         data = [([], {"input_ids": ids}) for ids in tiny_calib()]
         kw = {} if level == "exact" else {"fused_forward": False}  # "exact" through the constructor's default
         drv = Quantizer(model, data_loader=data, quantizable_modules=r".*layers.*((q|k|v|o|gate|up|down)_proj)$",
@@ -239,7 +252,7 @@ def test_default_forward_level_saves_the_same_bytes_as_hf_eager(tmp_path):
         torch.cuda.synchronize()
         assert drv.fused_forward == level
         names = " ".join(drv._fused_modules)
-        assert (level == "off" and not names) or ("apply_rotary_pos_emb" in names and "LlamaMLP" in names and "RMSNorm" not in names)
+        assert (level == "off" and not names) or all(k in names for k in ("apply_rotary_pos_emb", "LlamaMLP", "LlamaRMSNorm"))
         h = hashlib.sha256()
         for n, p in sorted(model.named_parameters()):
             h.update(p.detach().cpu().contiguous().view(torch.uint8).numpy().tobytes())
@@ -250,4 +263,26 @@ def test_default_forward_level_saves_the_same_bytes_as_hf_eager(tmp_path):
                     v = obj[k]
                     h.update(v.contiguous().view(torch.uint8).numpy().tobytes() if torch.is_tensor(v) else str(v).encode())
         digests[level] = h.hexdigest()
+    assert forward_fused._norm_verdict.get((512, dtype)) is True  # the ordered kernel matched HF eager and was used
     assert digests["off"] == digests["exact"]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(1, 2048, 4096), (4, 2048, 4096), (1, 2048, 2048), (1, 2048, 5120), (2, 1024, 8192),
+                                   (3, 77, 512), (2, 300, 14336), (1, 64, 3584), (1, 8, 7168)])
+def test_rmsnorm_ordered_is_bit_exact(dtype, shape):
+    """gq_fwd_rmsnorm_ordered against HF's LlamaRMSNorm: torch.equal (ATen's summation order for the mean, torch.rsqrt's
+    correct rounding).  If a PyTorch upgrade changes the reduction order this test fails -- and forward_fused's run-time
+    check keeps the eager module, so results stay right either way."""
+    from transformers.models.llama.modeling_llama import LlamaRMSNorm
+    from gptq_gguf_toolkit_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(9)
+    C = shape[-1]
+    x = (torch.randn(shape, device="cuda", generator=g) * torch.exp(torch.randn(C, device="cuda", generator=g))).to(dtype)
+    mod = LlamaRMSNorm(C, eps=1e-5).cuda().to(dtype)
+    with torch.no_grad():
+        mod.weight.copy_((1.0 + 0.2 * torch.randn(C, device="cuda", generator=g)).to(dtype))
+        want = mod(x)
+    assert torch.equal(ops.fwd_rmsnorm_ordered(x, mod.weight.data, 1e-5), want)
+    z = torch.zeros(8, C, device="cuda", dtype=dtype)  # all-zero rows: rsqrt(eps)
+    assert torch.equal(ops.fwd_rmsnorm_ordered(z, mod.weight.data, 1e-5), mod(z))
