@@ -91,7 +91,7 @@ def lib():
     L.gq_chol_gemm.argtypes = [vp, i64, vp, i64, vp, i64, i64, i64, i64, ci, ci, ci, ci, ci, vp, sz, vp]
     L.gq_stage_to_host.argtypes = [vp, vp, i64, vp]
     L.gq_fwd_rmsnorm.argtypes = [vp, vp, vp, i64, i64, cf, ci, vp]
-    L.gq_fwd_rmsnorm_ordered.argtypes = [vp, vp, vp, i64, i64, cf, ci, vp]
+    L.gq_fwd_rmsnorm_ordered.argtypes = [vp, vp, vp, i64, i64, cf, ci, vp, vp]
     L.gq_fwd_rope.argtypes = [vp, vp, vp, vp, i64, ci, ci, ci, vp]
     L.gq_fwd_silu_mul.argtypes = [vp, vp, vp, i64, ci, vp]
     L.gq_prof_enable.argtypes = [ctypes.c_uint]

@@ -40,7 +40,7 @@ size_t chol_gemm_workspace_bytes(int64_t, int64_t, int64_t);
 int chol_gemm(float*, int64_t, const float*, int64_t, const float*, int64_t, int64_t, int64_t, int64_t, int, int, int, int, int,
               void*, size_t, hipStream_t);
 int fwd_rmsnorm(const void*, const void*, void*, int64_t, int64_t, float, int, hipStream_t);
-int fwd_rmsnorm_ordered(const void*, const void*, void*, int64_t, int64_t, float, int, hipStream_t);
+int fwd_rmsnorm_ordered(const void*, const void*, void*, int64_t, int64_t, float, int, float*, hipStream_t);
 int fwd_rope(const void*, const void*, const void*, void*, int64_t, int, int, int, hipStream_t);
 int fwd_silu_mul(const void*, const void*, void*, int64_t, int, hipStream_t);
 }  // namespace gq
@@ -248,8 +248,8 @@ int gq_fwd_rmsnorm(const void* x, const void* weight, void* out, int64_t tokens,
     return fwd_rmsnorm(x, weight, out, tokens, C, eps, dtype, (hipStream_t)stream);
 }
 int gq_fwd_rmsnorm_ordered(const void* x, const void* weight, void* out, int64_t tokens, int64_t C, float eps, int dtype,
-                           void* stream) {
-    return fwd_rmsnorm_ordered(x, weight, out, tokens, C, eps, dtype, (hipStream_t)stream);
+                           float* stats, void* stream) {
+    return fwd_rmsnorm_ordered(x, weight, out, tokens, C, eps, dtype, stats, (hipStream_t)stream);
 }
 int gq_fwd_rope(const void* x, const void* cos_, const void* sin_, void* out, int64_t tokens, int heads, int head_dim, int dtype,
                 void* stream) {

@@ -135,7 +135,8 @@ template <bool BF16, bool SPLIT>
 __global__ __launch_bounds__(SPLIT ? 512 : 256) void fwd_rmsnorm_ordered_kernel(const uint16_t* __restrict__ x,
                                                                                 const uint16_t* __restrict__ w,
                                                                                 uint16_t* __restrict__ out, int64_t rows,
-                                                                                int64_t C, float eps, float factor) {
+                                                                                int64_t C, float eps, float factor,
+                                                                                float* __restrict__ stats) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     __shared__ float part[8];
     __shared__ float rr;
@@ -145,7 +146,12 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void fwd_rmsnorm_ordered_kernel(
         float s = rmsnorm_thread_sum<BF16>(x + row * C, C, lane, 64);
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) s = s + __shfl_down(s, o);
-        const float r = rsqrt_rn(__shfl(s, 0) * factor + eps);
+        const float var = __shfl(s, 0) * factor;
+        const float r = rsqrt_rn(var + eps);
+        if (stats && lane == 0) {
+            stats[2 * row] = var;
+            stats[2 * row + 1] = r;
+        }
         rmsnorm_apply_row<BF16>(x + row * C, w, out + row * C, C, r, lane, 64);
     } else {
         const int64_t row = blockIdx.x;
@@ -157,7 +163,12 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void fwd_rmsnorm_ordered_kernel(
         if (threadIdx.x == 0) {  // the eight wavefront sums: offsets 4, 2, 1
             const float v0 = part[0] + part[4], v1 = part[1] + part[5], v2 = part[2] + part[6], v3 = part[3] + part[7];
             const float u0 = v0 + v2, u1 = v1 + v3;
-            rr = rsqrt_rn((u0 + u1) * factor + eps);
+            const float var = (u0 + u1) * factor;
+            rr = rsqrt_rn(var + eps);
+            if (stats) {
+                stats[2 * row] = var;
+                stats[2 * row + 1] = rr;
+            }
         }
         __syncthreads();
         rmsnorm_apply_row<BF16>(x + row * C, w, out + row * C, C, rr, (int)threadIdx.x, 512);
@@ -240,7 +251,8 @@ int fwd_rmsnorm(const void* x, const void* w, void* out, int64_t T, int64_t C, f
     GQ_LAUNCH_CHECK();
     return GQ_OK;
 }
-int fwd_rmsnorm_ordered(const void* x, const void* w, void* out, int64_t T, int64_t C, float eps, int dtype, hipStream_t st) {
+int fwd_rmsnorm_ordered(const void* x, const void* w, void* out, int64_t T, int64_t C, float eps, int dtype, float* stats,
+                        hipStream_t st) {
     if (!x || !w || !out) GQ_FAIL(GQ_E_NULL, "gq_fwd_rmsnorm_ordered: null pointer");
     if (T <= 0 || C <= 0 || C % 512 || !al16(x) || !al16(w) || !al16(out))
         GQ_FAIL(GQ_E_BAD_SHAPE, "gq_fwd_rmsnorm_ordered: T=%ld C=%ld (C %% 512, 16-byte alignment)", (long)T, (long)C);
@@ -249,7 +261,7 @@ int fwd_rmsnorm_ordered(const void* x, const void* w, void* out, int64_t T, int6
     const bool split = C / 64 >= 128;                 // Reduce.cuh: values per thread >= block height (8) x 16
     const dim3 grid((unsigned)(split ? T : (T + 3) / 4)), block(split ? 512 : 256);
 #define GQ_RN_LAUNCH(B16, SP) \
-    hipLaunchKernelGGL((fwd_rmsnorm_ordered_kernel<B16, SP>), grid, block, 0, st, (const uint16_t*)x, (const uint16_t*)w, (uint16_t*)out, T, C, eps, factor)
+    hipLaunchKernelGGL((fwd_rmsnorm_ordered_kernel<B16, SP>), grid, block, 0, st, (const uint16_t*)x, (const uint16_t*)w, (uint16_t*)out, T, C, eps, factor, stats)
     if (dtype == GQ_BF16) { if (split) GQ_RN_LAUNCH(true, true); else GQ_RN_LAUNCH(true, false); }
     else { if (split) GQ_RN_LAUNCH(false, true); else GQ_RN_LAUNCH(false, false); }
 #undef GQ_RN_LAUNCH

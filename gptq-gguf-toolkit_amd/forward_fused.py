@@ -55,8 +55,9 @@ _norm_verdict = {}  # (C, dtype) -> True: the ordered kernel reproduced the eage
 
 def _rmsnorm_forward(orig, allow_free_order: bool):
     """LlamaRMSNorm.forward through gq_fwd_rmsnorm_ordered -- mean(x^2) summed in ATen's order, torch.rsqrt's rounding --
-    once that kernel has reproduced the eager module BIT FOR BIT on the first real input of its (hidden size, dtype)
-    (a whole [tokens, C] tensor: a different summation order would show on the first few rows).  Not verified (another
+    once that kernel has reproduced the eager module BIT FOR BIT on the first real input of its (hidden size, dtype):
+    the output and, row by row, the fp32 mean and rsqrt themselves (a different summation order shows in about half
+    of the rows' means, while the 16-bit outputs would hide most of it).  Not verified (another
     PyTorch build, an unusual shape): the eager module stays -- or, with allow_free_order (level "all"), the
     free-order kernel (<= 2 ulp)."""
     def forward(self, hidden_states):
@@ -70,9 +71,14 @@ def _rmsnorm_forward(orig, allow_free_order: bool):
         if C % 512 == 0 and x.numel() // C >= 8:
             ok = _norm_verdict.get(key)
             if ok is None:
+                # the outputs (rounded to 16 bits) would hide most order differences: the statistics themselves must agree,
+                # row by row, with what torch computes for the module's own expression
                 want = orig(self, x)
-                got = ops.fwd_rmsnorm_ordered(x, w, self.variance_epsilon)
-                _norm_verdict[key] = bool(torch.equal(want, got))
+                got, stats = ops.fwd_rmsnorm_ordered(x, w, self.variance_epsilon, want_stats=True)
+                var = x.to(torch.float32).pow(2).mean(-1, keepdim=True)
+                r = torch.rsqrt(var + self.variance_epsilon)
+                _norm_verdict[key] = bool(torch.equal(want, got) and torch.equal(stats[:, 0], var.reshape(-1))
+                                          and torch.equal(stats[:, 1], r.reshape(-1)))
                 return want
             if ok:
                 return ops.fwd_rmsnorm_ordered(x, w, self.variance_epsilon)

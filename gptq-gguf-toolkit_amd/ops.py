@@ -395,15 +395,17 @@ def fwd_rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tens
     return out
 
 
-def fwd_rmsnorm_ordered(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
-    """fwd_rmsnorm with the statistics summed in ATen's order (gq_fwd_rmsnorm_ordered; C % 512 == 0)."""
+def fwd_rmsnorm_ordered(x: torch.Tensor, weight: torch.Tensor, eps: float, want_stats: bool = False):
+    """fwd_rmsnorm with the statistics summed in ATen's order (gq_fwd_rmsnorm_ordered; C % 512 == 0).  want_stats: also
+    return fp32 [rows, 2] = (mean(x^2), rsqrt(mean + eps)) as the kernel computed them."""
     _need_cuda(x, weight)
     assert x.is_contiguous() and weight.is_contiguous() and weight.dtype == x.dtype and weight.numel() == x.shape[-1]
     out = torch.empty_like(x)
     C = x.shape[-1]
+    stats = torch.empty(x.numel() // C, 2, dtype=torch.float32, device=x.device) if want_stats else None
     check(lib().gq_fwd_rmsnorm_ordered(_ptr(x), _ptr(weight), _ptr(out), x.numel() // C, C, float(eps), _DT[x.dtype],
-                                       _stream(x)), "gq_fwd_rmsnorm_ordered")
-    return out
+                                       _ptr(stats), _stream(x)), "gq_fwd_rmsnorm_ordered")
+    return (out, stats) if want_stats else out
 
 
 def fwd_rope(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:

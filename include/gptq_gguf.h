@@ -259,9 +259,10 @@ int gq_stage_to_host(void* host_dst, const void* src, int64_t nbytes, void* stre
 int gq_fwd_rmsnorm(const void* x, const void* weight, void* out, int64_t tokens, int64_t C, float eps, int dtype, void* stream);
 /* gq_fwd_rmsnorm with mean(x^2) summed in the order of ATen's reduce kernel on a 64-wide wavefront (C % 512 == 0): bit-identical
    to the eager module on the PyTorch this was written against; the Python host verifies that on first use per (C, dtype)
-   and keeps the eager module otherwise. */
+   and keeps the eager module otherwise.  stats (optional, fp32 [tokens, 2]): the row's mean(x^2) and rsqrt(mean + eps) as
+   the kernel computed them -- what that verification compares with torch's own, bit for bit. */
 int gq_fwd_rmsnorm_ordered(const void* x, const void* weight, void* out, int64_t tokens, int64_t C, float eps, int dtype,
-                           void* stream);
+                           float* stats, void* stream);
 int gq_fwd_rope(const void* x, const void* cos_, const void* sin_, void* out, int64_t tokens, int heads, int head_dim, int dtype,
                 void* stream);
 int gq_fwd_silu_mul(const void* gate, const void* up, void* out, int64_t n, int dtype, void* stream);

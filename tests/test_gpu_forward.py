@@ -283,6 +283,9 @@ def test_rmsnorm_ordered_is_bit_exact(dtype, shape):
     with torch.no_grad():
         mod.weight.copy_((1.0 + 0.2 * torch.randn(C, device="cuda", generator=g)).to(dtype))
         want = mod(x)
-    assert torch.equal(ops.fwd_rmsnorm_ordered(x, mod.weight.data, 1e-5), want)
+    got, stats = ops.fwd_rmsnorm_ordered(x, mod.weight.data, 1e-5, want_stats=True)
+    assert torch.equal(got, want)
+    var = x.float().pow(2).mean(-1).reshape(-1)  # the fp32 statistics, bit for bit (the 16-bit outputs hide most differences)
+    assert torch.equal(stats[:, 0], var) and torch.equal(stats[:, 1], torch.rsqrt(var + 1e-5))
     z = torch.zeros(8, C, device="cuda", dtype=dtype)  # all-zero rows: rsqrt(eps)
     assert torch.equal(ops.fwd_rmsnorm_ordered(z, mod.weight.data, 1e-5), mod(z))
