@@ -1,13 +1,13 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
-timeout 900 python -m pytest tests -q -m gpu -x -k "gptq or golden or lookahead or step or trailing" 2>&1 | tail -4
+GQ_FAR_DMA=2 timeout 900 python -m pytest tests -q -m gpu -x -k "gptq or golden or lookahead or far_update" 2>&1 | tail -3
 cd /tmp && export TMPDIR=/tmp
-for v in 0 1; do
+for v in 0 1 2; do
   d=$R/gpurun_out/r3/far_dma_$v; mkdir -p $d
-  if [ $v = 0 ]; then export GQ_FAR_DMA=1; else unset GQ_FAR_DMA; fi
+  if [ $v = 0 ]; then unset GQ_FAR_DMA; else export GQ_FAR_DMA=$v; fi
   timeout 300 rocprofv3 --kernel-trace --output-format csv -d $d/p -o p -- python $R/profiles/near_probe.py > $d/log.txt 2>&1 || echo "pass failed"
-  python3 - $(find $d/p -name '*kernel_trace.csv' | head -1) "NO_DMA=$v" <<'PY'
+  python3 - $(find $d/p -name '*kernel_trace.csv' | head -1) "FAR_DMA=$v" <<'PY'
 import csv, sys
 t = n = 0
 for r in csv.DictReader(open(sys.argv[1])):

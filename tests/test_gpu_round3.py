@@ -260,14 +260,14 @@ print("HASH", h.hexdigest())
 def test_trailing_update_kernel_choices_are_bit_identical():
     """The column loop's trailing updates have three kernels that are selected per process (environment read once):
     the 64-tile near kernel with whole K = 256 panels in LDS (default) vs the 128-tile chained kernel
-    (GQ_NEAR64_MAXN=0), and the far update with DMA'd chunks (GQ_FAR_DMA=1, opt-in) vs register-staged chunks.  Every
+    (GQ_NEAR64_MAXN=0), and the far update with DMA'd chunks (GQ_FAR_DMA=1 / 2: four- / two-slot ring, opt-in) vs register-staged chunks.  Every
     output element is the same k-ordered chain in all of them: W and the quantized tensors hash identically."""
     import subprocess
     import sys
     from conftest import ROOT
     hashes = {}
     for tag, extra in (("default", {}), ("near128", {"GQ_NEAR64_MAXN": "0"}), ("far_dma", {"GQ_FAR_DMA": "1"}),
-                       ("classic", {"GQ_NEAR_CLASSIC": "1"})):
+                       ("far_dma_two_slots", {"GQ_FAR_DMA": "2"}), ("classic", {"GQ_NEAR_CLASSIC": "1"})):
         env = dict(os.environ, **extra)
         p = subprocess.run([sys.executable, "-c", _LOOP_HASH.format(root=ROOT)], env=env, capture_output=True, text=True,
                            timeout=600)
