@@ -408,6 +408,9 @@ __device__ __forceinline__ void g32_chain_full_tile(float* Cmat, int64_t ldc, co
     f32x2 fa0[4], fa1[4];  // [set]: A tile 0 / 1, k-steps (4g, 4g+2)
     float fb0[4], fb1[4];  // [set]: B at k-step 4g / 4g+2
     // reads of group g (0..7) of the image whose fragment bases are (pa0, pa1, pb) into set s
+#ifdef GQ_FAR_NOREADS  // timing probe: no fragment reads at all (MFMAs on whatever the registers hold)
+#define GQ_C_READS(g, s, pa0, pa1, pb) do { asm volatile("" : "+v"(fa0[s]), "+v"(fa1[s]), "+v"(fb0[s]), "+v"(fb1[s])); } while (0)
+#else
 #define GQ_C_READS(g, s, pa0, pa1, pb)                  \
     do {                                                \
         GQ_C_RD2(fa0[s], pa0, 4 * (g), 4 * (g) + 2);    \
@@ -415,6 +418,7 @@ __device__ __forceinline__ void g32_chain_full_tile(float* Cmat, int64_t ldc, co
         GQ_C_RD1(fb0[s], pb, (4 * (g)) * LDB * 4);      \
         GQ_C_RD1(fb1[s], pb, (4 * (g) + 2) * LDB * 4);  \
     } while (0)
+#endif
     fetch(0, va[0], vb[0]);
     commit(0, va[0], vb[0]);
     fetch(1, va[1], vb[1]);

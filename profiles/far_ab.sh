@@ -3,7 +3,7 @@
 # libraries built with -DGQ_FAR_NO*; results wrong, timing only)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
-for v in "" NOCOMMIT NOFETCH NOBARRIER NOCOMMITNOFETCHNOBARRIER; do
+for v in ${VARIANTS:-"" NOCOMMIT NOFETCH NOBARRIER NOCOMMITNOFETCHNOBARRIER MFMAONLY}; do
   d=$R/gpurun_out/r3/far_ab_$v; mkdir -p $d
   so=$R/gptq-gguf-toolkit_amd/csrc/libgptqgguf_hip.so; [ -n "$v" ] && so=$R/profiles/libgq_far_$v.so
   GQ_SO_PATH=$so timeout 300 rocprofv3 --kernel-trace --output-format csv -d $d/p -o p -- python $R/profiles/near_probe.py > $d/log.txt 2>&1 || echo "pass failed"
