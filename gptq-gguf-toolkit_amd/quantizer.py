@@ -592,17 +592,24 @@ class Quantizer:
             for _, m in pre_blocks:
                 m.cpu()
         ph.mark("rtn_pre")
-        # GQ_POST_BLOCKS_EARLY=1 (measured, off): quantize the post-block modules (lm_head) here instead of after the last
-        # block (quantizer.py:181-198) -- their RTN reads nothing the block loop writes, same tensors and files -- so that
-        # lm_head's data.pth (657 MB for Llama-3-8B: 0.6 s of torch.save) is written under the block loop: save tail
-        # 0.6 -> 0.3 s, but 2 of 5 runs then fell into the slow mode described at _Saver.put_many (+2.4 s), 0 of 9 without.
-        post_early = self.quant_non_block_modules and os.environ.get("GQ_POST_BLOCKS_EARLY") == "1"
+        # Where the post-block modules (lm_head) are quantized.  Their RTN reads nothing the block loop writes -- same tensors
+        # and files wherever it runs (a tied lm_head still sees embed_tokens' RTN first) -- but lm_head's data.pth (657 MB for
+        # Llama-3-8B: 0.6 s of clone + torch.save in the writer) is the tail of the run when it comes last, as in the
+        # reference (quantizer.py:181-198).  Default: right before the LAST block, so that the file is written under that
+        # block's work (save tail 0.65 -> 0.3 s).  GQ_POST_BLOCKS=last: the reference's place; =early: before the block loop
+        # (same gain; with two staging slots 2 of 5 such runs fell into the slow mode described at _Saver.put_many).
+        post_where = os.environ.get("GQ_POST_BLOCKS", "before_last_block") if self.quant_non_block_modules else "none"
+        post_early = post_where == "early"
         if post_early:
             for name, module in post_blocks:
                 self._quant_and_save_non_block(name, module.to(device), quant_config)
             ph.mark("rtn_post")
 
         for block_id, block in enumerate(blocks):
+            if post_where == "before_last_block" and block_id == len(blocks) - 1:
+                for name, module in post_blocks:
+                    self._quant_and_save_non_block(name, module.to(device), quant_config)
+                ph.mark("rtn_post")
             if self.verbose:
                 dist_utils.print_on_main(f"Processing {self.block_modules} {block_id}/{len(blocks)}.")
             block = block.to(device)
@@ -647,7 +654,7 @@ class Quantizer:
                       f"active {ms['active_bytes.all.current'] >> 20} MiB)", file=sys.stderr)
                 self._t_block = now
 
-        if self.quant_non_block_modules and not post_early:
+        if post_where == "last" or (post_where == "before_last_block" and len(blocks) == 0):
             for name, module in post_blocks:
                 self._quant_and_save_non_block(name, module.to(device), quant_config)
         if use_cache is not None:
