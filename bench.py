@@ -510,6 +510,12 @@ def whole_model_run(wl, dev, world, rank, save_root=None, nseq=None, L=None, lay
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        # one untimed forward of one calibration sequence: the first use of every GEMM shape loads its hipBLASLt code object
+        # (from a cold disk on a fresh box: +1.4 s in forward #1 of the first process, measured) -- warm-up, like the W steps
+        if os.environ.get("GQ_BENCH_WM_NO_WARMUP") != "1":
+            with torch.no_grad():
+                model(input_ids=ids[0].to(dev), use_cache=False)
+            torch.cuda.synchronize()
         wm_prof = os.environ.get("GQ_BENCH_WM_PROF")  # e.g. "syrk,transpose16": HIP-event time of those kernels in the run
         if wm_prof:
             _cabi.prof_enable(wm_prof.split(","))
@@ -541,7 +547,8 @@ def whole_model_run(wl, dev, world, rank, save_root=None, nseq=None, L=None, lay
            "wall_s_quantizer_region": round(wall, 2), "Mparams_per_s": round(params / wall / 1e6, 1),
            "split": dict(drv.timing, **({"kernel_ms_launches": prof_got} if wm_prof else {})), "schedule": getattr(drv, "schedule_stats", None), "model_build_s": round(t_build, 1),
            "data_pth": {"files": files, "GB": round(nbytes / 1e9, 2), "dir": root},
-           "region": "Quantizer.quantize (reference quant.py:251-254), model and ids resident on the GPU/host before it"}
+           "region": "Quantizer.quantize (reference quant.py:251-254), model and ids resident on the GPU/host before it, "
+                     "after one untimed forward of one sequence (GEMM code objects loaded)"}
     del drv, model
     torch.cuda.empty_cache()
     return out
