@@ -179,6 +179,7 @@ class _Saver:
         self.n_slots = max(2, int(os.environ.get("GQ_SAVE_SLOTS", 3)))
         self._ready = threading.Event()
         self._poll_lock = threading.Lock()
+        self._pinned_ids = set()
         self.slot_bytes = int(os.environ.get("GQ_SAVE_SLOT_MB", 704)) << 20  # embed_tokens of Llama-3 in Q4_K: 657 MB
 
     def _start_process(self):
@@ -195,22 +196,31 @@ class _Saver:
         if free < need:
             raise OSError(f"/dev/shm has {free >> 20} MiB free, the writer process needs {need >> 20} MiB "
                           f"(GQ_SAVE_SLOT_MB={self.slot_bytes >> 20})")
-        self.slots = [torch.empty(self.slot_bytes, dtype=torch.uint8).share_memory_() for _ in range(self.n_slots)]
+        # slots: shared-memory storages created as such (share_memory_() on an ordinary tensor would copy 704 MB each);
+        # nothing touches their pages until they are pinned
+        def new_slot():
+            try:
+                return torch.empty(0, dtype=torch.uint8).set_(torch.UntypedStorage._new_shared(self.slot_bytes))
+            except Exception:
+                return torch.empty(self.slot_bytes, dtype=torch.uint8).share_memory_()
+        self.slots = [new_slot() for _ in range(self.n_slots)]
         self._registered = []
-        for t in self.slots:  # pin the shared pages: device-to-host copies into them are plain DMA
+        self._pinned_ids = set()
+        self.inbox, self.outbox, self.freeq = ctx.Queue(), ctx.Queue(), ctx.Queue()
+        self.proc = ctx.Process(target=_writer_process, args=(self.save_dir, self.slots, self.inbox, self.freeq, self.outbox),
+                                daemon=True)
+        self.proc.start()  # the child imports torch while the slots are pinned here
+        for sid, t in enumerate(self.slots):  # pin the shared pages: the copy kernels write through their device mapping
             try:
                 if int(torch.cuda.cudart().cudaHostRegister(t.data_ptr(), t.numel(), 0)) == 0:
                     self._registered.append(t)
+                    self._pinned_ids.add(sid)
+                else:
+                    self._kernel_copy = False  # an unpinned slot has no device mapping: hipMemcpyAsync stages it
             except Exception:
-                pass
-        if len(self._registered) != len(self.slots):
-            self._kernel_copy = False  # an unpinned slot has no device mapping: hipMemcpyAsync stages it
-        self.inbox, self.outbox, self.freeq = ctx.Queue(), ctx.Queue(), ctx.Queue()
-        for sid in range(len(self.slots)):
+                self._kernel_copy = False
             self.freeq.put(sid)
-        self.proc = ctx.Process(target=_writer_process, args=(self.save_dir, self.slots, self.inbox, self.freeq, self.outbox),
-                                daemon=True)
-        self.proc.start()
+            self._ready.set()  # the first slot is enough to start with (embed_tokens); the others follow
 
     def _loop(self):
         stream = None
@@ -378,7 +388,10 @@ class _Saver:
                         layout, off = _layout_of(tensors, off)
                         modules.append((name, int(q_type), layout))
                         for v, t in zip(_slot_views(self.slots[sid], layout), tensors):
-                            _ops.stage_to_host(v, t.contiguous(), cur)
+                            if sid in self._pinned_ids:
+                                _ops.stage_to_host(v, t.contiguous(), cur)
+                            else:  # a slot that could not be pinned has no device mapping
+                                v.copy_(t.contiguous(), non_blocking=True)
                     ev = torch.cuda.Event()
                     ev.record(cur)
                     self.q.put(("staged", sid, modules, ev))
