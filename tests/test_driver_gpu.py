@@ -203,3 +203,41 @@ def test_saver_groups_oversize_and_slot_waits(tmp_path, monkeypatch):
         assert got["q_type"] == 12 and torch.equal(got["qweight"], q) and torch.equal(got["super_group_scale"], d)
         assert torch.equal(got["group_scale_quant"], s_) and torch.equal(got["super_group_zero"], dm)
         assert torch.equal(got["group_zero_quant"], m)
+
+
+def test_post_block_placement_changes_nothing(tmp_path, monkeypatch):
+    """lm_head is quantized before the last block by default (its file is written under that block's work); the reference
+    does it after the last block (quantizer.py:181-198).  Every placement saves the same bytes and leaves the same weights."""
+    import hashlib
+    from make_golden_shim import MIXED, tiny_calib, tiny_llama
+    from gptq_gguf_toolkit_amd.quant_utils import GGMLQuantizationType as T
+    from gptq_gguf_toolkit_amd.quantizer import Quantizer
+    digests = {}
+    for where in ("last", "before_last_block", "early"):
+        monkeypatch.setenv("GQ_POST_BLOCKS", where)
+        save_dir = str(tmp_path / where)
+        os.makedirs(save_dir)
+        model = tiny_llama().cuda()
+        data = [([], {"input_ids": ids}) for ids in tiny_calib()]
+        drv = Quantizer(model, data_loader=data, quantizable_modules=r".*layers.*((q|k|v|o|gate|up|down)_proj)$",
+                        quantizer_kwargs=dict(rel_damp=0.01, block_size=128, act_order=False, quant_scale="absmax",
+                                              static_groups=False, rmin=-1.0, rdelta=0.1, nstep=20, verbose=False),
+                        pre_block_modules=["model.embed_tokens"], block_modules="model.layers",
+                        post_block_modules=["lm_head"], quant_non_block_modules=True, device="cuda:0", save_dir=save_dir)
+        drv.quantize({k: T[v] for k, v in MIXED.items()})
+        torch.cuda.synchronize()
+        h = hashlib.sha256()
+        for n, p in sorted(model.named_parameters()):
+            h.update(p.detach().cpu().contiguous().view(torch.uint8).numpy().tobytes())
+        files = 0
+        for d, _, fs in sorted(os.walk(save_dir)):
+            for f in sorted(fs):
+                files += 1
+                obj = torch.load(os.path.join(d, f))
+                h.update(os.path.relpath(d, save_dir).encode())
+                for k in sorted(obj):
+                    v = obj[k]
+                    h.update(v.contiguous().view(torch.uint8).numpy().tobytes() if torch.is_tensor(v) else str(v).encode())
+        assert files == 16  # 2 blocks x 7 Linears + embed_tokens + lm_head
+        digests[where] = h.hexdigest()
+    assert len(set(digests.values())) == 1, digests
