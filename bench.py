@@ -27,7 +27,8 @@ The same JSON line carries, measured AFTER the timed region:
     (--fused_forward off: the reference's forward); `whole_model_batch4` the default with --calibration_batch 4;
   * `trailing_update`: the north star's GEMM three ways (far launches alone, near + far alone, far launches inside
     the timed region);
-  * `tolerance_parity`: GPU H -> U -> ints against the oracle's fp64 H -> fp64 U -> ints on the same inputs;
+  * `tolerance_parity` (k_proj, all rows) / `tolerance_parity_widest` (down_proj C = 14336, 128 rows): GPU H -> U -> ints
+    against fp64 H -> fp64 chain (on the GPU) -> the oracle's column loop on the same inputs;
   * `cpu_baseline`: the oracle's GPTQ.step on the host cores.
 
 Other workloads (`--workload`): tinyllama-block-q4k, llama3-8b-block-mixed (configs[2]), llama3-70b-block-q4k
@@ -288,20 +289,78 @@ def trailing_update_legs(wl, W16, X, in_region):
         return {"error": repr(e)}
 
 
-def tolerance_parity(wl, W16, X, n_seq=8):
+TYPE_SIZE = {10: 84, 11: 110, 12: 144, 13: 176, 14: 210}  # bytes per 256-value block
+PEAK_HBM_TBPS = 8.0
+
+
+def encoder_legs(wl, layers, W16, X, tu):
+    """SURVEY section 8(d)'s remaining figures (VERDICT r03 missing #4), from ONE more step of the same schedule after the
+    timed region with HIP events on the codec kernels' launch streams (the events cost ~4 us per launch on a chain of
+    ~170 launches, so they are kept out of the K timed steps; the other chains run next to them as in the region):
+      encoders     the HBM figure of the encoder side: sum over the block's Linears of R C (2 + 1 + type_size/256 + 2 + 4 C / R)
+                   bytes -- W fp16 in, ints out, packed out, dequantized fp16 out, U once -- (5.6 B/param + 4C/R for Q4_K)
+                   over the union of the launch intervals of scale_search* / gptq_segment / dequantize / pack (the column
+                   loop's own kernels are codec work: K4 + K5 + K7 + K9-13), and dequantize / pack alone with their own bytes
+                   (1 + 2 and 1 + type_size/256 per param);
+      column_loop  dependent column steps per second of the widest Linear's loop (alone on the GPU, as the product runs
+                   it: trailing_update.loop_ms.as_run) and the column-loop kernel's launch time per 128-column block."""
+    try:
+        tags = ["scale_search", "gptq_segment", "dequantize", "pack"]
+        _cabi.prof_enable(tags)
+        block_step(wl, layers, W16, X)
+        torch.cuda.synchronize()
+        got = _cabi.prof_collect(busy=True)
+        _cabi.prof_enable([])
+        shapes = wl["shapes"]
+        byts = sum(float(R) * C * (2 + 1 + TYPE_SIZE[int(q_of(wl, n))] / 256 + 2 + 4.0 * C / R) for n, (R, C, _) in shapes.items())
+        params = sum(float(R) * C for R, C, _ in shapes.values())
+        tot_ms = sum(got[t][0] for t in tags if t in got)  # sum of launch durations (chains overlap: not a wall time)
+        enc = {"bound": "hbm", "peak": PEAK_HBM_TBPS, "unit": "TB/s",
+               "bytes_per_param": round(byts / params, 3), "GB_per_step": round(byts / 1e9, 3),
+               "kernel_ms_per_step": {t: round(got[t][0], 3) for t in tags if t in got},
+               "launches": {t: got[t][1] for t in tags if t in got},
+               "achieved": round(byts / (tot_ms * 1e-3) / 1e12, 4) if tot_ms else None,
+               "frac": round(byts / (tot_ms * 1e-3) / 1e12 / PEAK_HBM_TBPS, 5) if tot_ms else None,
+               "note": "sum of launch durations over the four chains; the column loop is latency-bound by C dependent steps "
+                       "(column_loop), not by these bytes"}
+        for t, per in (("dequantize", lambda n: 3.0), ("pack", lambda n: 1 + TYPE_SIZE[int(q_of(wl, n))] / 256)):
+            if t in got and got[t][0]:
+                b = sum(float(R) * C * per(n) for n, (R, C, _) in shapes.items())
+                a = b / (got[t][0] * 1e-3) / 1e12
+                enc[t] = {"achieved": round(a, 3), "frac": round(a / PEAK_HBM_TBPS, 4), "bytes_per_param": round(b / params, 4)}
+        name = max(shapes, key=lambda n: shapes[n][0] * shapes[n][1] * shapes[n][1])
+        R, C, _ = shapes[name]
+        col = {"linear": f"{name} {R}x{C}", "steps": C}
+        loop = (tu or {}).get("loop_ms", {}).get("as_run")
+        if loop:
+            col.update({"loop_ms_alone": loop, "steps_per_s": round(C / (loop * 1e-3), 0), "ns_per_step": round(loop * 1e6 / C, 1)})
+        if "gptq_segment" in got and got["gptq_segment"][1]:
+            col["segment_kernel_us_per_launch_in_step"] = round(got["gptq_segment"][0] * 1e3 / got["gptq_segment"][1], 2)
+            col["all_linears_steps_per_s_of_segment_kernel_time"] = round(
+                sum(C_ for _, C_, _ in shapes.values()) / (got["gptq_segment"][0] * 1e-3), 0)
+        return enc, col
+    except Exception as e:
+        return {"error": repr(e)}, {"error": repr(e)}
+
+
+def tolerance_parity(wl, W16, X, n_seq=8, widest=False, n_rows=None):
     """K1/K3 are tolerance-class (summation order).  End-to-end effect on the result, on one Linear: the GPU's
     H -> U -> ints against an fp64 H -> fp64 LAPACK Cholesky chain -> the oracle's column loop (BASELINE.md section
     3): share of differing ints and scale bytes, max |delta w_hat|.  `ulp_noise_floor` is the same comparison
     between two ORACLE runs whose U differ by a 1e-7 relative perturbation (less than one fp32 rounding): the
     column loop's error feedback amplifies any last-bit difference, so this is the rate two correct fp32
-    implementations differ by.  Bounded: `n_seq` calibration sequences, the k_proj rows."""
+    implementations differ by.  Bounded: `n_seq` calibration sequences; the k_proj rows, or -- `widest`: the Linear with
+    the widest input (down_proj, C = 14336: the only chain on which all three image levels of K3 run) -- `n_rows` rows
+    of it through the oracle.  The fp64 Hessian and chain run on the GPU (torch: hipBLAS / hipSOLVER); the checker's
+    column loop is the oracle's C restatement on the host."""
     try:
         from oracle import oracle as O
         shapes = wl["shapes"]
-        name = "k_proj" if "k_proj" in shapes else min(shapes, key=lambda n: shapes[n][0] * shapes[n][1])
+        if widest:
+            name = max(shapes, key=lambda n: (shapes[n][1], shapes[n][0]))
+        else:
+            name = "k_proj" if "k_proj" in shapes else min(shapes, key=lambda n: shapes[n][0] * shapes[n][1])
         R, C, inp = shapes[name]
-        if C > 4096:
-            return {"skipped": f"C = {C}: the fp64 chain on the host takes minutes"}
         q_type = int(q_of(wl, name))
         xs = torch.cat([x.reshape(-1, C) for x in X[inp][:n_seq]])
         Wf = W16[name].float()
@@ -310,37 +369,47 @@ def tolerance_parity(wl, W16, X, n_seq=8):
         Wg = Wf.clone()
         U, flag = ops.h_prepare(H.clone(), Wg, 0.01)
         q, d, s, dmin, m = ops.gptq_quantize(Wg, U, q_type, 128)
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
-        # fp64 reference on the HOST with torch (MKL): a few seconds
-        x64 = xs.double().cpu()
-        H64 = (2.0 / n_seq) * (x64.T @ x64)
-        h_err = float((H.double().cpu() - H64).abs().max() / H64.abs().max())
-        Hd = H64.clone()  # gptq.py:304-324 in fp64 (no dead channel / zero column in these inputs)
-        Hd.diagonal().add_(0.01 * Hd.diagonal().mean())
-        Uo = torch.linalg.cholesky(torch.cholesky_inverse(torch.linalg.cholesky(Hd)), upper=True).numpy()
-        Wo = Wf.cpu().numpy()
-        del Hd, x64
+        H64 = torch.zeros(C, C, device=Wf.device, dtype=torch.float64)
+        for i in range(0, xs.shape[0], 4096):  # bounded fp64 scratch
+            x64 = xs[i:i + 4096].double()
+            H64.addmm_(x64.T, x64, alpha=2.0 / n_seq)
+        del x64
+        h_err = float((H.double() - H64).abs().max() / H64.abs().max())
+        H64.diagonal().add_(0.01 * H64.diagonal().mean())  # gptq.py:304-324 in fp64 (no dead channel / zero column here)
+        L = torch.linalg.cholesky(H64)
+        del H64
+        Hi = torch.cholesky_inverse(L)
+        del L
+        Uo_d = torch.linalg.cholesky(Hi, upper=True)
+        del Hi
+        u_err = float((U.double() - Uo_d).abs().max() / Uo_d.abs().max())
+        Uo = Uo_d.cpu().numpy()
+        del Uo_d
+        rows = slice(0, R) if not n_rows or n_rows >= R else slice(R // 4, R // 4 + n_rows)
+        Wo = Wf[rows].cpu().numpy()
         U32 = Uo.astype(np.float32)
         Wd, oq, od, os_, odm, om = O.gptq_step(Wo, U32, q_type, block_size=128)
         rng = np.random.default_rng(0)
         Un = (Uo * (1.0 + 1e-7 * rng.standard_normal(Uo.shape))).astype(np.float32)
         _, nq, nd, ns, ndm, nm = O.gptq_step(Wo, Un, q_type, block_size=128)
         dt = time.perf_counter() - t0
-        bits = lambda t: t.cpu().view(torch.int16).numpy().view(np.uint16)  # noqa: E731
+        bits = lambda t: t[rows].cpu().view(torch.int16).numpy().view(np.uint16)  # noqa: E731
 
         def scale_rate(a, b):
             return float(np.concatenate([(x != y).ravel() for x, y in zip(a, b)]).mean())
 
-        return {"linear": f"{name} {R}x{C} {QT(q_type).name}", "tokens": int(xs.shape[0]),
-                "H_rel_err": h_err,
-                "U_rel_err": float(np.abs(U.cpu().numpy().astype(np.float64) - Uo).max() / np.abs(Uo).max()),
-                "ints_differ": float((q.cpu().numpy() != oq).mean()),
-                "scale_bytes_differ": scale_rate((bits(d), s.cpu().numpy(), bits(dmin), m.cpu().numpy()), (od, os_, odm, om)),
-                "max_abs_dw": float(np.abs(Wg.cpu().numpy() - Wd).max()),
+        return {"linear": f"{name} {R}x{C} {QT(q_type).name}", "rows_checked": int(rows.stop - rows.start),
+                "tokens": int(xs.shape[0]), "H_rel_err": h_err, "U_rel_err": u_err,
+                "ints_differ": float((q[rows].cpu().numpy() != oq).mean()),
+                "scale_bytes_differ": scale_rate((bits(d), s[rows].cpu().numpy(), bits(dmin), m[rows].cpu().numpy()),
+                                                 (od, os_, odm, om)),
+                "max_abs_dw": float(np.abs(Wg[rows].cpu().numpy() - Wd).max()),
                 "ulp_noise_floor": {"ints_differ": float((nq != oq).mean()),
                                     "scale_bytes_differ": scale_rate((nd, ns, ndm, nm), (od, os_, odm, om))},
                 "checker_s": round(dt, 1),
-                "vs": "fp64 H and fp64 Cholesky chain (torch on the host), the oracle's C restatement of GPTQ.step"}
+                "vs": "fp64 H and fp64 Cholesky chain (torch on the GPU), the oracle's C restatement of GPTQ.step on the host"}
     except Exception as e:
         return {"error": repr(e)}
 
@@ -754,8 +823,11 @@ def main():
             "wall_s_llama3_8b_32_blocks_extrapolated": round(dt / args.steps * 32, 2)
             if args.workload.startswith("llama3-8b") else None,
             "roofline": roof,
-            "trailing_update": trailing_update_legs(wl, W16, X, (far[0], far[1], far[2], args.steps)) if side else None,
+            "trailing_update": (tu := trailing_update_legs(wl, W16, X, (far[0], far[1], far[2], args.steps)) if side else None),
+            "encoders": (el := encoder_legs(wl, layers, W16, X, tu) if side else (None, None))[0],
+            "column_loop": el[1],
             "tolerance_parity": tolerance_parity(wl, W16, X) if side else None,
+            "tolerance_parity_widest": tolerance_parity(wl, W16, X, widest=True, n_rows=128) if side else None,
             "fast_obq": fast_obq_leg(wl, W16, X) if side else None,
             "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline(wl, W16, keep),
         }

@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.environ.get("GQ_SO_PATH") or os.path.join(CSRC, "libgptqgguf_hip.so")  # override: kernel A/B probes
 
+ABI_VERSION = 3  # include/gptq_gguf.h GQ_ABI_VERSION this binding was written against
 F32, F16, BF16 = 0, 1, 2
 WS_H_ACCUMULATE, WS_H_PREPARE, WS_GPTQ_QUANTIZE, WS_CHOL_GEMM = 1, 2, 3, 4
 
@@ -63,6 +64,9 @@ def lib():
     vp, i64, ci, cf, sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
     sp = ctypes.POINTER(Search)
     L.gq_abi_version.restype = ci
+    if L.gq_abi_version() != ABI_VERSION:  # a stale build (or GQ_SO_PATH) must fail here, not at a symbol lookup later
+        raise GQError(f"{SO_PATH} has ABI version {L.gq_abi_version()}, this package binds version {ABI_VERSION}: rebuild "
+                      f"(`make -C {CSRC}`)")
     L.gq_last_error.restype = ctypes.c_char_p
     L.gq_type_info.argtypes = [ci, ctypes.POINTER(TypeInfo)]
     L.gq_workspace_bytes.argtypes = [ci, i64, i64, i64, ci]

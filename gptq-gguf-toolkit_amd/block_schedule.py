@@ -46,6 +46,7 @@ import torch.nn as nn
 from . import dist_utils
 from . import ops as _ops
 from .gptq import GPTQ
+from .model_utils import ForwardInterrupt
 from .quant_utils import GGML_QUANT_SIZES
 from .quant_utils import GGMLQuantizationType, dequantize_linear_weight
 
@@ -107,6 +108,9 @@ class BlockSchedule:
         for h in self.handles.values():
             h._scheduled = True  # the handle leaves threshold flushes to sample_done()
         self._seen: Dict[Any, Any] = {}  # per block call: input identity -> (leader handle, tensor kept alive)
+        self._fired: List[str] = []      # pre_hook(): the handles fed in the current sample, in order
+        self._last_fired: Optional[str] = None
+        self._n_samples = 0
         self.n_streams = int(os.environ.get("GQ_CHAIN_STREAMS", 4)) if n_streams is None else n_streams
         self.verbose = verbose
         self.stats = {"syrk_launches": 0, "allreduce_bytes": 0, "reused_U": 0, "own_U": 0, "refactorised": 0}
@@ -119,6 +123,22 @@ class BlockSchedule:
     def hook(self, name: str):
         def _hook(_, inp, out):
             self.feed(name, inp[0])
+        return _hook
+
+    def pre_hook(self, name: str, interrupt: bool = True):
+        """The same feed as hook(), from a forward PRE-hook -- the input of a Linear exists before its GEMM runs -- so that
+        forward #1 can stop at the last hooked Linear: the reference discards that forward's output (quantizer.py:150-151),
+        and for a Llama block the last Linear is down_proj, 27 % of the layer's GEMM flops (+ the residual add).  Which
+        Linear is last is LEARNED: the block's first sample runs to its end; if every handle fired exactly once there, the
+        later samples raise ForwardInterrupt right after feeding the Linear that fired last -- provided every other handle
+        has fired in that sample too (MoE experts fire data-dependently: then the forward just continues)."""
+        def _hook(_, inp):
+            self.feed(name, inp[0])
+            self._fired.append(name)
+            if interrupt and name == self._last_fired and len(self._fired) == len(self.handles) \
+                    and len(set(self._fired)) == len(self._fired):
+                self.stats["forward1_interrupts"] = self.stats.get("forward1_interrupts", 0) + 1
+                raise ForwardInterrupt
         return _hook
 
     def feed(self, name: str, x: torch.Tensor) -> None:
@@ -141,6 +161,10 @@ class BlockSchedule:
     def sample_done(self) -> None:
         """Called after every calibration sample (one forward of the block)."""
         self._seen.clear()
+        if self._n_samples == 0 and len(self._fired) == len(self.handles) and len(set(self._fired)) == len(self._fired):
+            self._last_fired = self._fired[-1]  # every Linear fired once: later samples may stop there (pre_hook)
+        self._n_samples += 1
+        self._fired = []
         if self._sharing is None:
             self._publish_sharing()
         if any(h._fill - h._marked >= h.flush_tokens for h in self.handles.values()):

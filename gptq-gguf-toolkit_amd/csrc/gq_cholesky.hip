@@ -851,7 +851,7 @@ static int chol_inv_rec(float* A, float* X, float* Tmp, int* flag, int64_t n, in
     const int64_t o21 = (mid * NB) * n + lo * NB, o11 = (lo * NB) * n + lo * NB, o22 = (mid * NB) * n + mid * NB;
     // large nodes: fp32-accurate products on the bf16 matrix cores (gq_gemm3b.hpp); small ones are
     // latency-bound and stay on the fp32 instruction
-    static const int64_t min3b = getenv("GQ_CHOL_FP32") ? (int64_t)1 << 40 : (getenv("GQ_CHOL_3B_MIN") ? atol(getenv("GQ_CHOL_3B_MIN")) : 1024);
+    const int64_t min3b = getenv("GQ_CHOL_FP32") ? (int64_t)1 << 40 : (getenv("GQ_CHOL_3B_MIN") ? atol(getenv("GQ_CHOL_3B_MIN")) : 1024);
     const bool big = n1 >= min3b && n2 >= min3b;
 #define GQ_CHOL_GEMM(TB, MODE, LOW, KRV, ...) \
     (big ? launch_gemm3b<TB, MODE, LOW, KRV>(__VA_ARGS__) : launch_gemm32<TB, MODE, LOW, KRV>(__VA_ARGS__))

@@ -9,10 +9,16 @@ those three with one gfx950 kernel each (csrc/gq_forward.hip) for the duration o
     apply_rotary_pos_emb       -> ops.fwd_rope      (per-op rounding of the eager expression)
     LlamaMLP.forward           -> down_proj(ops.fwd_silu_mul(gate_proj(x), up_proj(x)))
 
-The Linear modules are still called through `nn.Module.__call__`, so the Hessian hooks see the same inputs.  A model
-family is patched only when the source text of its module matches Llama's (Mistral, Qwen2 ... copy it verbatim), and
-every patched function falls back to the original for inputs the kernels do not take (fp32, non-contiguous, odd
-sizes, CPU tensors) -- the originals are torch code, not a CPU restatement of ours.  Levels (`level_of`): "exact"
+The Linear modules are still called through `nn.Module.__call__`, so the Hessian hooks see the same inputs.  Two guards
+(ADVICE r03): (1) the kernels were written for ONE definition of each function -- `_PINNED` holds the hashes of the
+normalised source of LlamaRMSNorm.forward, apply_rotary_pos_emb (+ rotate_half) and LlamaMLP.forward they implement; if the
+installed transformers' Llama differs (a `pretraining_tp` branch, a new keyword, ...) that function is NOT patched, and a
+model family is patched only when its module text equals the pinned Llama text (Mistral, Qwen2 ... copy it verbatim);
+(2) every kernel is trusted for a (shape class, dtype) only after it has reproduced the eager expression bit for bit on
+the first real input of that class -- RMSNorm (output + the fp32 statistics), the rotary embedding and SwiGLU alike; a
+mismatch leaves the eager code in place for that class.  Every patched function also falls back to the original for inputs
+the kernels do not take (fp32, non-contiguous, odd sizes, CPU tensors, unknown keywords) -- the originals are torch code,
+not a CPU restatement of ours.  Levels (`level_of`): "exact"
 -- the Quantizer's default -- installs only kernels that are bit-identical to HF eager: the rotary embedding and SwiGLU
 (tests/test_gpu_forward.py: torch.equal, every finite 16-bit gate value included), and RMSNorm through
 gq_fwd_rmsnorm_ordered, which sums mean(x^2) in the order of ATen's reduce kernel and rounds rsqrt the way torch.rsqrt
@@ -24,8 +30,10 @@ patches nothing.
 from __future__ import annotations
 
 import contextlib
+import hashlib
 import importlib
 import inspect
+import warnings
 from typing import List, Tuple
 
 import torch
@@ -50,7 +58,28 @@ def _body(fn) -> str:
     return "\n".join(ln for ln in text.splitlines() if ln.strip())
 
 
-_norm_verdict = {}  # (C, dtype) -> True: the ordered kernel reproduced the eager module bit for bit on first use
+def _sha(fn) -> str:
+    return hashlib.sha256(_body(fn).encode()).hexdigest()[:16]
+
+
+# The semantics csrc/gq_forward.hip implements, as sha256[:16] of `_body(fn)` of transformers' Llama (5.x):
+#   LlamaRMSNorm.forward:  x32 = x.float(); var = x32.pow(2).mean(-1, keepdim=True); x32 = x32 * rsqrt(var + eps);
+#                          return weight * x32.to(input dtype)
+#   apply_rotary_pos_emb:  (q * cos) + (rotate_half(q) * sin), same for k, cos / sin unsqueezed at unsqueeze_dim
+#   rotate_half:           cat((-x[..., D/2:], x[..., :D/2]), -1)
+#   LlamaMLP.forward:      down_proj(act_fn(gate_proj(x)) * up_proj(x))
+_PINNED = {"norm": "3480f6ca9ea40b53", "rope": "d2c323856b661430", "rotate_half": "e011a50957282b58", "mlp": "1923407024d5de0b"}
+
+_norm_verdict = {}  # (C, dtype, rows) -> True: the ordered kernel reproduced the eager module bit for bit on first use
+_rope_verdict = {}  # (L, heads q, heads k, D, dtype, batch) -> True: fwd_rope == the eager expression on first use
+_mlp_verdict = {}   # (intermediate size, dtype, rows) -> True: fwd_silu_mul == act_fn(g) * u on first use
+
+
+def reset_verdicts():
+    """Forget what has been verified (the Quantizer calls this at the start of a run: every run re-checks cheaply)."""
+    _norm_verdict.clear()
+    _rope_verdict.clear()
+    _mlp_verdict.clear()
 
 
 def _rmsnorm_forward(orig, allow_free_order: bool):
@@ -67,7 +96,8 @@ def _rmsnorm_forward(orig, allow_free_order: bool):
                 and x.numel() > 0 and not torch.is_grad_enabled()):
             return orig(self, x)
         C = x.shape[-1]
-        key = (C, x.dtype)
+        # ATen's reduce configuration depends on the number of rows as well as on C: every (C, dtype, rows) is verified
+        key = (C, x.dtype, x.numel() // C)
         if C % 512 == 0 and x.numel() // C >= 8:
             ok = _norm_verdict.get(key)
             if ok is None:
@@ -89,7 +119,11 @@ def _rmsnorm_forward(orig, allow_free_order: bool):
 
 
 def _rope(orig):
-    def apply_rotary_pos_emb(q, k, cos, sin, unsqueeze_dim=1):
+    def apply_rotary_pos_emb(q, k, cos, sin, *args, **kwargs):
+        # anything but the pinned signature (q, k, cos, sin, unsqueeze_dim=1) goes to the original untouched
+        if len(args) > 1 or (kwargs and set(kwargs) != {"unsqueeze_dim"}) or (args and kwargs):
+            return orig(q, k, cos, sin, *args, **kwargs)
+        unsqueeze_dim = args[0] if args else kwargs.get("unsqueeze_dim", 1)
         ok = (unsqueeze_dim == 1 and q.is_cuda and q.dim() == 4 and k.dim() == 4 and cos.dim() == 3 and q.dtype in _16BIT
               and k.dtype == q.dtype == cos.dtype == sin.dtype and q.shape[-1] % 16 == 0 and q.numel() > 0
               and not torch.is_grad_enabled())
@@ -100,10 +134,20 @@ def _rope(orig):
                   and cos.shape == sin.shape and cos.shape[0] in (1, B))
         if not ok:
             return orig(q, k, cos, sin, unsqueeze_dim)
-        if cos.shape[0] != B:
-            cos, sin = cos.expand(B, L, D), sin.expand(B, L, D)
-        cos, sin = cos.contiguous(), sin.contiguous()
-        return ops.fwd_rope(qt, cos, sin).transpose(1, 2), ops.fwd_rope(kt, cos, sin).transpose(1, 2)
+        key = (L, qt.shape[2], kt.shape[2], D, q.dtype, B)
+        verdict = _rope_verdict.get(key)
+        if verdict is False:
+            return orig(q, k, cos, sin, unsqueeze_dim)
+        c, s_ = cos, sin
+        if c.shape[0] != B:
+            c, s_ = c.expand(B, L, D), s_.expand(B, L, D)
+        c, s_ = c.contiguous(), s_.contiguous()
+        got = ops.fwd_rope(qt, c, s_).transpose(1, 2), ops.fwd_rope(kt, c, s_).transpose(1, 2)
+        if verdict is None:  # first input of this class: the eager expression decides, and is what is returned
+            want = orig(q, k, cos, sin, unsqueeze_dim)
+            _rope_verdict[key] = bool(torch.equal(want[0], got[0]) and torch.equal(want[1], got[1]))
+            return want
+        return got
     return apply_rotary_pos_emb
 
 
@@ -112,9 +156,18 @@ def _mlp_forward(orig):
         act = self.act_fn
         if (x.is_cuda and x.dtype in _16BIT and not torch.is_grad_enabled()
                 and (isinstance(act, torch.nn.SiLU) or type(act).__name__ == "SiLUActivation")):
+            # the three Linears are entered exactly once each, through nn.Module.__call__: the Hessian hooks see every
+            # input once whether or not the kernel is trusted yet
             g, u = self.gate_proj(x), self.up_proj(x)
             if g.is_contiguous() and u.is_contiguous() and g.numel() % 8 == 0 and g.numel() > 0:
-                return self.down_proj(ops.fwd_silu_mul(g, u))
+                key = (g.shape[-1], g.dtype, g.numel() // g.shape[-1])
+                verdict = _mlp_verdict.get(key)
+                if verdict:
+                    return self.down_proj(ops.fwd_silu_mul(g, u))
+                want = act(g) * u
+                if verdict is None:
+                    _mlp_verdict[key] = bool(torch.equal(want, ops.fwd_silu_mul(g, u)))
+                return self.down_proj(want)
             return self.down_proj(act(g) * u)
         return orig(self, x)
     return forward
@@ -124,7 +177,24 @@ def _targets(free_order_norm: bool = True) -> List[Tuple[object, str, object]]:
     """(owner, attribute, replacement) for every installed family whose module text equals Llama's.  free_order_norm:
     RMSNorm may fall back to the free-order kernel where the ordered one is not verified (level "all")."""
     from transformers.models.llama import modeling_llama as ref
-    want_norm, want_rope, want_mlp = _body(ref.LlamaRMSNorm.forward), _body(ref.apply_rotary_pos_emb), _body(ref.LlamaMLP.forward)
+    # what the installed Llama computes must be what the kernels were written for; a function whose text moved is left
+    # to the eager code (for every family), loudly
+    have = {"norm": (ref.LlamaRMSNorm.forward,), "rope": (ref.apply_rotary_pos_emb,), "rotate_half": (ref.rotate_half,),
+            "mlp": (ref.LlamaMLP.forward,)}
+    pinned = {}
+    for k, (fn,) in have.items():
+        try:
+            pinned[k] = _sha(fn) == _PINNED[k]
+        except (OSError, TypeError):
+            pinned[k] = False
+    pinned["rope"] = pinned["rope"] and pinned["rotate_half"]
+    moved = [k for k in ("norm", "rope", "mlp") if not pinned[k]]
+    if moved:
+        warnings.warn(f"forward_fused: transformers' Llama {moved} differ from the definitions the HIP kernels implement; "
+                      "these stay on HF eager code", RuntimeWarning)
+    want_norm = _body(ref.LlamaRMSNorm.forward) if pinned["norm"] else None
+    want_rope = _body(ref.apply_rotary_pos_emb) if pinned["rope"] else None
+    want_mlp = _body(ref.LlamaMLP.forward) if pinned["mlp"] else None
     out = []
     for fam in _FAMILIES:
         try:
@@ -135,15 +205,17 @@ def _targets(free_order_norm: bool = True) -> List[Tuple[object, str, object]]:
             if not inspect.isclass(cls) or getattr(cls, "__module__", None) != mod.__name__:
                 continue
             try:
-                if name.endswith("RMSNorm") and _body(cls.forward) == want_norm:
+                if want_norm and name.endswith("RMSNorm") and _body(cls.forward) == want_norm:
                     out.append((cls, "forward", _rmsnorm_forward(cls.forward, free_order_norm)))
-                elif name.endswith("MLP") and _body(cls.forward) == want_mlp:
+                elif want_mlp and name.endswith("MLP") and _body(cls.forward) == want_mlp:
                     out.append((cls, "forward", _mlp_forward(cls.forward)))
             except (OSError, TypeError):
                 continue
         fn = vars(mod).get("apply_rotary_pos_emb")
         try:
-            if fn is not None and getattr(fn, "__module__", None) == mod.__name__ and _body(fn) == want_rope:
+            rh = vars(mod).get("rotate_half")
+            if (want_rope and fn is not None and getattr(fn, "__module__", None) == mod.__name__ and _body(fn) == want_rope
+                    and rh is not None and _sha(rh) == _PINNED["rotate_half"]):
                 out.append((mod, "apply_rotary_pos_emb", _rope(fn)))
         except (OSError, TypeError):
             pass

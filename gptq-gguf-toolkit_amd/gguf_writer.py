@@ -27,12 +27,14 @@ class GGUFValueType:
 
 class GGMLType:
     F32, F16 = 0, 1
+    Q8_0 = 8
     Q2_K, Q3_K, Q4_K, Q5_K, Q6_K = 10, 11, 12, 13, 14
     BF16 = 30
 
 
 # (block size in values, bytes per block)
-GGML_QUANT_SIZES = {GGMLType.F32: (1, 4), GGMLType.F16: (1, 2), GGMLType.BF16: (1, 2), GGMLType.Q2_K: (256, 84),
+GGML_QUANT_SIZES = {GGMLType.F32: (1, 4), GGMLType.F16: (1, 2), GGMLType.BF16: (1, 2), GGMLType.Q8_0: (32, 34),
+                    GGMLType.Q2_K: (256, 84),
                     GGMLType.Q3_K: (256, 110), GGMLType.Q4_K: (256, 144), GGMLType.Q5_K: (256, 176),
                     GGMLType.Q6_K: (256, 210)}
 
@@ -63,6 +65,33 @@ def quant_shape_from_byte_shape(shape: Sequence[int], ggml_type: int) -> Tuple[i
     return (*shape[:-1], shape[-1] // ts * bs)
 
 
+class QuantError(Exception):
+    """gguf-py's `gguf.QuantError`: the tensor's row length is not a multiple of the type's block size."""
+
+
+def quantize_q8_0(data: np.ndarray) -> np.ndarray:
+    """`gguf.quants.quantize(data, Q8_0)` of gguf-py 0.17.1 (un-vendored; the reference calls it for the tensors GPTQ did
+    not quantize when `--outtype q8_0`, pack_gptq_into_gguf.py:404-405,419), restated from its published algorithm,
+    which is ggml-quants.c `quantize_row_q8_0_ref` in numpy: per block of 32 fp32 values `d = amax / 127` (fp32),
+    `id = 1 / d` (0 when d == 0), `q = roundf(x * id)` -- ROUND HALF AWAY FROM ZERO, computed as
+    `sign(x) * (floor(|v|) + floor(2 * (|v| - floor(|v|))))` -- stored as `block_q8_0 { fp16 d; int8 qs[32]; }`, 34 bytes.
+    -> uint8 [..., n / 32 * 34].  PARITY: pinned against an independent scalar restatement of the C routine
+    (tests/ggml_spec.py), not against gguf-py itself (not installable here)."""
+    data = np.asarray(data)
+    if data.shape[-1] % 32 != 0:
+        raise QuantError(f"Can't quantize tensor with shape {data.shape} to Q8_0")
+    blocks = np.ascontiguousarray(data, dtype=np.float32).reshape(-1, 32)
+    d = np.abs(blocks).max(axis=1, keepdims=True) / np.float32(127)
+    with np.errstate(divide="ignore"):
+        inv = np.where(d == 0, np.float32(0), np.float32(1) / d).astype(np.float32)
+    v = blocks * inv
+    a = np.abs(v)
+    fl = np.floor(a)
+    qs = (np.sign(v) * (fl + np.floor(2 * (a - fl)))).astype(np.int8).view(np.uint8)
+    out = np.concatenate([d.astype(np.float16).view(np.uint8), qs], axis=1)
+    return out.reshape(*data.shape[:-1], data.shape[-1] // 32 * 34)
+
+
 class GGUFWriter:
     def __init__(self, path: str, arch: str):
         self.path = path
@@ -72,6 +101,8 @@ class GGUFWriter:
 
     # ---- metadata
     def add(self, key, vtype, value, sub=None):
+        if any(k == key for k, *_ in self.kv):  # gguf-py's GGUFWriter.add_key_value raises the same way
+            raise ValueError(f"Duplicated key name {key!r}")
         self.kv.append((key, vtype, value, sub))
 
     def add_string(self, k, v): self.add(k, GGUFValueType.STRING, v)

@@ -30,7 +30,7 @@ import torch.nn as nn
 from . import dist_utils
 from . import ops as _ops
 from .block_schedule import BlockSchedule
-from .forward_fused import fused_forward, level_of
+from .forward_fused import fused_forward, level_of, reset_verdicts
 from .gptq import GPTQ
 from .model_utils import ForwardInterrupt, InputCollector, LINEAR_LAYERS, _to, select_layers
 from .quant_utils import GGML_QUANT_SIZES, GGMLQuantizationType, dequantize_linear_weight
@@ -517,7 +517,7 @@ class Quantizer:
                  block_modules: str, save_dir: str, quant_non_block_modules: bool = False,
                  device: Optional[torch.device] = None, cpu_offload_modules: bool = False,
                  cpu_offload_activations: bool = False, verbose: bool = False, non_block_fp32: bool = False,
-                 calibration_batch: int = 1, fused_forward="exact") -> None:
+                 calibration_batch: int = 1, fused_forward="exact", interrupt_forward1: bool = True) -> None:
         self.model = model
         self.data_loader = data_loader
         self.quantizable_modules = quantizable_modules
@@ -536,6 +536,9 @@ class Quantizer:
         # per block forward.  Same Hessians in exact arithmetic (GPTQ.update weighs a batch by its size,
         # gptq.py:86-112); one Llama-3-8B layer forward takes 0.91 instead of 1.16 ms per sequence at 4.
         self.calibration_batch = max(1, int(calibration_batch))
+        # forward #1 of a block (quantizer.py:150-151) only feeds the Hessian hooks, its output is discarded: stop it at the
+        # last hooked Linear (learned on the block's first sample; BlockSchedule.pre_hook).  Same Hessians, same bytes saved.
+        self.interrupt_forward1 = bool(interrupt_forward1)
         # beyond the reference (which runs the HF eager modules, quantizer.py:293): HIP kernels for the elementwise
         # modules of the block forward (forward_fused.py).  "exact" (default): rotary embedding, SwiGLU and RMSNorm, each
         # bit-identical to HF eager (RMSNorm verified at run time on this PyTorch before it is trusted) -- the saved
@@ -553,6 +556,7 @@ class Quantizer:
             self._saver.warm_up(device)
         self._saved_names: List[str] = []
         try:
+            reset_verdicts()  # every run re-verifies the forward kernels on its own first inputs
             with fused_forward(self.fused_forward if torch.device(device).type == "cuda" else "off") as patched:
                 self._fused_modules = patched
                 self._quantize(quant_config, device)
@@ -612,6 +616,8 @@ class Quantizer:
         # block's work (save tail 0.65 -> 0.3 s).  GQ_POST_BLOCKS=last: the reference's place; =early: before the block loop
         # (same gain; with two staging slots 2 of 5 such runs fell into the slow mode described at _Saver.put_many).
         post_where = os.environ.get("GQ_POST_BLOCKS", "before_last_block") if self.quant_non_block_modules else "none"
+        if post_where not in ("none", "early", "before_last_block", "last"):
+            raise ValueError(f"GQ_POST_BLOCKS={post_where!r}: expected early / before_last_block / last")
         post_early = post_where == "early"
         if post_early:
             for name, module in post_blocks:
@@ -631,7 +637,10 @@ class Quantizer:
             handles, hooks = self._prepare_hooks_and_handles(layers)
             sched = self._schedule
             for a, kw in zip(input_args, input_kwargs):  # forward #1: Hessians (quantizer.py:150-151)
-                block(*_to(a, device=device), **_to(kw, device=device))
+                try:
+                    block(*_to(a, device=device), **_to(kw, device=device))
+                except ForwardInterrupt:  # every hooked Linear has been fed; the reference discards the output anyway
+                    pass
                 sched.sample_done()  # grouped SYRK launches once the buffers hold flush_tokens tokens
             for h in hooks.values():
                 h.remove()
@@ -670,6 +679,9 @@ class Quantizer:
         if post_where == "last" or (post_where == "before_last_block" and len(blocks) == 0):
             for name, module in post_blocks:
                 self._quant_and_save_non_block(name, module.to(device), quant_config)
+        if self.quant_non_block_modules:  # wherever they ran, they ran: the packer would silently write a missing one as f16
+            missing = [n for n, _ in pre_blocks + post_blocks if n not in self._saved_names]
+            assert not missing, f"non-block modules never quantized: {missing}"
         if use_cache is not None:
             self.model.config.use_cache = use_cache
         BlockSchedule.verify()  # whatever is still on its way
@@ -686,7 +698,10 @@ class Quantizer:
     def _prepare_hooks_and_handles(self, layers: Dict[str, nn.Module]):
         """reference quantizer.py:221-239; the hook body lives in BlockSchedule.feed."""
         self._schedule = BlockSchedule(layers, self._create_handle, verbose=self.verbose)
-        hooks = {name: layer.register_forward_hook(self._schedule.hook(name)) for name, layer in layers.items()}
+        # forward PRE-hooks: same inp[0] as the reference's forward hook (quantizer.py:229), available before the Linear's
+        # GEMM, so that forward #1 can stop at the last hooked Linear (BlockSchedule.pre_hook)
+        hooks = {name: layer.register_forward_pre_hook(self._schedule.pre_hook(name, self.interrupt_forward1))
+                 for name, layer in layers.items()}
         return self._schedule.handles, hooks
 
     # ------------------------------------------------------------- quantize

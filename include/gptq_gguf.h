@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define GQ_ABI_VERSION 2
+#define GQ_ABI_VERSION 3
 
 /* ggml type ids (quant_utils.py:11-16) */
 enum { GQ_Q2_K = 10, GQ_Q3_K = 11, GQ_Q4_K = 12, GQ_Q5_K = 13, GQ_Q6_K = 14 };

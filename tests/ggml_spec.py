@@ -92,3 +92,33 @@ def unpack(q_type, packed):
     G = 256 // sc.shape[1]
     return (codes.reshape(R, nb * 256), d.reshape(R, nb), sc.reshape(R, nb * (256 // G)), dmin.reshape(R, nb),
             mn.reshape(R, nb * (256 // G)))
+
+
+# ---- Q8_0 (ggml-quants.c quantize_row_q8_0_ref / dequantize_row_q8_0), scalar, from the C source's definition ----
+def q8_0_encode_scalar(x):
+    """x: float32 [n], n % 32 == 0 -> bytes.  One Python loop per element (small inputs only): fp32 arithmetic through
+    np.float32 scalars, roundf as floor(|v| + 0.5) in exact double arithmetic with the sign restored."""
+    import math
+    import struct
+    x = np.asarray(x, np.float32).ravel()
+    out = bytearray()
+    for b in range(0, x.size, 32):
+        blk = x[b:b + 32]
+        amax = np.float32(0)
+        for v in blk:
+            amax = max(amax, np.float32(abs(v)))
+        d = np.float32(amax / np.float32(127))
+        inv = np.float32(1) / d if d != 0 else np.float32(0)
+        out += np.float16(d).tobytes()
+        for v in blk:
+            x0 = float(np.float32(v * inv))
+            out += struct.pack("<b", int(math.copysign(math.floor(abs(x0) + 0.5), x0)))
+    return bytes(out)
+
+
+def q8_0_decode(raw, n):
+    """bytes -> float32 [n]: y = d * q."""
+    b = np.frombuffer(raw, np.uint8).reshape(-1, 34)
+    d = b[:, :2].copy().view(np.float16).astype(np.float32)
+    q = b[:, 2:].copy().view(np.int8).astype(np.float32)
+    return (d * q).reshape(-1)[:n]

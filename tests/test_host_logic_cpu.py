@@ -815,6 +815,111 @@ def test_packer_sentencepiece_vocabulary(tmp_path, monkeypatch):
         convert(hf, tmp_path / "noquant", tmp_path / "x.gguf", "f16")
 
 
+def test_q8_0_encoder_against_the_scalar_restatement():
+    """f1: `quantize_q8_0` (gguf-py 0.17.1 `gguf.quants.quantize(.., Q8_0)`, which the reference calls for
+    un-quantized tensors under --outtype q8_0: pack_gptq_into_gguf.py:404-405,419) against an independent element-by-element
+    restatement of ggml-quants.c quantize_row_q8_0_ref (tests/ggml_spec.py): bytes identical, incl. all-zero blocks, exact
+    .5 ties (away from zero), the +-127 ends, large and tiny scales (blocks whose 1 / d overflows are undefined behaviour in the C routine too); decode error <= d / 2."""
+    from ggml_spec import q8_0_decode, q8_0_encode_scalar
+    from gptq_gguf_toolkit_amd.gguf_writer import QuantError, quantize_q8_0
+    rng = np.random.default_rng(5)
+    x = (rng.standard_normal((24, 96)) * 0.02).astype(np.float32)
+    x[0, :32] = 0.0                                                    # d = 0 -> id = 0
+    x[1, :32] = np.float32(1.5) * np.arange(32, dtype=np.float32)      # multiples of d / 2 ...: ties
+    x[2, :8] = [0.5, -0.5, 1.5, -1.5, 2.5, -2.5, 63.5, -63.5]
+    x[2, 8] = 127.0                                                    # d = 1: the values above are exact .5 ties
+    x[3, :32] = rng.standard_normal(32).astype(np.float32) * 1e4       # large
+    x[4, :32] = rng.standard_normal(32).astype(np.float32) * 1e-7      # d below the fp16 normal range
+    x[5, :32] = -x[1, :32]
+    x[6, 32:64] = np.float32(2.0e-36)                                   # tiny: d rounds to an fp16 zero, 1 / d stays finite
+    got = quantize_q8_0(x)
+    assert got.dtype == np.uint8 and got.shape == (24, 96 // 32 * 34)
+    assert got.tobytes() == q8_0_encode_scalar(x)
+    y = q8_0_decode(got.tobytes(), x.size).reshape(x.shape)
+    d = got.reshape(-1, 34)[:, :2].copy().view(np.float16).astype(np.float32).reshape(24, 3)
+    amax = np.abs(x.reshape(24, 3, 32)).max(-1)
+    # |x - d16 q| <= d/2 (rounding of q) + 127 |d - d16| (fp16 rounding of the stored scale, 2^-11 relative or half a
+    # subnormal step)
+    bound = amax / 127 / 2 + 127 * np.abs(d - amax / 127) + 1e-30
+    assert (np.abs(y - x).reshape(24, 3, 32).max(-1) <= bound * 1.0001).all()
+    q = got.reshape(-1, 34)[:, 2:].view(np.int8)
+    assert q.min() >= -127 and q.max() == 127
+    xh = x.astype(np.float16)                                          # fp16 checkpoints are widened first
+    assert quantize_q8_0(xh).tobytes() == q8_0_encode_scalar(xh.astype(np.float32))
+    with pytest.raises(QuantError):
+        quantize_q8_0(np.zeros((4, 48), np.float32))
+
+
+@pytest.mark.parametrize("ckpt_dtype", [torch.float16, torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("outtype", ["f32", "f16", "bf16", "q8_0", "auto"])
+def test_pack_into_gguf_outtypes(tmp_path, monkeypatch, outtype, ckpt_dtype):
+    """--outtype (reference :8804, :395-410, :144-152): the type of every tensor GPTQ did not quantize, `general.file_type`,
+    1-D tensors and norms always F32, `auto` = f16 for an fp16 checkpoint and bf16 otherwise, Q8_0's fallback to F16 for rows
+    that are no multiple of 32; the quantized tensor keeps its K-quant payload whatever the outtype."""
+    import fake_ops
+    from safetensors.torch import save_file
+    from ggml_spec import q8_0_encode_scalar
+    from gptq_gguf_toolkit_amd import packing_utils
+    from gptq_gguf_toolkit_amd.gguf_writer import read_gguf
+    from gptq_gguf_toolkit_amd.pack_gptq_into_gguf import convert, permute
+    monkeypatch.setattr(packing_utils, "_ops", fake_ops)
+    monkeypatch.setattr(packing_utils, "_dev", lambda t: t.contiguous())
+    h, V = 256, 48
+    cfg = {"architectures": ["LlamaForCausalLM"], "hidden_size": h, "intermediate_size": 336, "num_hidden_layers": 1,
+           "num_attention_heads": 4, "num_key_value_heads": 2, "vocab_size": V, "max_position_embeddings": 128,
+           "rms_norm_eps": 1e-5, "rope_theta": 10000.0}
+    g = torch.Generator().manual_seed(1)
+    p = "model.layers.0."
+    sd = {"model.embed_tokens.weight": torch.randn(V, h, generator=g), "model.norm.weight": torch.rand(h, generator=g),
+          p + "self_attn.q_proj.weight": torch.randn(h, h, generator=g), p + "self_attn.k_proj.weight": torch.randn(h // 2, h, generator=g),
+          p + "mlp.down_proj.weight": torch.randn(h, 336, generator=g),  # 336 % 32 != 0: no Q8_0 rows
+          p + "input_layernorm.weight": torch.rand(h, generator=g), "lm_head.weight": torch.randn(V, h, generator=g)}
+    sd = {k: v.to(ckpt_dtype) for k, v in sd.items()}
+    hf = tmp_path / "hf"
+    hf.mkdir()
+    save_file(sd, str(hf / "model.safetensors"))
+    (hf / "config.json").write_text(json.dumps(cfg))
+    qdir = tmp_path / "q" / "model.layers.0.self_attn.q_proj"
+    qdir.mkdir(parents=True)
+    qd = {"q_type": 12, "qweight": torch.randint(0, 16, (h, h), generator=g).to(torch.uint8),
+          "super_group_scale": torch.rand(h, 1, generator=g).half(), "super_group_zero": torch.rand(h, 1, generator=g).half(),
+          "group_scale_quant": torch.randint(0, 64, (h, 8), generator=g).to(torch.uint8),
+          "group_zero_quant": torch.randint(0, 64, (h, 8), generator=g).to(torch.uint8)}
+    torch.save(qd, str(qdir / "data.pth"))
+    kv, ts = read_gguf(str(convert(hf, tmp_path / "q", tmp_path / "m.gguf", outtype, vocab=False)))
+    eff = outtype if outtype != "auto" else ("f16" if ckpt_dtype == torch.float16 else "bf16")
+    assert kv["general.file_type"] == {"f32": 0, "f16": 1, "bf16": 32, "q8_0": 7}[eff]
+    gg = {"f32": 0, "f16": 1, "bf16": 30, "q8_0": 8}[eff]
+    for name in ("output_norm.weight", "blk.0.attn_norm.weight"):
+        assert ts[name][1] == 0  # F32 whatever the outtype (:355-356)
+    shape, gt, raw = ts["blk.0.attn_q.weight"]
+    assert gt == 12 and shape == (h, h)  # the GPTQ tensor: Q4_K bytes, rows un-permuted (:320-324)
+    five = [permute(qd[k], 4, 4) for k in ("qweight", "super_group_scale", "group_scale_quant", "super_group_zero", "group_zero_quant")]
+    assert np.array_equal(raw.reshape(h, -1), packing_utils.pack_tensor(12, *five))
+    wide = lambda t: t if t.dtype in (torch.float16, torch.float32) else t.float()  # noqa: E731  (:296-297)
+    for name, src in (("token_embd.weight", sd["model.embed_tokens.weight"]), ("output.weight", sd["lm_head.weight"]),
+                      ("blk.0.attn_k.weight", permute(sd[p + "self_attn.k_proj.weight"], 4, 2)),
+                      ("blk.0.ffn_down.weight", sd[p + "mlp.down_proj.weight"])):
+        shape, gt, raw = ts[name]
+        src = wide(src)
+        assert shape == tuple(src.shape)
+        if eff == "q8_0" and src.shape[-1] % 32:
+            assert gt == 1 and raw.tobytes() == src.half().numpy().tobytes()  # QuantError -> F16 (:419-424)
+            continue
+        assert gt == gg, (name, gt)
+        if eff == "f32":
+            assert raw.tobytes() == src.float().numpy().tobytes()
+        elif eff == "f16":
+            assert raw.tobytes() == src.half().numpy().tobytes()
+        elif eff == "bf16":
+            assert raw.tobytes() == src.to(torch.bfloat16).view(torch.int16).numpy().tobytes()
+        else:
+            assert raw.tobytes() == q8_0_encode_scalar(src.float().numpy())
+    for bad in ("tq1_0", "tq2_0"):
+        with pytest.raises(NotImplementedError, match="ternary"):
+            convert(hf, tmp_path / "q", tmp_path / "t.gguf", bad, vocab=False)
+
+
 def test_calibration_batch_merges_block_inputs(tmp_path):
     """calibration_batch (beyond the reference): 4 samples per block forward give the same tree and -- the Hessians
     being the same sums -- the same integers up to the tolerance-class rate; inputs that differ in anything but the
@@ -994,3 +1099,95 @@ def test_fused_forward_patch_targets_and_restore():
         assert M.apply_rotary_pos_emb is not orig[1]
         assert torch.equal(model(input_ids=ids).logits, want)  # CPU fp32: the originals
     assert (M.LlamaRMSNorm.forward, M.apply_rotary_pos_emb, M.LlamaMLP.forward) == orig[:3]
+
+
+def test_fused_forward_refuses_a_llama_whose_text_moved(monkeypatch):
+    """the source check is against PINNED definitions, not against whatever the installed transformers
+    ships -- a LlamaMLP.forward that grew a branch is left to the eager code (for every family), with a warning; unknown
+    keywords of apply_rotary_pos_emb go to the original."""
+    import warnings
+    from transformers.models.llama import modeling_llama as M
+    from gptq_gguf_toolkit_amd import forward_fused as ff
+
+    def forward(self, x):  # what a `pretraining_tp`-style change would look like
+        if getattr(self.config, "pretraining_tp", 1) > 1:
+            return None
+        return self.down_proj(self.act_fn(self.gate_proj(x)) * self.up_proj(x))
+    monkeypatch.setattr(M.LlamaMLP, "forward", forward)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        names = [f"{getattr(o, '__name__', o)}.{a}" for o, a, _ in ff._targets()]
+    assert any("mlp" in str(x.message) for x in w)
+    assert not any(n.endswith("MLP.forward") for n in names)  # Mistral / Qwen copies equal the OLD text: not patched either
+    assert "LlamaRMSNorm.forward" in names and any(n.endswith("apply_rotary_pos_emb") for n in names)
+    calls = []
+    wrapped = ff._rope(lambda q, k, cos, sin, *a, **kw: calls.append((a, kw)) or "orig")
+    assert wrapped(1, 2, 3, 4, position_ids=5) == "orig" and calls == [((), {"position_ids": 5})]
+    assert wrapped(1, 2, 3, 4, 1, 7) == "orig"
+
+
+def test_forward1_stops_at_the_last_hooked_linear(tmp_path):
+    """VERDICT r03 next #3a: forward #1 of a block only feeds the Hessian hooks (reference quantizer.py:150-151 discards its
+    output), so after the block's first sample it ends at the last hooked Linear -- down_proj's GEMM and the residual add
+    are not run.  Same tree, same bytes as with the full forwards; down_proj is entered 1 + n (forward #2) times per
+    block fewer... counted."""
+    import fake_ops
+    from make_golden_shim import MIXED, tiny_calib, tiny_llama
+    from gptq_gguf_toolkit_amd.quant_utils import GGMLQuantizationType as T
+    from gptq_gguf_toolkit_amd.quantizer import Quantizer
+    fake_ops.install()
+    trees, counts = [], []
+    ids = tiny_calib()
+    for interrupt in (True, False):
+        d = str(tmp_path / f"i{int(interrupt)}")
+        os.makedirs(d)
+        model = tiny_llama()
+        n_calls = [0]
+        model.model.layers[0].mlp.down_proj.register_forward_hook(lambda *a: n_calls.__setitem__(0, n_calls[0] + 1))
+        drv = Quantizer(model, data_loader=[([], {"input_ids": t}) for t in ids],
+                        quantizable_modules=r".*layers.*((q|k|v|o|gate|up|down)_proj)$",
+                        quantizer_kwargs=dict(rel_damp=0.01, block_size=128), pre_block_modules=["model.embed_tokens"],
+                        block_modules="model.layers", post_block_modules=["lm_head"], quant_non_block_modules=True,
+                        device="cpu", save_dir=d, interrupt_forward1=interrupt)
+        drv.quantize({k: T[v] for k, v in MIXED.items()})
+        trees.append(d)
+        counts.append(n_calls[0])
+    n = len(ids)
+    assert counts == [1 + n, 2 * n]  # forward #1: the first sample only | every sample; forward #2: every sample
+    for name in sorted(os.listdir(trees[0])):
+        a = torch.load(os.path.join(trees[0], name, "data.pth"), weights_only=True)
+        b = torch.load(os.path.join(trees[1], name, "data.pth"), weights_only=True)
+        for k in a:
+            assert (a[k] == b[k]) if k == "q_type" else torch.equal(a[k], b[k]), (name, k)
+    assert sorted(os.listdir(trees[0])) == sorted(os.listdir(trees[1]))
+
+
+def test_vocab_tail_codellama_granite_and_pair_merges(tmp_path):
+    """the rest of LlamaModel.set_vocab (reference pack_gptq_into_gguf.py:2138-2158) -- the CodeLlama
+    fill-in-the-middle ids (vocab 32016), granite's add_bos_token = False (vocab 49152, a duplicate key raises like gguf-py) --
+    and merges given as [a, b] pairs, whose inner spaces gguf-py's SpecialVocab encodes as chr(ord(' ') + 256)."""
+    from gptq_gguf_toolkit_amd.gguf_writer import GGUFWriter
+    from gptq_gguf_toolkit_amd.pack_gptq_into_gguf import add_tokenizer
+    d = tmp_path / "hf"
+    d.mkdir()
+    vocab = {"a": 0, "b": 1, "Ġc": 2, "ab": 3}
+    (d / "tokenizer.json").write_text(json.dumps({"added_tokens": [{"id": 4, "content": "<|x|>", "special": True}],
+                                                  "model": {"type": "BPE", "vocab": vocab, "merges": [["a", "b"], ["a b", "c"], "b c"]}}))
+    (d / "tokenizer_config.json").write_text(json.dumps({"add_prefix_space": False}))
+
+    def kv_of(vs):
+        w = GGUFWriter(str(tmp_path / "x.gguf"), "llama")
+        add_tokenizer(w, d, vs)
+        return {k: v for k, _, v, _ in w.kv}, [k for k, *_ in w.kv]
+    kv, order = kv_of(32016)
+    assert kv["tokenizer.ggml.merges"] == ["a b", "aĠb c", "b c"]
+    assert [kv[f"tokenizer.ggml.{t}_token_id"] for t in ("prefix", "suffix", "middle", "eot")] == [32007, 32008, 32009, 32010]
+    assert order.index("tokenizer.ggml.eot_token_id") < order.index("tokenizer.ggml.add_space_prefix")  # :2138 before :2150
+    kv, order = kv_of(49152)
+    assert kv["tokenizer.ggml.add_bos_token"] is False and order[-1] == "tokenizer.ggml.add_bos_token"
+    assert "tokenizer.ggml.prefix_token_id" not in kv
+    (d / "tokenizer_config.json").write_text(json.dumps({"add_bos_token": True}))
+    with pytest.raises(ValueError, match="Duplicated key"):
+        kv_of(49152)
+    kv, _ = kv_of(5)
+    assert "tokenizer.ggml.prefix_token_id" not in kv and kv["tokenizer.ggml.add_bos_token"] is True
