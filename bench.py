@@ -540,7 +540,8 @@ def build_model(cfg_kw, dev, dtype=torch.bfloat16, seed=0):
     return model
 
 
-def whole_model_run(wl, dev, world, rank, save_root=None, nseq=None, L=None, layers=None, calib_batch=1, fused="exact"):
+def whole_model_run(wl, dev, world, rank, save_root=None, nseq=None, L=None, layers=None, calib_batch=1, fused="exact",
+                    reference_cadence=False):
     """Quantizer.quantize on a random-init Llama of the workload's architecture (the reference's timed region,
     quant.py:251-254) -> dict with wall seconds, Mparams/s and the split."""
     from gptq_gguf_toolkit_amd.quantizer import Quantizer
@@ -572,7 +573,10 @@ def whole_model_run(wl, dev, world, rank, save_root=None, nseq=None, L=None, lay
     drv = Quantizer(model, data_loader=data, quantizable_modules=r".*layers.*((q|k|v|o|gate|up|down)_proj)$",
                     quantizer_kwargs=dict(QUANTIZER_KW, verbose=False), pre_block_modules=["model.embed_tokens"],
                     block_modules="model.layers", post_block_modules=["lm_head"], quant_non_block_modules=True,
-                    device=str(dev), save_dir=save_dir, calibration_batch=calib_batch, fused_forward=fused)
+                    device=str(dev), save_dir=save_dir, calibration_batch=calib_batch, fused_forward=fused,
+                    # reference_cadence: two FULL forwards per block, as the reference runs it (quantizer.py:150-172);
+                    # default: forward #1 stops at the last hooked Linear -- same saved bytes (tests/test_gpu_forward.py)
+                    interrupt_forward1=not reference_cadence)
     params = sum(p.numel() for n, p in model.named_parameters() if p.dim() == 2)
     os.environ.setdefault("GQ_TIMING", "gpu")  # HIP-event split per phase next to the host-side one (read once, at the end)
     try:
@@ -610,6 +614,8 @@ def whole_model_run(wl, dev, world, rank, save_root=None, nseq=None, L=None, lay
                        "exact": "HF modules with the bit-exact HIP kernels (rotary embedding, SwiGLU, RMSNorm in ATen's "
                                 "summation order, verified at run time): same saved bytes as HF eager",
                        "all": "as exact; RMSNorm through the free-order kernel (<= 2 ulp) where the ordered one is not verified"}[drv.fused_forward],
+           "block_forwards": ("two full forwards per block (reference quantizer.py:150-172)" if reference_cadence else
+                              "forward #1 stops at the last hooked Linear (the reference discards its output too); forward #2 in full"),
            "calib": f"{nseq}x{L} synthetic ids ({len(ids)} sequences on this rank), {calib_batch} per block forward"
                     + (" (the reference's cadence)" if calib_batch == 1 else " (--calibration_batch: same Hessian sums, fewer and larger GEMMs)"),
            "params_quantized_M": round(params / 1e6, 1),
@@ -731,7 +737,7 @@ def main():
     _cabi.prof_enable(["syrk", "trailing_far_gemm32"])
     keep = {}
     sched = None
-    coll0 = dict(dist_utils.collective_calls)
+    coll0, collb0 = dict(dist_utils.collective_calls), dict(dist_utils.collective_bytes)
     t0 = time.perf_counter()
     for i in range(args.steps):
         sched = block_step(wl, layers, W16, X, keep=keep if i == args.steps - 1 else None)
@@ -742,6 +748,7 @@ def main():
     # data-path collectives one step issued on this rank (N > 1: one all-reduce per distinct Hessian, ONE all-gather of
     # the block's results, no broadcast -- asserted by tests/test_gpu_round3.py)
     coll = {k: (v - coll0.get(k, 0)) / args.steps for k, v in dist_utils.collective_calls.items()}
+    coll_bytes = {k: (v - collb0.get(k, 0)) / args.steps for k, v in dist_utils.collective_bytes.items()}
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -819,6 +826,7 @@ def main():
             "ranks_seen": ranks_seen, "collective_backend": (f"{args.backend} (RCCL over xGMI)" if args.backend == "nccl"
                                                              else args.backend) if world > 1 else None,
             "collectives_per_step": coll if world > 1 else None,
+            "collective_bytes_per_step": coll_bytes if world > 1 else None,  # this rank's payloads
             "allreduce_probe": ar_probe, "schedule": sched.stats,
             "wall_s_llama3_8b_32_blocks_extrapolated": round(dt / args.steps * 32, 2)
             if args.workload.startswith("llama3-8b") else None,
@@ -840,7 +848,7 @@ def main():
         for key, cb, fused in (("whole_model", 1, "exact"), ("whole_model_hf_eager", 1, "off"), ("whole_model_batch4", 4, "exact")):
             try:
                 wm[key] = whole_model_run(WORKLOADS["llama3-8b-model-q4k"], dev, world, rank, layers=args.layers, calib_batch=cb,
-                                          fused=fused)
+                                          fused=fused, reference_cadence=(fused == "off"))
             except Exception as e:  # the bench line must still print
                 wm[key] = {"error": repr(e)}
         if rank == 0:

@@ -341,6 +341,8 @@ class BlockSchedule:
             elif h.H is not None or h._fill > 0:
                 v[i] = i
         mine = v.clone()
+        dist_utils.collective_calls["small_all_reduce"] += 1
+        dist_utils.collective_bytes["small_all_reduce"] += v.numel() * 8
         torch.distributed.all_reduce(v, op=torch.distributed.ReduceOp.MAX)
         got, mine = v.tolist(), mine.tolist()
         for i, n in enumerate(names):
@@ -358,7 +360,11 @@ class BlockSchedule:
         """-> {name: (qweight, super_group_scale, group_scale_quant, super_group_zero, group_zero_quant)} on every
         rank, in the reference's order (gptq.py:295); with `writeback` the dequantized matrix replaces
         layer.weight.data (quantizer.py:257-264).  `extra(name, handle, result)` runs on the chain's stream right
-        after a Linear's column loop on the rank that computed it (bench.py packs the GGUF bytes there)."""
+        after a Linear's column loop on the rank that computed it (bench.py packs the GGUF bytes there).
+
+        (Measured and removed, r04: a deferred join -- the caller's stream runs the attention half of forward #2 behind the
+        attention chains while the MLP chains are still going, DESIGN.md 6b -- the down_proj chain, ~1500 small dependent
+        launches, takes 3x as long next to the forward's GEMMs as alone: quant_group + forward #2 5.35 s against 5.2 s.)"""
         handles = self.handles
         world, rank = dist_utils.get_world_size(), dist_utils.get_rank()
         for n, h in handles.items():
@@ -376,6 +382,15 @@ class BlockSchedule:
             if any(h.allow_no_samples for h in handles.values()):
                 self._agree_on_sharing()
             self.owners = {n: (f"rows/{world}" if h._row_split_active() else h.owner_rank) for n, h in handles.items()}
+            # reduce-to-owner (SURVEY section 5 iii): a Hessian whose Linears -- the leader and its followers -- all belong to
+            # ONE rank is needed there only; row-split matrices are factorised by every rank: all-reduce
+            need: Dict[int, set] = {}
+            for n, h in handles.items():
+                lead = h.shared_H_with or h
+                need.setdefault(id(lead), set()).update(range(world) if h._row_split_active() else (h.owner_rank,))
+            for h in self.leaders():
+                ranks = need.get(id(h), set())
+                h.reduce_to = next(iter(ranks)) if len(ranks) == 1 else None
         dev = next(iter(handles.values())).W_device
         on_gpu = torch.device(dev).type == "cuda"
         main = torch.cuda.current_stream(dev) if on_gpu else None

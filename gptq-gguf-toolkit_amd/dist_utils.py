@@ -9,7 +9,10 @@ import torch.distributed as dist
 
 # data-path collectives issued by this process (tests and bench.py read it: "one all-reduce per distinct Hessian and
 # one all-gather per block" is asserted, not only claimed)
-collective_calls: Dict[str, int] = {"all_reduce": 0, "all_gather": 0, "broadcast": 0}
+collective_calls: Dict[str, int] = {"all_reduce": 0, "reduce": 0, "all_gather": 0, "broadcast": 0, "small_all_reduce": 0}
+# bytes this rank handed to them (the Hessian payloads and the packed results; "small_all_reduce" = the few-byte ones:
+# per-expert sample counts, the MoE sharing agreement)
+collective_bytes: Dict[str, int] = {"all_reduce": 0, "reduce": 0, "all_gather": 0, "broadcast": 0, "small_all_reduce": 0}
 
 
 def is_dist_available_and_initialized() -> bool:
@@ -44,9 +47,25 @@ def shard_calibration(data: Sequence, rank: int, world_size: int) -> list:
     return list(data[rank * n:(rank + 1) * n])
 
 
-def allreduce_hessian(H, num_samples=None):
+def _avg(payload, dst=None):
+    """AVG over the ranks, to every rank or -- `dst` -- to that rank only (half the bytes on every link of a ring)."""
+    if dst is None:
+        dist.all_reduce(payload, op=dist.ReduceOp.AVG)
+        return
+    try:
+        dist.reduce(payload, dst=dst, op=dist.ReduceOp.AVG)
+    except (RuntimeError, ValueError):  # a backend without AVG for reduce: SUM, divided where the result lives
+        dist.reduce(payload, dst=dst, op=dist.ReduceOp.SUM)
+        if get_rank() == dst:
+            payload.div_(get_world_size())
+
+
+def allreduce_hessian(H, num_samples=None, dst=None):
     """One collective per distinct Hessian (reference gptq.py:131-132: all_reduce AVG).
     Backend 'nccl' is RCCL over xGMI on ROCm; 'gloo' in the CPU tests.
+
+    `dst`: REDUCE TO OWNER (SURVEY section 5 iii) -- once the Linears are fanned out, a Hessian whose Linears all belong to one
+    rank is needed there only: `dist.reduce` instead of the reference's all_reduce; H is valid on `dst` alone afterwards.
 
     `num_samples` (this rank's sample count behind H) makes the reduction sample-weighted when the ranks saw
     DIFFERENT counts -- MoE experts receive a data-dependent number of tokens per rank, and
@@ -65,20 +84,27 @@ def allreduce_hessian(H, num_samples=None):
     else:
         payload = H
     total = None
-    collective_calls["all_reduce"] += 1
+    kind = "all_reduce" if dst is None else "reduce"
+    collective_calls[kind] += 1
+    collective_bytes[kind] += payload.numel() * payload.element_size()
     if num_samples is None:
-        dist.all_reduce(payload, op=dist.ReduceOp.AVG)
+        _avg(payload, dst)
     else:
         counts = torch.zeros(get_world_size(), dtype=torch.float64, device=H.device)
         counts[get_rank()] = float(num_samples)
+        collective_calls["small_all_reduce"] += 1
+        collective_bytes["small_all_reduce"] += counts.numel() * 8
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)  # (a few bytes: the sample counts of an MoE expert)
         total = int(counts.sum().item())
         if bool((counts == counts[0]).all()):
-            dist.all_reduce(payload, op=dist.ReduceOp.AVG)
+            _avg(payload, dst)
         elif total > 0:
             payload.mul_(float(num_samples) / total)
-            dist.all_reduce(payload, op=dist.ReduceOp.SUM)
-    if packed:
+            if dst is None:
+                dist.all_reduce(payload, op=dist.ReduceOp.SUM)
+            else:
+                dist.reduce(payload, dst=dst, op=dist.ReduceOp.SUM)
+    if packed and (dst is None or dst == get_rank()):
         ops.h_unpack_upper(payload, H)
     return total
 
@@ -150,6 +176,7 @@ def all_gather_rows(part, rows: int, chunk: int):
 def _all_gather_into(out, inp) -> None:
     """out[r * n : (r + 1) * n] = rank r's inp (n = inp.numel()), ONE collective, no list of temporaries."""
     collective_calls["all_gather"] += 1
+    collective_bytes["all_gather"] += inp.numel() * inp.element_size()
     try:
         dist.all_gather_into_tensor(out.view(-1), inp.view(-1))
     except (RuntimeError, NotImplementedError):  # a backend without the tensor form: views of `out` as the list

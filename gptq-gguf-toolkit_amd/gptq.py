@@ -45,6 +45,7 @@ class GPTQ:
         # --- beyond the reference ---
         self.owner_rank = 0            # rank that runs step(); the reference hard-codes rank 0 (gptq.py:158)
         self.row_split = False         # every rank runs step() on its own rows (dist_utils.row_split_names)
+        self.reduce_to = None          # the ONE rank that needs this handle's reduced H (None: every rank -> all-reduce)
         # MoE experts may receive no calibration token at all: with allow_no_samples the handle then uses H = I
         # (round-to-nearest with the lazily computed scales) instead of the reference's assertion (gptq.py:126)
         self.allow_no_samples = allow_no_samples
@@ -195,6 +196,7 @@ class GPTQ:
         self.no_samples = False
         self.owner_rank = 0
         self.row_split = False
+        self.reduce_to = None
 
     # ------------------------------------------------------------------- quantize
     @torch.no_grad()
@@ -224,12 +226,13 @@ class GPTQ:
         if not self._reduced:
             if self.allow_no_samples:
                 # experts: sample-weighted when the ranks' token counts differ (costs one host read of the counts)
-                total = dist_utils.allreduce_hessian(self.H, self.num_samples)
+                total = dist_utils.allreduce_hessian(self.H, self.num_samples, dst=self.reduce_to)
                 if total == 0:
                     self.H = torch.eye(self.d_col, device=self.W_device, dtype=torch.float32)
                     self.no_samples = True
             else:
-                dist_utils.allreduce_hessian(self.H)  # every dense Linear: the reference's AVG, no host sync
+                # every dense Linear: the reference's AVG, no host sync (reduce_to: to the one rank that needs it)
+                dist_utils.allreduce_hessian(self.H, dst=self.reduce_to)
             self._reduced = True
 
     @torch.no_grad()

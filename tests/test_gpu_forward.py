@@ -226,9 +226,11 @@ def _llama512(dtype):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_default_forward_level_saves_the_same_bytes_as_hf_eager(tmp_path, dtype):
-    """The Quantizer's default (fused_forward="exact": rotary embedding, SwiGLU and the order-matched RMSNorm kernel) against
-    fused_forward=False on a 16-bit model: every saved tensor and every written-back weight is bit-identical -- the default
-    changes no result.  The RMSNorm kernel must have been verified and used (hidden size 512)."""
+    """The Quantizer's default (fused_forward="exact": rotary embedding, SwiGLU and the order-matched RMSNorm kernel; forward #1
+    stopped at the last hooked Linear) against fused_forward=False and against
+    the reference's cadence (two full forwards per block, quantizer.py:150-172) on a 16-bit model: every saved tensor and every
+    written-back weight is bit-identical -- the defaults change no result.  All three kernels must have been verified and
+    used (hidden size 512)."""
     import hashlib
     from make_golden_shim import tiny_calib
     from gptq_gguf_toolkit_amd import forward_fused
@@ -236,12 +238,14 @@ def test_default_forward_level_saves_the_same_bytes_as_hf_eager(tmp_path, dtype)
     from gptq_gguf_toolkit_amd.quantizer import Quantizer
     forward_fused._norm_verdict.clear()
     digests = {}
-    for level in ("off", "exact"):
+    for level in ("reference_cadence", "off", "exact"):
         save_dir = str(tmp_path / level)
         os.makedirs(save_dir)
         model = _llama512(dtype).cuda()
         data = [([], {"input_ids": ids}) for ids in tiny_calib()]
         kw = {} if level == "exact" else {"fused_forward": False}  # "exact" through the constructor's default
+        if level == "reference_cadence":  # r04: the reference's two full forwards per block, nothing overlapped
+            kw.update(interrupt_forward1=False)
         drv = Quantizer(model, data_loader=data, quantizable_modules=r".*layers.*((q|k|v|o|gate|up|down)_proj)$",
                         quantizer_kwargs=dict(rel_damp=0.01, block_size=128, act_order=False, quant_scale="absmax",
                                               static_groups=False, rmin=-1.0, rdelta=0.1, nstep=20, verbose=False),
@@ -250,9 +254,13 @@ def test_default_forward_level_saves_the_same_bytes_as_hf_eager(tmp_path, dtype)
         drv.quantize({k: T.Q4_K for k in ("q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj",
                                           "embed_tokens", "lm_head")})
         torch.cuda.synchronize()
-        assert drv.fused_forward == level
+        assert drv.fused_forward == ("exact" if level == "exact" else "off")
         names = " ".join(drv._fused_modules)
-        assert (level == "off" and not names) or all(k in names for k in ("apply_rotary_pos_emb", "LlamaMLP", "LlamaRMSNorm"))
+        assert (level != "exact" and not names) or all(k in names for k in ("apply_rotary_pos_emb", "LlamaMLP", "LlamaRMSNorm"))
+        if level == "reference_cadence":
+            assert "forward1_interrupts" not in drv.schedule_stats
+        else:  # forward #1 stopped at down_proj for every sample but the first
+            assert drv.schedule_stats["forward1_interrupts"] == len(data) - 1
         h = hashlib.sha256()
         for n, p in sorted(model.named_parameters()):
             h.update(p.detach().cpu().contiguous().view(torch.uint8).numpy().tobytes())
@@ -263,8 +271,11 @@ def test_default_forward_level_saves_the_same_bytes_as_hf_eager(tmp_path, dtype)
                     v = obj[k]
                     h.update(v.contiguous().view(torch.uint8).numpy().tobytes() if torch.is_tensor(v) else str(v).encode())
         digests[level] = h.hexdigest()
-    assert forward_fused._norm_verdict.get((512, dtype)) is True  # the ordered kernel matched HF eager and was used
-    assert digests["off"] == digests["exact"]
+    # the three kernels matched HF eager on the run's own first inputs and were used
+    assert any(k[:2] == (512, dtype) and v for k, v in forward_fused._norm_verdict.items())
+    assert forward_fused._rope_verdict and all(forward_fused._rope_verdict.values())
+    assert forward_fused._mlp_verdict and all(forward_fused._mlp_verdict.values())
+    assert digests["reference_cadence"] == digests["off"] == digests["exact"]
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -446,7 +446,9 @@ def test_two_rank_gloo_matches_single_rank(tmp_path):
     # the data-path collectives of the two blocks: one all-reduce per DISTINCT Hessian (4 per block; the reference: 7),
     # ONE all-gather per block for all results (the reference: 5 broadcasts per Linear), no broadcast
     for c in (calls0, calls1):
-        assert (c["coll_all_reduce"], c["coll_all_gather"], c["coll_broadcast"]) == (8, 2, 0), c
+        # (r04: a Hessian whose Linears all have ONE owner travels as a reduce to that rank, SURVEY section 5 iii)
+        assert (c["coll_all_reduce"] + c["coll_reduce"], c["coll_all_gather"], c["coll_broadcast"]) == (8, 2, 0), c
+        assert c["coll_reduce"] >= 2, c
     d1 = str(tmp_path / "w1")
     os.makedirs(d1)
     data = [([], {"input_ids": ids}) for ids in tiny_calib()]
