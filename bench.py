@@ -219,10 +219,10 @@ def trailing_update_legs(wl, W16, X, in_region):
         U, _ = ops.h_prepare(H, W16[name].float(), 0.01)
         del H, xs
         B = 128
-        sb = B * int(os.environ.get("GQ_LA", "8"))  # columns per look-ahead super-block (gq_gptq.hip LA)
+        sb = B * int(ops.option_get("la"))  # columns per look-ahead super-block (gq_gptq.hip LA)
         far = sum(2.0 * R * (min(s0 + sb, C) - s0) * (C - min(s0 + sb, C)) for s0 in range(0, C, sb))
         near_all = sum(2.0 * R * B * (min((c1 // sb + 1) * sb, C) - (c1 + B)) for c1 in range(0, C, B))
-        if os.environ.get("GQ_NEAR_CLASSIC") or os.environ.get("GQ_NEAR_LEFT"):
+        if ops.option_get("near_classic"):
             near, fused = near_all, 0.0
         else:
             # r03: an even block's errors reach its partner block inside the column-loop kernel (not a GEMM launch: its
@@ -284,6 +284,12 @@ def trailing_update_legs(wl, W16, X, in_region):
             out["far_in_region"] = {"achieved": round(a, 2), "frac": round(a / PEAK_F32_MFMA_TFLOPS, 4),
                                     "launches": in_region[1], "ms_per_step": round(in_region[0] / in_region[3], 3),
                                     "note": "all Linears of the block, sum of launch durations, other chains running"}
+            if in_region[2]:
+                # the chains overlap: two far GEMMs that share the chip each take twice as long, and the SUM of their durations
+                # counts that time twice.  Over the UNION of the launch intervals (how the SYRK's roofline is taken):
+                u = far_all * in_region[3] / (in_region[2] * 1e-3) / 1e12
+                out["far_in_region"].update({"achieved_over_busy_time": round(u, 2), "frac_over_busy_time": round(u / PEAK_F32_MFMA_TFLOPS, 4),
+                                             "busy_ms_per_step": round(in_region[2] / in_region[3], 3)})
         return out
     except Exception as e:  # the bench line must still print
         return {"error": repr(e)}
@@ -645,11 +651,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-whole-model", action="store_true", help="skip the whole-model leg of the block workloads")
     ap.add_argument("--no-side-legs", action="store_true", help="skip trailing_update / tolerance_parity legs")
+    ap.add_argument("--no-stagger", action="store_true", help="A/B: all chains of a block start together (r03's schedule)")
     ap.add_argument("--breakdown", action="store_true", help="one extra profiled step: per-kernel ms to stderr")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend: nccl (= RCCL over xGMI, default); gloo only to exercise the "
                          "N>1 code path with several ranks sharing one GPU")
     args = ap.parse_args()
+    if args.no_stagger:
+        BlockSchedule.stagger_chains = False
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -11,13 +11,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.environ.get("GQ_SO_PATH") or os.path.join(CSRC, "libgptqgguf_hip.so")  # override: kernel A/B probes
 
-ABI_VERSION = 3  # include/gptq_gguf.h GQ_ABI_VERSION this binding was written against
+ABI_VERSION = 4  # include/gptq_gguf.h GQ_ABI_VERSION this binding was written against
 F32, F16, BF16 = 0, 1, 2
 WS_H_ACCUMULATE, WS_H_PREPARE, WS_GPTQ_QUANTIZE, WS_CHOL_GEMM = 1, 2, 3, 4
 
 EXPORTS = (
-    "gq_abi_version", "gq_last_error", "gq_type_info", "gq_workspace_bytes", "gq_h_accumulate", "gq_h_accumulate_grouped", "gq_h_accumulate_segments", "gq_h_stage", "gq_h_prepare", "gq_w_prepare", "gq_h_pack_upper", "gq_h_unpack_upper",
-    "gq_scale_search", "gq_group_search", "gq_gptq_quantize", "gq_gptq_quantize_perm", "gq_gptq_uses_helper_stream", "gq_far_helper_enable", "gq_syrk_workgroups", "gq_obq_h_prepare", "gq_obq_quantize", "gq_rtn_quantize", "gq_dequantize", "gq_pack", "gq_trailing_update", "gq_chol_gemm", "gq_stage_to_host", "gq_fwd_rmsnorm", "gq_fwd_rmsnorm_ordered", "gq_fwd_rope", "gq_fwd_silu_mul",
+    "gq_abi_version", "gq_last_error", "gq_option_count", "gq_option_name", "gq_option_get", "gq_option_default", "gq_option_set", "gq_type_info", "gq_workspace_bytes", "gq_h_accumulate", "gq_h_accumulate_grouped", "gq_h_accumulate_segments", "gq_h_stage", "gq_h_prepare", "gq_w_prepare", "gq_h_pack_upper", "gq_h_unpack_upper",
+    "gq_scale_search", "gq_group_search", "gq_gptq_quantize", "gq_gptq_quantize_perm", "gq_gptq_uses_helper_stream", "gq_far_helper_enable", "gq_obq_h_prepare", "gq_obq_quantize", "gq_rtn_quantize", "gq_dequantize", "gq_pack", "gq_trailing_update", "gq_chol_gemm", "gq_stage_to_host", "gq_fwd_rmsnorm", "gq_fwd_rmsnorm_ordered", "gq_fwd_rope", "gq_fwd_silu_mul",
     "gq_prof_enable", "gq_prof_ntags", "gq_prof_name", "gq_prof_collect", "gq_prof_collect2",
 )
 
@@ -68,6 +68,11 @@ def lib():
         raise GQError(f"{SO_PATH} has ABI version {L.gq_abi_version()}, this package binds version {ABI_VERSION}: rebuild "
                       f"(`make -C {CSRC}`)")
     L.gq_last_error.restype = ctypes.c_char_p
+    L.gq_option_name.restype = ctypes.c_char_p
+    L.gq_option_name.argtypes = [ci]
+    L.gq_option_get.argtypes = [ctypes.c_char_p, ctypes.POINTER(i64)]
+    L.gq_option_default.argtypes = [ctypes.c_char_p, ctypes.POINTER(i64)]
+    L.gq_option_set.argtypes = [ctypes.c_char_p, i64, ctypes.POINTER(i64)]
     L.gq_type_info.argtypes = [ci, ctypes.POINTER(TypeInfo)]
     L.gq_workspace_bytes.argtypes = [ci, i64, i64, i64, ci]
     L.gq_workspace_bytes.restype = sz
@@ -85,7 +90,6 @@ def lib():
     L.gq_gptq_quantize_perm.argtypes = [vp, vp, i64, i64, ci, ci, vp, vp, vp, vp, vp, vp, vp, sz, vp]
     L.gq_gptq_uses_helper_stream.argtypes = [i64, i64, ci]
     L.gq_far_helper_enable.argtypes = [ci]
-    L.gq_syrk_workgroups.argtypes = [ci]
     L.gq_obq_h_prepare.argtypes = L.gq_h_prepare.argtypes
     L.gq_obq_quantize.argtypes = [vp, vp, i64, i64, ci, ci, ci, ci, vp, vp, vp, vp, sz, vp]
     L.gq_rtn_quantize.argtypes = [vp, ci, i64, i64, ci, sp, vp, vp, vp, vp, vp, vp]
@@ -148,3 +152,46 @@ def prof_collect(busy: bool = False) -> dict:
     if busy:
         return {L.gq_prof_name(i).decode(): (ms[i], cnt[i], bz[i]) for i in range(n) if cnt[i]}
     return {L.gq_prof_name(i).decode(): (ms[i], cnt[i]) for i in range(n) if cnt[i]}
+
+
+# ---- library options (include/gptq_gguf.h lists them): tuning and test switches, process-wide ----
+def option_names():
+    L = lib()
+    return [L.gq_option_name(i).decode() for i in range(L.gq_option_count())]
+
+
+def option_get(name: str) -> int:
+    v = ctypes.c_int64()
+    check(lib().gq_option_get(name.encode(), ctypes.byref(v)), "gq_option_get")
+    return int(v.value)
+
+
+def option_default(name: str) -> int:
+    v = ctypes.c_int64()
+    check(lib().gq_option_default(name.encode(), ctypes.byref(v)), "gq_option_default")
+    return int(v.value)
+
+
+def option_set(name: str, value: int) -> int:
+    """-> the previous value."""
+    prev = ctypes.c_int64()
+    check(lib().gq_option_set(name.encode(), int(value), ctypes.byref(prev)), "gq_option_set")
+    return int(prev.value)
+
+
+class options:
+    """`with options(chol_fp32=1, chol_3p_min=0): ...` -- sets library options for the block (None: the default) and restores
+    the previous values on exit.  Process-wide: calls enqueued from other threads meanwhile see them too."""
+
+    def __init__(self, **kv):
+        self.kv, self.prev = kv, {}
+
+    def __enter__(self):
+        for k, v in self.kv.items():
+            self.prev[k] = option_set(k, option_default(k) if v is None else v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.prev.items():
+            option_set(k, v)
+        return False

@@ -15,7 +15,7 @@ schedules kernels:
                quantize() time on a side stream, UNDER the widest input's factorisation and column loop,
                which are chains of small dependent launches that leave the matrix cores idle (-0.7 % per
                step for 6 GB of kept activations: off by default).
-  quantize()   phase 0  the remaining tokens are folded in (the postponed narrow inputs on a side stream);
+  quantize()   phase 0  the remaining tokens are folded in;
                         [N>1] ONE all-reduce per distinct Hessian, widest first (gptq.py:131-132 does one per
                         handle);
                phase 1  every input group is an independent chain (h_prepare -> per Linear: working copy,
@@ -99,6 +99,10 @@ def _zero_columns(w: torch.Tensor) -> torch.Tensor:
 
 class BlockSchedule:
     unverified: List[torch.Tensor] = []  # device flags of speculative U reuses, see verify()
+    # r04: the other chains start when the COSTLIEST chain's factorisation is through (an event between its gq_h_prepare
+    # and its column loop) instead of next to it: the widest Hessian's chain of ~560 small dependent launches takes 25 ms
+    # next to three other chains' GEMMs and 14.6 ms alone, and what the others have to do fits under its column loop
+    stagger_chains = True
 
     def __init__(self, layers: Dict[str, nn.Module], make_handle: Callable[[nn.Module, str], GPTQ],
                  n_streams: Optional[int] = None, verbose: bool = False):
@@ -115,9 +119,6 @@ class BlockSchedule:
         self.verbose = verbose
         self.stats = {"syrk_launches": 0, "allreduce_bytes": 0, "reused_U": 0, "own_U": 0, "refactorised": 0}
         self.owners: Dict[str, Any] = {}  # name -> owner rank or "rows/<world>" of the last quantize()
-        # postponed folds of the narrow inputs (single rank): on / off, and the bytes of activations it may keep
-        self.defer_narrow = os.environ.get("GQ_DEFER_NARROW", "0") == "1"
-        self.defer_bytes = int(float(os.environ.get("GQ_DEFER_GB", 48)) * 2 ** 30)
 
     # ------------------------------------------------------------------ hook side
     def hook(self, name: str):
@@ -167,8 +168,8 @@ class BlockSchedule:
         self._fired = []
         if self._sharing is None:
             self._publish_sharing()
-        if any(h._fill - h._marked >= h.flush_tokens for h in self.handles.values()):
-            self.flush(postpone=True)
+        if any(h._fill >= h.flush_tokens for h in self.handles.values()):
+            self.flush()
 
     def _publish_sharing(self) -> None:
         """After the block's first sample: for every follower, "its weight's all-zero columns differ from its
@@ -244,75 +245,28 @@ class BlockSchedule:
     def leaders(self) -> List[GPTQ]:
         return [h for h in self.handles.values() if h.shared_H_with is None]
 
-    def _postponable(self, todo: List[GPTQ]) -> List[GPTQ]:
-        """The narrow inputs whose fold may wait for quantize(): single rank, a strictly widest input exists,
-        everything pending is a kept reference (nothing staged), and the kept bytes fit the budget."""
-        if not self.defer_narrow or len(todo) < 2 or dist_utils.get_world_size() > 1:
-            return []
-        if todo[0].d_col <= todo[1].d_col or torch.device(todo[0].W_device).type != "cuda" or self.n_streams < 2:
-            return []
-        rest = todo[1:]
-        if any(h._staged or not h._segs for h in rest):
-            return []
-        kept = sum(x.numel() * x.element_size() for h in rest for x, _, _ in h._segs)
-        return rest if kept <= self.defer_bytes else []
-
-    def _fold(self, grids: List[List[GPTQ]], upto: Optional[Dict[int, int]] = None) -> List[Any]:
-        """One grouped SYRK launch per grid (on the current stream); returns the activation blocks it reads."""
-        read = []
+    def _fold(self, grids: List[List[GPTQ]]) -> None:
+        """One grouped SYRK launch per grid (on the current stream)."""
         for grp in grids:
-            args = [h._flush_args(None if upto is None else upto[id(h)]) for h in grp]
+            args = [h._flush_args() for h in grp]
             _ops.h_accumulate_grouped([a[0] for a in args], [a[1] for a in args], [a[2] for a in args],
                                       [a[3] for a in args])
             self.stats["syrk_launches"] += 1
-            read += [a[1] for a in args]
             for h in grp:
-                h._flush_done(None if upto is None else upto[id(h)])
-        return read
+                h._flush_done()
 
-    def _fold_postponed(self) -> List[Any]:
-        """The postponed folds of the narrow inputs, portion by portion exactly as sample_done() would have issued
-        them (same launches, same order per Hessian: bit-identical H), on the current stream."""
-        read = []
-        while True:
-            todo = [h for h in self.leaders() if h._marks]
-            if not todo:
-                return read
-            todo.sort(key=lambda h: (-h.d_col, id(h)))
-            upto = {id(h): h._marks[0] for h in todo}
-            by_kind: Dict[Any, List[GPTQ]] = {}
-            for h in todo:
-                by_kind.setdefault((h._pending_dtype(), h._pending_device()), []).append(h)
-            grids = [grp[i:i + 8] for grp in by_kind.values() for i in range(0, len(grp), 8)]
-            read += self._fold(grids, upto)
-            for h in todo:
-                first = h._marks.pop(0)
-                h._marks = [m - first for m in h._marks]
-
-    def flush(self, postpone: bool = False) -> None:
+    def flush(self) -> None:
         """Fold every leader's buffered activations into its Hessian: grouped SYRK launches (<= 8 problems per
         grid, one activation dtype per grid), the narrow inputs first and the widest input alone -- its tiles
         fill the chip for ~5 ms per 64 Ki tokens, nothing is gained by mixing it with the others.
-        `postpone` (sample_done): the narrow inputs only note where this fold would have ended (_postponable)."""
+        (Measured and removed, r02 / r04: postponing the narrow inputs' folds to quantize(), next to the widest chain --
+        0.7-1 % per step for 6 GB of kept activations)"""
         todo = [h for h in self.leaders() if h._fill > 0]
         if not todo:
             return
         todo.sort(key=lambda h: (-h.d_col, id(h)))
-        later = self._postponable(todo) if postpone else []
-        if later:
-            for h in later:
-                h._marks.append(len(h._segs))
-                h._marked = h._fill
-            self._fold([[todo[0]]])
-            self.stats["postponed_folds"] = self.stats.get("postponed_folds", 0) + 1
-            return
-        if any(h._marks for h in todo):  # postponed portions first, in their own launches (never merged with newer tokens)
-            self._fold_postponed()
-            todo = [h for h in todo if h._fill > 0]
-            if not todo:
-                return
         grids: List[List[GPTQ]] = []
-        if len(todo) > 1 and todo[0].d_col > todo[1].d_col and not os.environ.get("GQ_SYRK_ONE_GRID"):
+        if len(todo) > 1 and todo[0].d_col > todo[1].d_col:
             rest, grids_tail = todo[1:], [[todo[0]]]
         else:
             rest, grids_tail = todo, []
@@ -397,33 +351,6 @@ class BlockSchedule:
 
         # ---- phase 0: the rest of the tokens, then one all-reduce per distinct Hessian, widest first
         ready: Dict[int, Any] = {}
-        held: List[Any] = []
-        late = [h for h in self.leaders() if h._marks]
-        side = _chain_streams(dev, self.n_streams - 1)[:1] if on_gpu and late else []
-        if side:
-            # the postponed narrow inputs: every portion on the first side stream, next to the widest chain; their
-            # last tokens ride along as one more portion.  The kept activation tensors stay referenced until the
-            # lanes have joined the caller's stream (they were allocated on it).
-            entry = torch.cuda.Event()
-            entry.record(main)
-            wide = [h for h in self.leaders() if h._fill > 0 and not h._marks]
-            for h in late:
-                if len(h._segs) > h._marks[-1]:
-                    h._marks.append(len(h._segs))
-            side[0].wait_event(entry)
-            with torch.cuda.stream(side[0]):
-                # fewer resident SYRK workgroups than CUs: the widest chain's kernels always find free ones
-                prev = _ops.syrk_workgroups(int(os.environ.get("GQ_DEFER_WGS", "192")))
-                try:
-                    held = self._fold_postponed()
-                finally:
-                    _ops.syrk_workgroups(prev)
-                folded = torch.cuda.Event()
-                folded.record(side[0])
-            for h in late:
-                ready[id(h)] = folded
-            if wide:
-                self._fold([[h] for h in sorted(wide, key=lambda h: -h.d_col)])
         self.flush()
         for h in sorted(self.leaders(), key=lambda h: -h.d_col):
             h.sync_hessian()
@@ -452,7 +379,7 @@ class BlockSchedule:
         own = self._needs_own_factorisation()
         order = sorted(chains.values(), key=chain_cost)
         # the costliest chain stays on the caller's stream (it ends last anyway), the others get side streams
-        on_main = 1 if os.environ.get("GQ_CHAIN_MAIN", "1") == "1" else 0
+        on_main = 1
         # a chain whose column loop keeps its far updates on the library's helper stream brings a hardware queue
         # of its own: one lane fewer here (five queues cost more than the overlap gains).  Only when
         # every chain still gets a lane of its own or nearly so (a dense block: 4 chains); a Mixtral block's 20 chains
@@ -466,7 +393,8 @@ class BlockSchedule:
             results: Dict[str, tuple] = {}
             deq: Dict[str, torch.Tensor] = {}
             lanes = []
-            trace = os.environ.get("GQ_SCHED_TRACE")
+            prepared = None
+            trace = "sched" in os.environ.get("GQ_TRACE", "")
             t_host = time.perf_counter()
             # lanes: longest-processing-time-first over all lanes; the costliest chain comes first and lands on lane 0 = the
             # caller's stream (a dense block: four chains over three lanes + the library's helper; a Mixtral block: 20 chains over 4 lanes)
@@ -483,6 +411,12 @@ class BlockSchedule:
                 lane = _Lane(streams[lane_of[k]] if streams else None, main)
                 lead = handles[names[0]].shared_H_with or handles[names[0]]
                 lane.wait(ready.get(id(lead), start))
+                if k > 0 and prepared is not None:
+                    lane.wait(prepared)  # (chain 0 was enqueued first: the event is recorded by now)
+                mark = None
+                if k == 0 and on_gpu and self.stagger_chains and len(order) > 1 and streams and lane.stream is None:
+                    prepared = torch.cuda.Event()
+                    mark = lambda ev=prepared: ev.record(main)  # noqa: E731
                 born = []
                 with lane.run():
                     # the leader first: it factorises, the followers reuse its U
@@ -493,7 +427,8 @@ class BlockSchedule:
                         h.make_working_copy()
                         # follower with the same zero columns as its leader: reuse (flag kept for verify());
                         # different: own factorisation; unknown (first fed after the first sample): checked below
-                        res = h.compute(qtypes[n], defer_check=True, own_U=own.get(n, False))
+                        res = h.compute(qtypes[n], defer_check=True, own_U=own.get(n, False), after_prepare=mark)
+                        mark = None  # once per chain: after the leader's factorisation
                         if n in own and h._pending_mismatch is not None:
                             BlockSchedule.unverified.append(h._pending_mismatch)
                             h._pending_mismatch = None

@@ -31,7 +31,6 @@ int obq_quantize(float*, const float*, int64_t, int64_t, int, int, int, int, uin
                  hipStream_t);
 int gptq_uses_helper_stream(int64_t, int64_t, int);
 int far_helper_enable(int);
-int syrk_workgroups(int);
 int w_prepare(const uint8_t*, float*, int64_t, int64_t, int*, hipStream_t);
 int h_pack_upper(const float*, int64_t, float*, hipStream_t);
 int h_unpack_upper(const float*, int64_t, float*, hipStream_t);
@@ -47,10 +46,58 @@ int fwd_silu_mul(const void*, const void*, void*, int64_t, int, hipStream_t);
 
 #include <algorithm>
 #include <mutex>
+#include <string>
 #include <utility>
 #include <vector>
 
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
+
 namespace gq {
+// ---- the option table (gq_common.hpp GQ_OPTION_LIST) ----
+namespace {
+struct OptEntry { const char* name; int64_t def; };
+const OptEntry g_opt_table[OPT_COUNT] = {
+#define GQ_X(name, def) {#name, (int64_t)(def)},
+    GQ_OPTION_LIST(GQ_X)
+#undef GQ_X
+};
+std::atomic<int64_t> g_opt[OPT_COUNT];
+std::once_flag g_opt_once;
+int opt_index(const char* name) {
+    for (int i = 0; i < OPT_COUNT; ++i)
+        if (!strcmp(g_opt_table[i].name, name)) return i;
+    return -1;
+}
+void opt_init() {
+    for (int i = 0; i < OPT_COUNT; ++i) g_opt[i].store(g_opt_table[i].def, std::memory_order_relaxed);
+    const char* e = getenv("GQ_OPTIONS");  // "name=value,name=value": the library's ONE tuning variable
+    if (!e) return;
+    std::string s(e);
+    size_t pos = 0;
+    while (pos < s.size()) {
+        size_t end = s.find(',', pos);
+        if (end == std::string::npos) end = s.size();
+        const std::string item = s.substr(pos, end - pos);
+        pos = end + 1;
+        const size_t eq = item.find('=');
+        if (item.empty()) continue;
+        const std::string key = eq == std::string::npos ? item : item.substr(0, eq);
+        const int i = opt_index(key.c_str());
+        if (i < 0) {
+            fprintf(stderr, "gq: GQ_OPTIONS names an unknown option '%s'\n", key.c_str());
+            abort();  // a typo must not silently measure the default
+        }
+        g_opt[i].store(eq == std::string::npos ? 1 : strtoll(item.c_str() + eq + 1, nullptr, 0), std::memory_order_relaxed);
+    }
+}
+}  // namespace
+int64_t opt(Opt o) {
+    std::call_once(g_opt_once, opt_init);
+    return g_opt[o].load(std::memory_order_relaxed);
+}
+
 unsigned g_prof_mask = 0;
 namespace {
 struct Rec { hipEvent_t a, b; int tag; hipStream_t st; };
@@ -82,6 +129,29 @@ using namespace gq;
 extern "C" {
 
 int gq_abi_version(void) { return GQ_ABI_VERSION; }
+
+int gq_option_count(void) { return OPT_COUNT; }
+const char* gq_option_name(int i) { return (i >= 0 && i < OPT_COUNT) ? g_opt_table[i].name : nullptr; }
+int gq_option_get(const char* name, int64_t* value) {
+    const int i = name ? opt_index(name) : -1;
+    if (i < 0 || !value) GQ_FAIL(GQ_E_UNSUPPORTED, "gq_option_get: unknown option '%s'", name ? name : "(null)");
+    *value = opt((Opt)i);
+    return GQ_OK;
+}
+int gq_option_set(const char* name, int64_t value, int64_t* previous) {
+    const int i = name ? opt_index(name) : -1;
+    if (i < 0) GQ_FAIL(GQ_E_UNSUPPORTED, "gq_option_set: unknown option '%s'", name ? name : "(null)");
+    const int64_t old = opt((Opt)i);  // (also runs the one-time initialisation)
+    g_opt[i].store(value, std::memory_order_relaxed);
+    if (previous) *previous = old;
+    return GQ_OK;
+}
+int gq_option_default(const char* name, int64_t* value) {
+    const int i = name ? opt_index(name) : -1;
+    if (i < 0 || !value) GQ_FAIL(GQ_E_UNSUPPORTED, "gq_option_default: unknown option '%s'", name ? name : "(null)");
+    *value = g_opt_table[i].def;
+    return GQ_OK;
+}
 const char* gq_last_error(void) { return g_err; }
 
 int gq_type_info(int q_type, gq_type_info_t* out) {
@@ -139,7 +209,6 @@ int gq_h_prepare(float* H, float* W, int64_t R, int64_t C, float rel_damp, float
 
 int gq_gptq_uses_helper_stream(int64_t R, int64_t C, int block_size) { return gptq_uses_helper_stream(R, C, block_size); }
 int gq_far_helper_enable(int on) { return far_helper_enable(on); }
-int gq_syrk_workgroups(int n) { return syrk_workgroups(n); }
 
 int gq_obq_h_prepare(float* H, float* W, int64_t R, int64_t C, float rel_damp, float* U, int* not_invertible,
                      uint8_t* col_flags_out, void* ws, size_t ws_bytes, void* stream) {
@@ -240,8 +309,7 @@ int gq_stage_to_host(void* host_dst, const void* src, int64_t nbytes, void* stre
     if (!host_dst || !src) GQ_FAIL(GQ_E_NULL, "gq_stage_to_host: null pointer");
     void* dptr = nullptr;
     GQ_HIP(hipHostGetDevicePointer(&dptr, host_dst, 0));  // fails unless host_dst is pinned (hipHostRegister / hipHostMalloc)
-    static const int wgs = getenv("GQ_STAGE_HOST_WGS") ? atoi(getenv("GQ_STAGE_HOST_WGS")) : 0;
-    return h_stage(dptr, src, nbytes, (hipStream_t)stream, wgs);
+    return h_stage(dptr, src, nbytes, (hipStream_t)stream, (int)opt(OPT_stage_host_wgs));
 }
 
 int gq_fwd_rmsnorm(const void* x, const void* weight, void* out, int64_t tokens, int64_t C, float eps, int dtype, void* stream) {

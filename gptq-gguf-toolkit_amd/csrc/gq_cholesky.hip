@@ -371,7 +371,6 @@ __global__ __launch_bounds__(256) void diag_potrf_inv_kernel(float* __restrict__
 // LDS rows have an odd stride (129 floats): MFMA operand reads walk rows with stride-1 banks.
 constexpr int LDQ = NB + 1;
 constexpr int TQ = 33;  // wave-private 32x32 scratch tile stride
-constexpr size_t DIAG_BLK_LDS = (size_t)(2 * NB * LDQ + 4 * 32 * TQ) * sizeof(float);
 
 __device__ __forceinline__ float rdlane(float v, int l) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
@@ -529,140 +528,8 @@ __device__ __forceinline__ f32x16 mfma_nt_32(const float* Ap, int lda_, const fl
     return acc;
 }
 
-__global__ __launch_bounds__(256) void diag_blk_kernel(float* __restrict__ A, int64_t lda, float* __restrict__ Xout,
-                                                       int64_t ldx, int* __restrict__ flag) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* S = smem;              // [NB][LDQ]  A (lower) -> L, zeros above the diagonal
-    float* X = smem + NB * LDQ;   // [NB][LDQ]  L^-1 (lower), zeros above
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    float* Tw = X + NB * LDQ + wid * 32 * TQ;  // wave-private scratch tile
-    {   // 16-byte global accesses (lda % 4 == 0).  All 16 loads of a thread are issued before the first LDS write
-        // (one memory latency instead of several); chunks entirely above the diagonal are not read at all.
-        float4 v[NB * NB / 4 / 256];
-#pragma unroll
-        for (int q = 0; q < NB * NB / 4 / 256; ++q) {
-            const int idx = tid + q * 256, r = idx / (NB / 4), c = (idx % (NB / 4)) * 4;
-            v[q] = (c <= r) ? *reinterpret_cast<const float4*>(A + r * lda + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int q = 0; q < NB * NB / 4 / 256; ++q) {
-            const int idx = tid + q * 256, r = idx / (NB / 4), c = (idx % (NB / 4)) * 4;
-            S[r * LDQ + c + 0] = (c + 0 <= r) ? v[q].x : 0.0f;
-            S[r * LDQ + c + 1] = (c + 1 <= r) ? v[q].y : 0.0f;
-            S[r * LDQ + c + 2] = (c + 2 <= r) ? v[q].z : 0.0f;
-            S[r * LDQ + c + 3] = (c + 3 <= r) ? v[q].w : 0.0f;
-            X[r * LDQ + c + 0] = 0.0f; X[r * LDQ + c + 1] = 0.0f; X[r * LDQ + c + 2] = 0.0f; X[r * LDQ + c + 3] = 0.0f;
-        }
-    }
-    __syncthreads();
-    const int lc = lane & 31, lh = lane >> 5;  // MFMA D layout: col = lc, row = (e&3) + 8*(e>>2) + 4*lh
-    for (int sb = 0; sb < 4; ++sb) {
-        const int c0 = 32 * sb;
-        if (wid == 0) {
-            // ---- factor + invert the 32x32 diagonal sub-block in registers (lanes 32-63 mirror 0-31)
-            const int i = lane & 31;
-            float a[32], x[32];
-            float myinv = 0.0f;  // lane j: 1 / L[j][j]
-#pragma unroll
-            for (int c = 0; c < 32; ++c) a[c] = S[(c0 + i) * LDQ + c0 + c];
-            bool bad = false;
-            d_factor<0>(a, i, myinv, bad);
-            d_inverse<0>(a, x, i, myinv);
-            if (lane < 32) {
-#pragma unroll
-                for (int c = 0; c < 32; ++c) {
-                    int ii = i;  // opaque: no 32 precomputed (c <= lane) masks spilled into VGPR lanes
-                    asm volatile("" : "+v"(ii));
-                    S[(c0 + i) * LDQ + c0 + c] = (c <= ii) ? a[c] : 0.0f;
-                    X[(c0 + c) * LDQ + c0 + i] = x[c];
-                }
-                if (bad && lane == 0) *flag = 1;
-            }
-        }
-        __syncthreads();
-        // ---- panel: P_t = A_t * Dinv^T for the 32-row tiles below (one per wave)
-        const int ntile = 3 - sb;
-        if (wid < ntile) {
-            const int r0 = c0 + 32 * (wid + 1);
-            f32x16 acc = mfma_nt_32(S + r0 * LDQ + c0, LDQ, X + c0 * LDQ + c0, LDQ, lane);
-#pragma unroll
-            for (int e = 0; e < 16; ++e) S[(r0 + (e & 3) + 8 * (e >> 2) + 4 * lh) * LDQ + c0 + lc] = acc[e];
-        }
-        __syncthreads();
-        // ---- trailing update of the remaining lower sub-blocks: S_ij -= P_i P_j^T
-        int t = 0;
-        for (int bi = sb + 1; bi < 4; ++bi)
-            for (int bj = sb + 1; bj <= bi; ++bj, ++t) {
-                if ((t & 3) != wid) continue;
-                f32x16 acc = mfma_nt_32(S + (32 * bi) * LDQ + c0, LDQ, S + (32 * bj) * LDQ + c0, LDQ, lane);
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    float* p = S + (32 * bi + (e & 3) + 8 * (e >> 2) + 4 * lh) * LDQ + 32 * bj + lc;
-                    *p = *p - acc[e];
-                }
-            }
-        __syncthreads();
-    }
-    // ---- L^-1 off-diagonal sub-blocks by block forward substitution, distance d = i - j
-    for (int d = 1; d < 4; ++d) {
-        const int bi = d + wid, bj = wid;  // one (bi, bj) pair per wave, 4 - d pairs
-        const bool mine = bi < 4;
-        if (mine) {
-            // T[r][c] = sum_{k = 32 bj .. 32 bi - 1} L[32bi + r][k] * X[k][32bj + c]
-            // (A operand: rows of L; B operand: row k of X, lanes along its columns)
-            f32x16 acc;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
-            const int li = lane & 31, lk = lane >> 5;
-            for (int c = 0; c < d; ++c) {  // 32 k per chunk, operands read ahead of the MFMAs
-                float av[16], bv[16];
-#pragma unroll
-                for (int p = 0; p < 16; ++p) {
-                    const int k = 32 * (bj + c) + 2 * p + lk;
-                    av[p] = S[(32 * bi + li) * LDQ + k];
-                    bv[p] = X[k * LDQ + 32 * bj + li];
-                }
-#pragma unroll
-                for (int p = 0; p < 16; ++p) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p], bv[p], acc, 0, 0, 0);
-            }
-#pragma unroll
-            for (int e = 0; e < 16; ++e) Tw[((e & 3) + 8 * (e >> 2) + 4 * lh) * TQ + lc] = acc[e];
-        }
-        __syncthreads();
-        if (mine) {
-            // X_ij[r][c] = -sum_k X_ii[r][k] * T[k][c]
-            f32x16 acc;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
-            const int li = lane & 31, lk = lane >> 5;
-            float av[16], bv[16];
-#pragma unroll
-            for (int p = 0; p < 16; ++p) {
-                const int k = 2 * p + lk;
-                av[p] = X[(32 * bi + li) * LDQ + 32 * bi + k];
-                bv[p] = Tw[k * TQ + li];
-            }
-#pragma unroll
-            for (int p = 0; p < 16; ++p) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p], bv[p], acc, 0, 0, 0);
-#pragma unroll
-            for (int e = 0; e < 16; ++e) X[(32 * bi + (e & 3) + 8 * (e >> 2) + 4 * lh) * LDQ + 32 * bj + lc] = -acc[e];
-        }
-        __syncthreads();
-    }
-    for (int idx = tid; idx < NB * NB / 4; idx += 256) {
-        const int r = idx / (NB / 4), c = (idx % (NB / 4)) * 4;
-        const float* sr = S + r * LDQ + c;
-        const float* xr = X + r * LDQ + c;
-        // the WHOLE block of X is written, zeros above the diagonal included: the k-range skips of the GEMMs end at tile
-        // boundaries and read them.  (Blocks of X above the block diagonal are never written and never read.)
-        *reinterpret_cast<float4*>(Xout + r * ldx + c) = make_float4(xr[0], xr[1], xr[2], xr[3]);
-        if (c > r) continue;  // above the diagonal A keeps its (unused) values
-        if (c + 3 <= r) *reinterpret_cast<float4*>(A + r * lda + c) = make_float4(sr[0], sr[1], sr[2], sr[3]);
-        else
-            for (int u = 0; u < 4; ++u)
-                if (c + u <= r) A[r * lda + c + u] = sr[u];
-    }
-}
+// (diag_blk_kernel, the four-wave leaf of r01 / r02 that used the helpers above with ONE wave factoring and inverting each
+// 32x32 sub-block -- 51.5 us per leaf against 34.3 us for the five-wave pipeline of gq_diag5.hpp -- lives in the git history.)
 
 }  // namespace gq
 #include "gq_diag5.hpp"
@@ -673,11 +540,8 @@ namespace gq {
 // its GEMMs depend on C only: they are planned once per C (cached), and uploaded with ONE copy per gq_h_prepare
 // call (the upload also zeroes the pop counters).
 // (The switches are read on every call -- a handful per transformer block -- so that tests can flip them.)
-static int64_t p3_min() {
-    const char* e = getenv("GQ_CHOL_3P_MIN");
-    return e ? atol(e) : 1792;  // 0: never
-}
-static int p3_planes() { return getenv("GQ_CHOL_BF16X3") ? 3 : 2; }  // default: row-scaled fp16 x 2, equilibrated matrix
+static int64_t p3_min() { return opt(OPT_chol_3p_min); }  // 0: never
+static int p3_planes() { return opt(OPT_chol_planes) == 3 ? 3 : 2; }  // default: row-scaled fp16 x 2, equilibrated matrix
 static inline bool p3_node(int64_t n1, int64_t n2) {
     return p3_min() > 0 && n1 >= p3_min() && n2 >= p3_min() && n1 % 256 == 0 && n2 % 256 == 0;
 }
@@ -698,7 +562,6 @@ static void p3_collect(P3Plans& pl, int64_t lo, int64_t hi) {
     const bool big = p3_node(n1, n2);
     const int gran = p3_planes() == 3 ? 2 : 4;
     auto add = [&](const std::vector<p3::GemmShape>& shs) {
-        const p3::GemmShape& sh = shs[0];
         p3::Plan p = p3::make_plan(shs, gran, P3_MAX_SLOTS);
         P3Gemm g;
         while (pl.words.size() % 4) pl.words.push_back(0u);
@@ -708,10 +571,6 @@ static void p3_collect(P3Plans& pl, int64_t lo, int64_t hi) {
         pl.words.insert(pl.words.end(), p.rlist.begin(), p.rlist.end());
         g.n_reduce = (int)(p.rlist.size() / 2);
         if (p.nslots < 0) fprintf(stderr, "gq: image GEMM plan needs more than %d partial slots\n", P3_MAX_SLOTS), abort();
-        if (getenv("GQ_CHOL_3P_VERBOSE"))
-            fprintf(stderr, "p3 plan MT=%d NT=%d KC=%d kr=%d lower=%d: units=%zu split tiles=%d slots=%d makespan=%.1f ideal=%.1f chunks\n",
-                    sh.MT, sh.NT, sh.KC, sh.kr, (int)sh.lower, (p.table.size() - p3::T_UNITS) / 4, g.n_reduce, p.nslots,
-                    p.makespan, p.ideal);
         pl.gemms.push_back(g);
     };
     if (big) {
@@ -834,8 +693,6 @@ static int chol_inv_rec(float* A, float* X, float* Tmp, int* flag, int64_t n, in
         const int64_t o = (lo * NB) * n + lo * NB;
         if (diag_lds == DIAG5_LDS)
             hipLaunchKernelGGL(diag_blk5_kernel, dim3(1), dim3(320), diag_lds, st, A + o, n, X + o, n, flag);
-        else if (diag_lds == DIAG_BLK_LDS)
-            hipLaunchKernelGGL(diag_blk_kernel, dim3(1), dim3(256), diag_lds, st, A + o, n, X + o, n, flag);
         else
             hipLaunchKernelGGL(diag_potrf_inv_kernel, dim3(1), dim3(256), diag_lds, st, A + o, n, X + o, n, flag);
         GQ_LAUNCH_CHECK();
@@ -851,13 +708,13 @@ static int chol_inv_rec(float* A, float* X, float* Tmp, int* flag, int64_t n, in
     const int64_t o21 = (mid * NB) * n + lo * NB, o11 = (lo * NB) * n + lo * NB, o22 = (mid * NB) * n + mid * NB;
     // large nodes: fp32-accurate products on the bf16 matrix cores (gq_gemm3b.hpp); small ones are
     // latency-bound and stay on the fp32 instruction
-    const int64_t min3b = getenv("GQ_CHOL_FP32") ? (int64_t)1 << 40 : (getenv("GQ_CHOL_3B_MIN") ? atol(getenv("GQ_CHOL_3B_MIN")) : 1024);
+    const int64_t min3b = opt(OPT_chol_fp32) ? (int64_t)1 << 40 : opt(OPT_chol_3b_min);
     const bool big = n1 >= min3b && n2 >= min3b;
 #define GQ_CHOL_GEMM(TB, MODE, LOW, KRV, ...) \
     (big ? launch_gemm3b<TB, MODE, LOW, KRV>(__VA_ARGS__) : launch_gemm32<TB, MODE, LOW, KRV>(__VA_ARGS__))
     // small nodes: the SYRK update and L21 X11 (both need only L21) share one launch of whole 64-tiles, in front of the
     // recursion into A22 (bit-identical to separate launches: every output element is the same k-ordered chain)
-    const bool pair = !big && !getenv("GQ_CHOL_NO_PAIR") && n % 4 == 0 && gemm32_uses_64_full(n2, n2, n1, true) &&
+    const bool pair = !big && !opt(OPT_chol_no_pair) && n % 4 == 0 && gemm32_uses_64_full(n2, n2, n1, true) &&
                       gemm32_uses_64_full(n2, n1, n1, false);
     {
         ProfScope ps(PT_CHOL_GEMM, st);
@@ -947,27 +804,24 @@ int h_prepare(float* H, float* W, int64_t R, int64_t C, float rel_damp, float* U
         hipLaunchKernelGGL(damp_kernel, dim3(1), dim3(1024), 0, st, H, C, rel_damp);
     }
     GQ_LAUNCH_CHECK();
-    const bool equil = getenv("GQ_CHOL_NO_EQUIL") == nullptr;
+    const bool equil = !opt(OPT_chol_no_equil);
     if (equil) {
         eq_s = reinterpret_cast<float*>(((uintptr_t)(zc + n) + 255) & ~(uintptr_t)255);
         hipLaunchKernelGGL(equil_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, H, n, eq_s);
     }
     // Neither A above its block diagonal nor X needs clearing: every block that is read is written first (diagonal
-    // blocks whole, zeros included).  The test that pins this fills both with NaN patterns first (GQ_POISON_X=1) and
+    // blocks whole, zeros included).  The test that pins this fills both with NaN patterns first (option chol_poison) and
     // expects the same U.
-    if (getenv("GQ_POISON_X")) GQ_HIP(hipMemsetAsync(A, 0xff, 2 * (size_t)n * n * sizeof(float), st));
+    if (opt(OPT_chol_poison)) GQ_HIP(hipMemsetAsync(A, 0xff, 2 * (size_t)n * n * sizeof(float), st));
     hipLaunchKernelGGL(reverse_copy_kernel, dim3((unsigned)n), dim3(256), 0, st, A, H, n, eq_s);
     GQ_LAUNCH_CHECK();
     }
     static std::atomic<bool> attr_set{false};  // guards an idempotent call: a race sets the same value twice
-    const bool use_ref = getenv("GQ_DIAG_REF") != nullptr;  // A/B: the column-by-column kernel
-    const bool use_v1 = getenv("GQ_DIAG_V1") != nullptr;    // A/B: the four-wave kernel of r01/r02
-    const size_t diag_lds = use_ref ? (2 * NB * LDP + NB) * sizeof(float) : (use_v1 ? DIAG_BLK_LDS : DIAG5_LDS);
+    const bool use_ref = opt(OPT_diag_ref) != 0;  // the column-by-column kernel
+    const size_t diag_lds = use_ref ? (2 * NB * LDP + NB) * sizeof(float) : DIAG5_LDS;
     if (!attr_set) {
         GQ_HIP(hipFuncSetAttribute((const void*)diag_potrf_inv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)((2 * NB * LDP + NB) * sizeof(float))));
-        GQ_HIP(hipFuncSetAttribute((const void*)diag_blk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)DIAG_BLK_LDS));
         GQ_HIP(hipFuncSetAttribute((const void*)diag_blk5_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)DIAG5_LDS));
         attr_set = true;

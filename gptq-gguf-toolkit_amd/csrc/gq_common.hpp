@@ -31,6 +31,51 @@ extern thread_local char g_err[512];
 
 #define GQ_LAUNCH_CHECK() GQ_HIP(hipGetLastError())
 
+// ---- library options: every tuning / test switch of the library in ONE table (include/gptq_gguf.h documents them).
+// Set through gq_option_set() or, once at load, from the single environment variable
+//   GQ_OPTIONS="name=value,name=value"
+// and read per call with opt() (a relaxed atomic load).  X(name, default).
+#define GQ_OPTION_LIST(X)                                                                                              \
+    /* K1 SYRK */                                                                                                      \
+    X(syrk_128, 0)          /* 1: the 128x128-tile kernel for every shape */                                            \
+    X(syrk_image, 0)        /* 1: re-laid-out operand image + syrk16_256e_kernel instead of reading X in place */       \
+    X(syrk_nosplit, 0)      /* 1: no K-split of the last, partial round of tiles */                                     \
+    X(syrk_persist, 1)      /* 0: one tile per workgroup instead of the persistent launch with XCD rendezvous */         \
+    X(syrk_wgs, 0)          /* resident workgroups of the persistent launch (0: one per CU) */                          \
+    X(syrk_stagger, 0)      /* 1: waves 4-7 issue their LDS-DMA pieces at the end of a k32 step */                       \
+    /* K3 Cholesky chain */                                                                                            \
+    X(chol_3p_min, 1792)    /* smallest half of a recursion node that runs on the image GEMMs (0: never) */             \
+    X(chol_planes, 2)       /* 2: row-scaled fp16 x 2 images, 3: exact bf16 x 3 */                                      \
+    X(chol_3b_min, 1024)    /* smallest half that runs on the on-the-fly split-bf16 GEMM */                             \
+    X(chol_fp32, 0)         /* 1: v_mfma_f32_32x32x2_f32 everywhere below the image levels */                           \
+    X(chol_no_pair, 0)      /* 1: SYRK update and L21 X11 of a small node as two launches */                            \
+    X(chol_no_equil, 0)     /* 1: no power-of-two equilibration */                                                      \
+    X(chol_poison, 0)       /* 1: NaN-fill the scratch the chain must never read (tests) */                             \
+    X(diag_ref, 0)          /* 1: the column-by-column 128x128 leaf kernel (reference for tests) */                      \
+    /* K5/K6 column loop */                                                                                            \
+    X(no_lookahead, 0)      /* 1: trailing update after every block, no chained far update */                           \
+    X(la, 8)                /* blocks per look-ahead super-block (even, 2..8) */                                        \
+    X(near_classic, 0)      /* 1: a near launch after every block instead of the pair form */                           \
+    X(near_quad, 0)         /* 1: near launches after every second pair */                                              \
+    X(near64_maxn, 768)     /* widest near update that takes gemm32_near256_kernel */                                   \
+    X(far_sync, 0)          /* 1: far updates on the caller's stream (no helper stream) */                              \
+    X(far_async_max_rows, 8192) X(far_async_min_sb, 8) /* shape window of the helper-stream form */                     \
+    X(far_wgs, 192)         /* resident workgroups of the helper's persistent far GEMM */                               \
+    X(chain_generic, 0)     /* 1: the generic chained kernel instead of the dedicated far kernel */                     \
+    X(gemm32_64_max, 256)   /* problems with fewer 128-tiles than this take 64x64 tiles (0: never) */                   \
+    /* K4 */                                                                                                           \
+    X(ss_wide, -1)          /* scale-search mapping: -1 by size, 1 eight lanes, 0 one lane, 2 a lane pair per group */  \
+    /* saver */                                                                                                        \
+    X(stage_host_wgs, 0)    /* workgroups of gq_stage_to_host (0: default) */
+
+enum Opt {
+#define GQ_X(name, def) OPT_##name,
+    GQ_OPTION_LIST(GQ_X)
+#undef GQ_X
+    OPT_COUNT
+};
+int64_t opt(Opt o);
+
 struct TypeInfo {
     int bits, qmin, qmax, scale_maxq, group, is_signed, k_search, type_size;
 };

@@ -208,12 +208,7 @@ __device__ __forceinline__ void d5_inverse(float (&x)[32], int i, unsigned lrowb
     }
 }
 
-#ifdef D5_STAMPS  // profiles/micro/diag5_stamps.hip: cycle stamps of the phases (one workgroup)
-__device__ long long d5_stamps[128];
-#define D5_STAMP(k) do { if (lane == 0) d5_stamps[(k)] = (long long)__builtin_readcyclecounter(); } while (0)
-#else
 #define D5_STAMP(k) (void)0
-#endif
 
 __global__ __launch_bounds__(320) void diag_blk5_kernel(float* __restrict__ A, int64_t lda, float* __restrict__ Xout,
                                                         int64_t ldx, int* __restrict__ flag_out) {

@@ -324,7 +324,7 @@ inline int launch_gemm32_pair(float* Ca, const float* Aa, int64_t Ma, int64_t Ka
 }
 // does launch_gemm32 pick whole 64-tiles for a Cholesky-node product of this size?
 inline bool gemm32_uses_64_full(int64_t M, int64_t N, int64_t K, bool lower) {
-    static const int64_t max64 = getenv("GQ_GEMM32_64_MAX") ? atol(getenv("GQ_GEMM32_64_MAX")) : 256;
+    const int64_t max64 = opt(OPT_gemm32_64_max);
     const int64_t tiles128 = ((M + 127) / 128) * ((N + 127) / 128) / (lower ? 2 : 1);
     return tiles128 < max64 && M % 64 == 0 && N % 64 == 0 && K % TK == 0;
 }
@@ -353,21 +353,9 @@ typedef uint32_t g32_u32x4 __attribute__((ext_vector_type(4)));
     asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(fa0[s]), "+v"(fa1[s]), "+v"(fb0[s]), "+v"(fb1[s]) : "n"(N))
 
 // timing probes (results wrong): -DGQ_FAR_NOCOMMIT / -DGQ_FAR_NOFETCH / -DGQ_FAR_NOBARRIER drop a piece of the loop
-#ifdef GQ_FAR_NOCOMMIT
-#define GQ_FAR_AB_COMMIT(x) do {} while (0)
-#else
 #define GQ_FAR_AB_COMMIT(x) x
-#endif
-#ifdef GQ_FAR_NOFETCH
-#define GQ_FAR_AB_FETCH(x) do {} while (0)
-#else
 #define GQ_FAR_AB_FETCH(x) x
-#endif
-#ifdef GQ_FAR_NOBARRIER
-#define GQ_FAR_AB_BARRIER() do {} while (0)
-#else
 #define GQ_FAR_AB_BARRIER() __builtin_amdgcn_s_barrier()
-#endif
 template <int CHAIN>
 __device__ __forceinline__ void g32_chain_full_tile(float* Cmat, int64_t ldc, const float* A, int64_t lda, const float* B,
                                                     int64_t ldb, int64_t K, const int64_t m0, const int64_t n0) {
@@ -408,9 +396,6 @@ __device__ __forceinline__ void g32_chain_full_tile(float* Cmat, int64_t ldc, co
     f32x2 fa0[4], fa1[4];  // [set]: A tile 0 / 1, k-steps (4g, 4g+2)
     float fb0[4], fb1[4];  // [set]: B at k-step 4g / 4g+2
     // reads of group g (0..7) of the image whose fragment bases are (pa0, pa1, pb) into set s
-#ifdef GQ_FAR_NOREADS  // timing probe: no fragment reads at all (MFMAs on whatever the registers hold)
-#define GQ_C_READS(g, s, pa0, pa1, pb) do { asm volatile("" : "+v"(fa0[s]), "+v"(fa1[s]), "+v"(fb0[s]), "+v"(fb1[s])); } while (0)
-#else
 #define GQ_C_READS(g, s, pa0, pa1, pb)                  \
     do {                                                \
         GQ_C_RD2(fa0[s], pa0, 4 * (g), 4 * (g) + 2);    \
@@ -418,7 +403,6 @@ __device__ __forceinline__ void g32_chain_full_tile(float* Cmat, int64_t ldc, co
         GQ_C_RD1(fb0[s], pb, (4 * (g)) * LDB * 4);      \
         GQ_C_RD1(fb1[s], pb, (4 * (g) + 2) * LDB * 4);  \
     } while (0)
-#endif
     fetch(0, va[0], vb[0]);
     commit(0, va[0], vb[0]);
     fetch(1, va[1], vb[1]);
@@ -512,314 +496,9 @@ __global__ __launch_bounds__(512, 2) void gemm32_chain_full_persistent_kernel(fl
     }
 }
 
-// ---- the far update with the operand chunks DMA'd into LDS (global_load_lds_dwordx4): no VGPR staging, no ds_write ----
-// Same tile, waves, fragment schedule and arithmetic as g32_chain_full_tile; what changes is how a 32-k chunk reaches
-// LDS.  There every thread loads 4 float4 into registers two chunks ahead and later writes them out (8 ds_write_b32 for
-// the padded A rows + 2 ds_write_b128): measured with the probe builds above, dropping that commit alone shortens the
-// far launches by 11 %, the loads by another 6 % -- issue slots and LDS write cycles taken from the MFMA stream.  Here
-// a wave issues 4 DMA instructions per chunk (2 KiB of A, 2 KiB of B each) and nothing else.  OPT-IN (GQ_FAR_DMA=1):
-// bit-identical results, no LDS bank conflicts (SQ_LDS_BANK_CONFLICT = 0), yet 6 % slower than the register-staged
-// kernel on the 4096 x 14336 loop (profiles/far_dma_ab.sh, profiles/pmc_far_lds.sh) -- see launch_gemm32_chain_full.
-//   LDS: A ring [4 slots][128 rows][8 units of 16 B] (64 KiB) then B ring [4 slots][32 k][128 columns] (64 KiB).
-//   A unit (row, kq) sits at position kq ^ ((row >> 1) & 7) of its row: the ds_read_b128 of a 16-lane group (16 rows,
-//   one kq) touches 16 distinct 16-byte columns of the 256-byte LDS line.  A lane keeps k = 4 kq + lk and 4 kq + 2 + lk
-//   of the four floats (lk = lane >> 5), the operands of the group's two k-steps.  Slots are immediate offsets: the
-//   chunk body is instantiated per slot, one chain (4 chunks) = slots 0..3.
-//   Ring discipline at group 6 of chunk t: this wave's DMAs of chunk t + 1 have landed (vmcnt), barrier (everybody's
-//   have, and everybody's reads of chunk t - 1 are done), DMAs of chunk t + 3 into the slot of chunk t - 1.
-template <int CHAIN>
-__device__ __forceinline__ void g32_chain_dma_tile(float* Cmat, int64_t ldc, const float* A, int64_t lda, const float* B,
-                                                   int64_t ldb, int64_t K, const int64_t m0, const int64_t n0) {
-    extern __shared__ __attribute__((aligned(16))) float g32_smem[];
-    static_assert(CHAIN == 128 && TK == 32, "one chain = four 32-k chunks = the four ring slots");
-    constexpr unsigned A_SLOT = 128 * 128, B_SLOT = 32 * 512, B_RING = 4 * A_SLOT;  // bytes
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wid >> 2, wn = wid & 3;
-    const int li = lane & 31, lk = lane >> 5;
-    const int64_t nk = K / TK;
-    const unsigned lds0 = (unsigned)(uintptr_t)g32_smem;
-    f32x16 acc[2], cv[2];
-    float* cp[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) cp[i] = Cmat + (m0 + wm * 64 + i * 32 + 4 * lk) * ldc + n0 + wn * 32 + li;
-    // DMA pieces of this wave: A pieces 2 wid, 2 wid + 1 (8 rows x 128 B each), B pieces 2 wid, 2 wid + 1 (2 k x 512 B)
-    unsigned avo[2], bvo[2];
-#pragma unroll
-    for (int jj = 0; jj < 2; ++jj) {
-        const int row = 8 * (2 * wid + jj) + (lane >> 3);
-        const int kq = (lane & 7) ^ ((row >> 1) & 7);
-        avo[jj] = (unsigned)((row * lda + kq * 4) * 4);
-        bvo[jj] = (unsigned)(((2 * (2 * wid + jj) + (lane >> 5)) * ldb + (lane & 31) * 4) * 4);
-    }
-    const float* ap = A + m0 * lda;  // + 32 floats per chunk
-    const float* bp = B + n0;        // + 32 ldb floats per chunk
-    const int64_t bstep = 32 * ldb;
-    const unsigned adst = lds0 + (unsigned)(2 * wid) * 1024u, bdst = lds0 + B_RING + (unsigned)(2 * wid) * 1024u;
-#define GQ_D_DL(vo, sp, ldsaddr) \
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vo), "s"(sp), "s"(ldsaddr) : "memory")
-    // chunk t -> slot; past the end the last chunk is loaded again (into a slot nobody reads any more)
-#define GQ_D_STAGE(t_, slot)                                                \
-    do {                                                                    \
-        const int64_t tt_ = ((t_) < nk) ? (t_) : nk - 1;                    \
-        const float* sa_ = ap + tt_ * 32;                                   \
-        const float* sb_ = bp + tt_ * bstep;                                \
-        GQ_D_DL(avo[0], sa_, adst + (slot) * A_SLOT);                       \
-        GQ_D_DL(avo[1], sa_, adst + (slot) * A_SLOT + 1024u);               \
-        GQ_D_DL(bvo[0], sb_, bdst + (slot) * B_SLOT);                       \
-        GQ_D_DL(bvo[1], sb_, bdst + (slot) * B_SLOT + 1024u);               \
-    } while (0)
-    GQ_D_STAGE(0, 0);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) cv[i][e] = cp[i][((e & 3) + 8 * (e >> 2)) * ldc];
-    GQ_D_STAGE(1, 1);
-    GQ_D_STAGE(2, 2);
-    // fragment addresses: A tile i, group g (unit kq = g) in slot 0; B k = lk in slot 0
-    unsigned aaddr[2][8];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = wm * 64 + i * 32 + li;
-#pragma unroll
-        for (int g = 0; g < 8; ++g) aaddr[i][g] = lds0 + (unsigned)(row * 128 + ((g ^ ((row >> 1) & 7)) << 4));
-    }
-    const unsigned bbase = lds0 + B_RING + (unsigned)(lk * 512 + (wn * 32 + li) * 4);
-    g32_u32x4 fa0[4], fa1[4];
-    float fb0[4], fb1[4];
-#define GQ_D_READS(g, s, slot)                                                                                           \
-    do {                                                                                                                 \
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa0[s]) : "v"(aaddr[0][g]), "n"((slot) * 16384) : "memory");  \
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa1[s]) : "v"(aaddr[1][g]), "n"((slot) * 16384) : "memory");  \
-        asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(fb0[s]) : "v"(bbase), "n"((slot) * 16384 + (4 * (g)) * 512) : "memory"); \
-        asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(fb1[s]) : "v"(bbase), "n"((slot) * 16384 + (4 * (g) + 2) * 512) : "memory"); \
-    } while (0)
-    // chunk 0 has landed when at most the C loads and chunks 1, 2 (32 + 8 operations of this wave) are outstanding
-    asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    GQ_D_READS(0, 0, 0);
-    GQ_D_READS(1, 1, 0);
-    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    int64_t t = 0;
-#define GQ_D_GROUP(g, SLOT, FIRST)                                                                           \
-    do {                                                                                                     \
-        constexpr int s_ = (g) & 3, NS_ = ((SLOT) + 1) & 3;                                                   \
-        if ((g) == 6) {                                                                                      \
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); /* chunk t + 1 of this wave; t + 2 may be in flight */ \
-            __builtin_amdgcn_s_barrier();                                                                    \
-            GQ_D_STAGE(t + 3, ((SLOT) + 3) & 3);                                                             \
-        }                                                                                                    \
-        if ((g) < 6) GQ_D_READS((g) + 2, ((g) + 2) & 3, SLOT);                                               \
-        else GQ_D_READS((g) - 6, ((g) + 2) & 3, NS_);                                                        \
-        asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(fa0[s_]), "+v"(fa1[s_]), "+v"(fb0[s_]), "+v"(fb1[s_])::"memory"); \
-        const float a00_ = __builtin_bit_cast(float, lk ? fa0[s_].y : fa0[s_].x);                            \
-        const float a10_ = __builtin_bit_cast(float, lk ? fa1[s_].y : fa1[s_].x);                            \
-        const float a01_ = __builtin_bit_cast(float, lk ? fa0[s_].w : fa0[s_].z);                            \
-        const float a11_ = __builtin_bit_cast(float, lk ? fa1[s_].w : fa1[s_].z);                            \
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a00_, fb0[s_], ((FIRST) && (g) == 0) ? zero : acc[0], 0, 0, 0); \
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a10_, fb0[s_], ((FIRST) && (g) == 0) ? zero : acc[1], 0, 0, 0); \
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a01_, fb1[s_], acc[0], 0, 0, 0);                       \
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a11_, fb1[s_], acc[1], 0, 0, 0);                       \
-    } while (0)
-#define GQ_D_CHUNK(SLOT, FIRST)                                                                     \
-    do {                                                                                            \
-        GQ_D_GROUP(0, SLOT, FIRST); GQ_D_GROUP(1, SLOT, FIRST); GQ_D_GROUP(2, SLOT, FIRST); GQ_D_GROUP(3, SLOT, FIRST); \
-        GQ_D_GROUP(4, SLOT, FIRST); GQ_D_GROUP(5, SLOT, FIRST); GQ_D_GROUP(6, SLOT, FIRST); GQ_D_GROUP(7, SLOT, FIRST); \
-        ++t;                                                                                        \
-    } while (0)
-#define GQ_D_CHAIN()                                                                 \
-    do {                                                                             \
-        GQ_D_CHUNK(0, true);                                                         \
-        GQ_D_CHUNK(1, false);                                                        \
-        GQ_D_CHUNK(2, false);                                                        \
-        GQ_D_CHUNK(3, false);                                                        \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                \
-            _Pragma("unroll") for (int e = 0; e < 16; ++e) cv[i][e] = cv[i][e] - acc[i][e]; \
-    } while (0)
-    // The first chain is peeled: the compiler does not see the DMAs (inline asm) and waits for "its" C loads with
-    // vmcnt(0) at their first use -- once per tile here, at every chain end if that use were inside the loop.
-    const int64_t nchain = nk / 4;
-    GQ_D_CHAIN();
-    for (int64_t c = 1; c < nchain; ++c) GQ_D_CHAIN();
-#undef GQ_D_CHAIN
-#undef GQ_D_CHUNK
-#undef GQ_D_GROUP
-#undef GQ_D_READS
-#undef GQ_D_STAGE
-#undef GQ_D_DL
-    // the prefetched (unused) fragments and the over-fetched chunks must be home before the LDS ring or the registers
-    // are reused (persistent form: the next tile's first DMA)
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) cp[i][((e & 3) + 8 * (e >> 2)) * ldc] = cv[i][e];
-}
-
-// ---- the DMA form with a TWO-slot ring (64 KiB of LDS, <= 128 VGPRs): two workgroups per CU ----
-// One workgroup per CU leaves the matrix pipe idle while that workgroup loads and stores its C tile, waits at a barrier or
-// for its operands (76.7 % busy, see above).  With two resident workgroups the other one's MFMAs fill those gaps.  Chunk t
-// lives in slot t & 1.  In chunk t: at group 1 a barrier (every wave has entered chunk t, i.e. finished reading chunk t - 1)
-// and then the DMAs of chunk t + 1 into the slot chunk t - 1 occupied; before group 7 issues the first fragment reads of
-// chunk t + 1: vmcnt(0) + barrier.  Fragment reads run one group ahead (two register sets); the A addresses are
-// base ^ (group << 4) (the swizzle is an XOR on address bits 4..6), so two address registers serve all eight groups.
-template <int CHAIN>
-__device__ __forceinline__ void g32_chain_dma2_tile(float* Cmat, int64_t ldc, const float* A, int64_t lda, const float* B,
-                                                    int64_t ldb, int64_t K, const int64_t m0, const int64_t n0) {
-    extern __shared__ __attribute__((aligned(128))) float g32_smem[];
-    static_assert(CHAIN == 128 && TK == 32, "one chain = four 32-k chunks");
-    constexpr unsigned A_SLOT = 128 * 128, B_SLOT = 32 * 512, B_RING = 2 * A_SLOT;  // bytes
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wid >> 2, wn = wid & 3;
-    const int li = lane & 31, lk = lane >> 5;
-    const int64_t nk = K / TK;
-    const unsigned lds0 = (unsigned)(uintptr_t)g32_smem;
-    f32x16 acc[2], cv[2];
-    unsigned avo[2], bvo[2];
-#pragma unroll
-    for (int jj = 0; jj < 2; ++jj) {
-        const int row = 8 * (2 * wid + jj) + (lane >> 3);
-        const int kq = (lane & 7) ^ ((row >> 1) & 7);
-        avo[jj] = (unsigned)((row * lda + kq * 4) * 4);
-        bvo[jj] = (unsigned)(((2 * (2 * wid + jj) + (lane >> 5)) * ldb + (lane & 31) * 4) * 4);
-    }
-    const float* ap = A + m0 * lda;
-    const float* bp = B + n0;
-    const int64_t bstep = 32 * ldb;
-    const unsigned adst = lds0 + (unsigned)(2 * wid) * 1024u, bdst = lds0 + B_RING + (unsigned)(2 * wid) * 1024u;
-#define GQ_E_DL(vo, sp, ldsaddr) \
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vo), "s"(sp), "s"(ldsaddr) : "memory")
-#define GQ_E_STAGE(t_, slot)                                                \
-    do {                                                                    \
-        const int64_t tt_ = ((t_) < nk) ? (t_) : nk - 1;                    \
-        const float* sa_ = ap + tt_ * 32;                                   \
-        const float* sb_ = bp + tt_ * bstep;                                \
-        GQ_E_DL(avo[0], sa_, adst + (slot) * A_SLOT);                       \
-        GQ_E_DL(avo[1], sa_, adst + (slot) * A_SLOT + 1024u);               \
-        GQ_E_DL(bvo[0], sb_, bdst + (slot) * B_SLOT);                       \
-        GQ_E_DL(bvo[1], sb_, bdst + (slot) * B_SLOT + 1024u);               \
-    } while (0)
-    GQ_E_STAGE(0, 0);
-    {
-        float* cp0 = Cmat + (m0 + wm * 64 + 4 * lk) * ldc + n0 + wn * 32 + li;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) cv[i][e] = cp0[(i * 32 + (e & 3) + 8 * (e >> 2)) * ldc];
-    }
-    // A fragment address of tile i, group g, slot 0: abase[i] ^ (g << 4)
-    unsigned abase[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = wm * 64 + i * 32 + li;
-        abase[i] = lds0 + (unsigned)(row * 128 + (((row >> 1) & 7) << 4));
-    }
-    const unsigned bbase = lds0 + B_RING + (unsigned)(lk * 512 + (wn * 32 + li) * 4);
-    g32_u32x4 fa0[2], fa1[2];
-    float fb0[2], fb1[2];
-#define GQ_E_READS(g, s, slot)                                                                                           \
-    do {                                                                                                                 \
-        const unsigned a0_ = abase[0] ^ (unsigned)((g) << 4), a1_ = abase[1] ^ (unsigned)((g) << 4);                      \
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa0[s]) : "v"(a0_), "n"((slot) * 16384) : "memory");          \
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa1[s]) : "v"(a1_), "n"((slot) * 16384) : "memory");          \
-        asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(fb0[s]) : "v"(bbase), "n"((slot) * 16384 + (4 * (g)) * 512) : "memory"); \
-        asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(fb1[s]) : "v"(bbase), "n"((slot) * 16384 + (4 * (g) + 2) * 512) : "memory"); \
-    } while (0)
-    // chunk 0 has landed when at most the 32 C loads are outstanding
-    asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    GQ_E_READS(0, 0, 0);
-    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    int64_t t = 0;
-#define GQ_E_GROUP(g, SLOT, FIRST)                                                                           \
-    do {                                                                                                     \
-        constexpr int s_ = (g) & 1;                                                                          \
-        if ((g) == 1) {                                                                                      \
-            __builtin_amdgcn_s_barrier(); /* every wave is in this chunk: the other slot is free */           \
-            GQ_E_STAGE(t + 1, (SLOT) ^ 1);                                                                   \
-        }                                                                                                    \
-        if ((g) == 7) {                                                                                      \
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                 \
-            __builtin_amdgcn_s_barrier(); /* chunk t + 1 is complete */                                      \
-            GQ_E_READS(0, s_ ^ 1, (SLOT) ^ 1);                                                               \
-        } else {                                                                                             \
-            GQ_E_READS((g) + 1, s_ ^ 1, SLOT);                                                               \
-        }                                                                                                    \
-        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fa0[s_]), "+v"(fa1[s_]), "+v"(fb0[s_]), "+v"(fb1[s_])::"memory"); \
-        const float a00_ = __builtin_bit_cast(float, lk ? fa0[s_].y : fa0[s_].x);                            \
-        const float a10_ = __builtin_bit_cast(float, lk ? fa1[s_].y : fa1[s_].x);                            \
-        const float a01_ = __builtin_bit_cast(float, lk ? fa0[s_].w : fa0[s_].z);                            \
-        const float a11_ = __builtin_bit_cast(float, lk ? fa1[s_].w : fa1[s_].z);                            \
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a00_, fb0[s_], ((FIRST) && (g) == 0) ? zero : acc[0], 0, 0, 0); \
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a10_, fb0[s_], ((FIRST) && (g) == 0) ? zero : acc[1], 0, 0, 0); \
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a01_, fb1[s_], acc[0], 0, 0, 0);                       \
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a11_, fb1[s_], acc[1], 0, 0, 0);                       \
-    } while (0)
-#define GQ_E_CHUNK(SLOT, FIRST)                                                                     \
-    do {                                                                                            \
-        GQ_E_GROUP(0, SLOT, FIRST); GQ_E_GROUP(1, SLOT, FIRST); GQ_E_GROUP(2, SLOT, FIRST); GQ_E_GROUP(3, SLOT, FIRST); \
-        GQ_E_GROUP(4, SLOT, FIRST); GQ_E_GROUP(5, SLOT, FIRST); GQ_E_GROUP(6, SLOT, FIRST); GQ_E_GROUP(7, SLOT, FIRST); \
-        ++t;                                                                                        \
-    } while (0)
-#define GQ_E_CHAIN()                                                                 \
-    do {                                                                             \
-        GQ_E_CHUNK(0, true);                                                         \
-        GQ_E_CHUNK(1, false);                                                        \
-        GQ_E_CHUNK(0, false);                                                        \
-        GQ_E_CHUNK(1, false);                                                        \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                \
-            _Pragma("unroll") for (int e = 0; e < 16; ++e) cv[i][e] = cv[i][e] - acc[i][e]; \
-    } while (0)
-    const int64_t nchain = nk / 4;
-    GQ_E_CHAIN();  // peeled: the compiler's vmcnt(0) for the C loads is paid once per tile (see g32_chain_dma_tile)
-    for (int64_t c = 1; c < nchain; ++c) GQ_E_CHAIN();
-#undef GQ_E_CHAIN
-#undef GQ_E_CHUNK
-#undef GQ_E_GROUP
-#undef GQ_E_READS
-#undef GQ_E_STAGE
-#undef GQ_E_DL
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    {
-        float* cp0 = Cmat + (m0 + wm * 64 + 4 * lk) * ldc + n0 + wn * 32 + li;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) cp0[(i * 32 + (e & 3) + 8 * (e >> 2)) * ldc] = cv[i][e];
-    }
-}
-template <int CHAIN>
-__global__ __launch_bounds__(512, 4) void gemm32_chain_dma2_kernel(float* Cmat, int64_t ldc, const float* A, int64_t lda,
-                                                                   const float* B, int64_t ldb, int64_t K) {
-    g32_chain_dma2_tile<CHAIN>(Cmat, ldc, A, lda, B, ldb, K, (int64_t)blockIdx.y * 128, (int64_t)blockIdx.x * 128);
-}
-template <int CHAIN>
-__global__ __launch_bounds__(512, 4) void gemm32_chain_dma2_persistent_kernel(float* Cmat, int64_t ldc, const float* A,
-                                                                              int64_t lda, const float* B, int64_t ldb,
-                                                                              int64_t K, int64_t ntx, int64_t ntiles) {
-    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        g32_chain_dma2_tile<CHAIN>(Cmat, ldc, A, lda, B, ldb, K, (t / ntx) * 128, (t % ntx) * 128);
-        __syncthreads();
-    }
-}
-
-template <int CHAIN>
-__global__ __launch_bounds__(512, 1) void gemm32_chain_dma_kernel(float* Cmat, int64_t ldc, const float* A, int64_t lda,
-                                                                  const float* B, int64_t ldb, int64_t K) {
-    g32_chain_dma_tile<CHAIN>(Cmat, ldc, A, lda, B, ldb, K, (int64_t)blockIdx.y * 128, (int64_t)blockIdx.x * 128);
-}
-template <int CHAIN>
-__global__ __launch_bounds__(512, 1) void gemm32_chain_dma_persistent_kernel(float* Cmat, int64_t ldc, const float* A,
-                                                                             int64_t lda, const float* B, int64_t ldb,
-                                                                             int64_t K, int64_t ntx, int64_t ntiles) {
-    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        g32_chain_dma_tile<CHAIN>(Cmat, ldc, A, lda, B, ldb, K, (t / ntx) * 128, (t % ntx) * 128);
-        __syncthreads();  // every wave's DMAs have landed and its reads are done before the next tile refills the ring
-    }
-}
-
-// max_wgs > 0: the persistent form with at most that many workgroups
+// (Measured and removed, r03/r04: two LDS-DMA forms of the far update -- a four-slot ring with one workgroup per CU,
+// 6 % slower than the register-staged chunks above although it issues a tenth of the staging instructions, and a
+// two-slot ring with two workgroups per CU, +1.6 % -- DESIGN.md K6; they live in the git history.)
 template <int CHAIN>
 inline int launch_gemm32_chain_full(float* Cmat, int64_t ldc, const float* A, int64_t lda, const float* B, int64_t ldb,
                                     int64_t M, int64_t N, int64_t K, hipStream_t st, int max_wgs = 0) {
@@ -832,50 +511,6 @@ inline int launch_gemm32_chain_full(float* Cmat, int64_t ldc, const float* A, in
         attr_set = true;
     }
     const int64_t ntx = N / 128, ntiles = ntx * (M / 128);
-    // GQ_FAR_DMA=1: the DMA form above (measured r03, 4096 x 14336 column loop: 14.4-14.7 vs 13.6-13.7 ms of far launches,
-    // matrix pipe busy 72.5 vs 76.6 % -- slower than the register-staged chunks although it issues a tenth of the staging
-    // instructions); GQ_FAR_DMA=2: its two-slot variant, two workgroups per CU: 13.5 ms, +1.6 % -- so neither the staging
-    // instructions nor the per-tile prologue is where the missing 23 % goes (the instruction itself sustains 156 TFLOP/s
-    // with one to four accumulators per wave: profiles/micro/mfma32_rate.hip).  Both opt-in, bit-identical; they need
-    // 32-bit operand offsets
-    static const int dma_form = getenv("GQ_FAR_DMA") ? atoi(getenv("GQ_FAR_DMA")) : 0;  // 1: four-slot ring, 2: two-slot ring
-    const bool dma = dma_form == 1;
-    if (dma_form == 2 && K % CHAIN == 0 && 128 * lda * 4 < (int64_t)1 << 31 && 32 * ldb * 4 < (int64_t)1 << 31) {
-        constexpr int DLDS2 = 64 * 1024;
-        static std::atomic<bool> d2attr_set{false};
-        if (!d2attr_set) {
-            GQ_HIP(hipFuncSetAttribute((const void*)gemm32_chain_dma2_kernel<CHAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, DLDS2));
-            GQ_HIP(hipFuncSetAttribute((const void*)gemm32_chain_dma2_persistent_kernel<CHAIN>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, DLDS2));
-            d2attr_set = true;
-        }
-        if (max_wgs > 0 && ntiles > max_wgs)
-            hipLaunchKernelGGL((gemm32_chain_dma2_persistent_kernel<CHAIN>), dim3((unsigned)max_wgs), dim3(512), DLDS2, st, Cmat,
-                               ldc, A, lda, B, ldb, K, ntx, ntiles);
-        else
-            hipLaunchKernelGGL((gemm32_chain_dma2_kernel<CHAIN>), dim3((unsigned)ntx, (unsigned)(M / 128)), dim3(512), DLDS2, st,
-                               Cmat, ldc, A, lda, B, ldb, K);
-        GQ_LAUNCH_CHECK();
-        return GQ_OK;
-    }
-    if (dma && K % CHAIN == 0 && 128 * lda * 4 < (int64_t)1 << 31 && 32 * ldb * 4 < (int64_t)1 << 31) {
-        constexpr int DLDS = 128 * 1024;
-        static std::atomic<bool> dattr_set{false};
-        if (!dattr_set) {
-            GQ_HIP(hipFuncSetAttribute((const void*)gemm32_chain_dma_kernel<CHAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, DLDS));
-            GQ_HIP(hipFuncSetAttribute((const void*)gemm32_chain_dma_persistent_kernel<CHAIN>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, DLDS));
-            dattr_set = true;
-        }
-        if (max_wgs > 0 && ntiles > max_wgs)
-            hipLaunchKernelGGL((gemm32_chain_dma_persistent_kernel<CHAIN>), dim3((unsigned)max_wgs), dim3(512), DLDS, st, Cmat,
-                               ldc, A, lda, B, ldb, K, ntx, ntiles);
-        else
-            hipLaunchKernelGGL((gemm32_chain_dma_kernel<CHAIN>), dim3((unsigned)ntx, (unsigned)(M / 128)), dim3(512), DLDS, st,
-                               Cmat, ldc, A, lda, B, ldb, K);
-        GQ_LAUNCH_CHECK();
-        return GQ_OK;
-    }
     if (max_wgs > 0 && ntiles > max_wgs) {
         hipLaunchKernelGGL((gemm32_chain_full_persistent_kernel<CHAIN>), dim3((unsigned)max_wgs), dim3(512), LDS, st, Cmat, ldc,
                            A, lda, B, ldb, K, ntx, ntiles);
@@ -1056,7 +691,7 @@ inline int launch_gemm32_ts(float* Cmat, int64_t ldc, const float* A, int64_t ld
                             int64_t N, int64_t K, hipStream_t st) {
     // whole tiles only (every GPTQ / Cholesky shape of a 128-multiple Linear): the unpredicated kernel
     if constexpr (CHAIN == 128 && TS == 128 && !TRANS_B && MODE == 0 && !LOWER && KR == 0) {
-        static const bool generic = getenv("GQ_CHAIN_GENERIC") != nullptr;  // A/B: the generic chained kernel
+        const bool generic = opt(OPT_chain_generic) != 0;  // the generic chained kernel
         if (!generic && M % TS == 0 && N % TS == 0) return launch_gemm32_chain_full<CHAIN>(Cmat, ldc, A, lda, B, ldb, M, N, K, st);
     }
     if (M % TS == 0 && N % TS == 0 && K % TK == 0 && ldc % 4 == 0)
@@ -1074,7 +709,7 @@ inline int launch_gemm32(float* Cmat, int64_t ldc, const float* A, int64_t lda, 
     // fewer 128-tiles than CUs: 64-tiles put four times as many CUs on the (latency-bound) problem.  Every output
     // element is the same k-ordered chain either way, so the choice never changes a result.
     const int64_t tiles128 = ((M + 127) / 128) * ((N + 127) / 128) / (LOWER ? 2 : 1);
-    static const int64_t max64 = getenv("GQ_GEMM32_64_MAX") ? atol(getenv("GQ_GEMM32_64_MAX")) : 256;  // 0: never
+    const int64_t max64 = opt(OPT_gemm32_64_max);  // 0: never
     if (CHAIN == 0 && tiles128 < max64)
         return launch_gemm32_ts<TRANS_B, MODE, LOWER, KR, CHAIN == 0 ? 0 : 0, 64>(Cmat, ldc, A, lda, B, ldb, M, N, K, st);
     return launch_gemm32_ts<TRANS_B, MODE, LOWER, KR, CHAIN, 128>(Cmat, ldc, A, lda, B, ldb, M, N, K, st);

@@ -136,7 +136,6 @@ __global__ __launch_bounds__(SEG_WAVES * 64) void gptq_segment_kernel(
         if (t >= ntile) break;
         const int i0 = t * SB;
         float* net = ne + (t & 1) * (SB * 64);
-#ifndef GQ_SEG_NOCHAIN  // (timing probes only: profiles/seg_ab.sh)
         if (wid == 0) {
             const int64_t col0 = a + i0;
             float ds = 0.f, dm = 0.f, dsv[PERM ? SB : 1], dmv[PERM ? SB : 1];
@@ -196,8 +195,6 @@ __global__ __launch_bounds__(SEG_WAVES * 64) void gptq_segment_kernel(
                 }
             }
         }
-#endif
-#ifndef GQ_SEG_NOUPDATE
         // deferred: the errors of tile t-1 go into the tiles t+1.., 16 columns per helper wave and turn; each element
         // sees the same sequence of (mul, add) pairs, in the same order of i, as 16 successive addr_ calls
         // (packed v_pk_mul_f32 / v_pk_add_f32 were measured 35 % SLOWER here)
@@ -227,9 +224,7 @@ __global__ __launch_bounds__(SEG_WAVES * 64) void gptq_segment_kernel(
                 for (int jj = 0; jj < SB; ++jj) wl[(j0 + jj) * 64 + lane] = wt[jj];
             }
         }
-#endif
         __syncthreads();
-#ifndef GQ_SEG_NOUPDATE
         // the next tile needs this tile's errors NOW: all eight waves, two of its columns each
         if (i0 + SB < len) {
             constexpr int CPW = SB / SEG_WAVES;
@@ -246,7 +241,6 @@ __global__ __launch_bounds__(SEG_WAVES * 64) void gptq_segment_kernel(
 #pragma unroll
             for (int jj = 0; jj < CPW; ++jj) wl[(j0 + jj) * 64 + lane] = wt[jj];
         }
-#endif
         __syncthreads();
     }
     // ---- epilogue (r03): this block's errors into the NEXT block's 128 columns (its partner in the 256-column
@@ -255,12 +249,10 @@ __global__ __launch_bounds__(SEG_WAVES * 64) void gptq_segment_kernel(
     // computed -- here with the negated errors the kernel already keeps, sum' = -sum exactly, w + sum' = w - sum -- so
     // the launch, its gap and its W round trip disappear.  U's diagonal block in LDS is dead once the chains are through.
     if (Unext != nullptr) {
-#ifndef GQ_EPI_NOLOADU  // (timing probes only)
         for (int idx = tid; idx < SEG * (SEG / 4); idx += SEG_WAVES * 64) {
             const int i = idx / (SEG / 4), j4 = (idx % (SEG / 4)) * 4;
             *reinterpret_cast<float4*>(Us + i * SEG + j4) = *reinterpret_cast<const float4*>(Unext + (int64_t)i * C + j4);
         }
-#endif
         __syncthreads();
         const int rb = (wid & 1) * 32, cb = (wid >> 1) * 32;  // 2 x 4 sub-tiles of 32 x 32, one per wave
         const int li = lane & 31, lk = lane >> 5;
@@ -268,15 +260,12 @@ __global__ __launch_bounds__(SEG_WAVES * 64) void gptq_segment_kernel(
         f32x16 acc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
-#ifndef GQ_EPI_NOMFMA
 #pragma unroll 8
         for (int k0 = 0; k0 < SEG; k0 += 2) {
             const int k = k0 + lk;
             const float ev = (k < SEG - SB) ? wl[k * 64 + rb + li] : nel[(k - (SEG - SB)) * 64 + rb + li];
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ev, Us[k * SEG + cb + li], acc, 0, 0, 0);
         }
-#endif
-#ifndef GQ_EPI_NOW
         // all 16 loads in flight before the first store (written as `*p += acc` the compiler must keep every load behind
         // the previous store: 16 dependent HBM round trips, 12 us per block)
         const int64_t r0 = (int64_t)blockIdx.x * 64 + rb + 4 * lk;
@@ -292,7 +281,6 @@ __global__ __launch_bounds__(SEG_WAVES * 64) void gptq_segment_kernel(
             const int ro = (e & 3) + 8 * (e >> 2);
             if (r0 + ro < R) wp[(int64_t)ro * C] = wv[e] + acc[e];
         }
-#endif
     }
 }
 
@@ -388,10 +376,9 @@ static std::atomic<int> g_far_enabled{1};
 int far_helper_enable(int on) { return g_far_enabled.exchange(on ? 1 : 0); }
 static bool far_async_shape(int64_t R, int64_t C, int64_t B, int la) {
     if (!g_far_enabled.load()) return false;
-    // read per call (three getenv per Linear): tests and A/B runs flip them inside one process
-    const bool off = getenv("GQ_FAR_SYNC") != nullptr;
-    const int64_t max_rows = getenv("GQ_FAR_ASYNC_MAX_ROWS") ? atol(getenv("GQ_FAR_ASYNC_MAX_ROWS")) : 8192;
-    const int64_t min_sb = getenv("GQ_FAR_ASYNC_MIN_SB") ? atol(getenv("GQ_FAR_ASYNC_MIN_SB")) : 8;
+    // options are read per call: tests and A/B runs flip them inside one process
+    const bool off = opt(OPT_far_sync) != 0;
+    const int64_t max_rows = opt(OPT_far_async_max_rows), min_sb = opt(OPT_far_async_min_sb);
     return !off && B == LA_B && R % 128 == 0 && C % 128 == 0 && R <= max_rows && C >= min_sb * (int64_t)la * B;
 }
 // One helper stream per device, held by ONE call at a time: from the start of its enqueue until its last helper launch
@@ -450,8 +437,8 @@ static int far_event(int i, hipEvent_t* out) {
 int gptq_uses_helper_stream(int64_t R, int64_t C, int block_size) {
     const int64_t B = block_size <= 0 || block_size > C ? C : block_size;
     int la = LA;
-    if (const char* e = getenv("GQ_LA")) la = (atoi(e) >= 2 && atoi(e) <= LA && atoi(e) % 2 == 0) ? atoi(e) : LA;
-    return getenv("GQ_NO_LOOKAHEAD") == nullptr && far_async_shape(R, C, B, la);
+    if (const int64_t e = opt(OPT_la)) la = (e >= 2 && e <= LA && e % 2 == 0) ? (int)e : LA;
+    return !opt(OPT_no_lookahead) && far_async_shape(R, C, B, la);
 }
 
 size_t gptq_workspace_bytes(int64_t R, int64_t C, int block_size) {
@@ -510,32 +497,26 @@ static int column_loop(float* W, const float* U, int64_t R, int64_t C, int q_typ
     // the column-loop workgroups, which need a whole CU's LDS, waiting.)
     int la = LA;
     // tuning knob; even only: a 256-column scale-search group must not straddle two super-blocks
-    if (const char* e = getenv("GQ_LA")) la = (atoi(e) >= 2 && atoi(e) <= LA && atoi(e) % 2 == 0) ? atoi(e) : LA;
+    if (const int64_t e = opt(OPT_la)) la = (e >= 2 && e <= LA && e % 2 == 0) ? (int)e : LA;
     // a uniform group must lie inside one super-block as well: its grid is found from columns that every earlier
     // block has already updated
-    const bool lookahead = (B == LA_B) && getenv("GQ_NO_LOOKAHEAD") == nullptr &&
+    const bool lookahead = (B == LA_B) && !opt(OPT_no_lookahead) &&
                            (!uni || uni->group <= 0 || (la * B) % uni->group == 0);
-    // GQ_NEAR_LEFT=1 (r03 experiment, measured and left off): inside a super-block the updates become LEFT-looking --
-    // before block b runs, its columns receive the errors of the super-block's earlier blocks: at an even b the 256
-    // columns of blocks b and b + 1 (the lazy scale search of gptq.py:240-245 reads the whole 256-column group at b's
-    // first column) in ONE chained launch with K = 128 b, at an odd b the block's own 128 columns from block b - 1.
-    // Per element the same subtractions in the same order as the right-looking form (bit-identical: the parity tests
-    // pass either way), a quarter of its traffic on W -- and no faster: the chained 64-tile launches average 39 us
-    // (2.4 us per 32-k chunk against 0.46 us of matrix-pipe time: one or two workgroups per CU cannot cover the
-    // L2 latency of so short a chunk), 2.33 vs 2.30 ms of near updates inside the 4096 x 14336 loop.
-    const bool left_look = lookahead && getenv("GQ_NEAR_LEFT") != nullptr && (!uni || uni->group <= 0 || 256 % uni->group == 0);
+    // (Measured and removed, r03: a LEFT-looking form of the near updates -- before block b its columns receive the errors of
+    // the super-block's earlier blocks in one chained 64-tile launch with K = 128 b: a quarter of the traffic on W, bit-identical,
+    // and no faster (2.33 vs 2.30 ms of near updates in the 4096 x 14336 loop))
     // r03, default: near updates at the granularity of the 256-column scale-search groups.  An even block hands its
     // errors to its partner (the odd block of the group) in the column-loop kernel's epilogue; after the odd block ONE
     // chained launch (K = 256, chain 128) brings both blocks' errors to the rest of the super-block.  Per element the
     // same subtractions in the same order as after-every-block updates (bit-identical: the parity tests run both);
-    // 3 launches per super-block instead of 7.  GQ_NEAR_CLASSIC=1: one launch after every block (r02).
-    const bool pair_look = lookahead && !left_look && getenv("GQ_NEAR_CLASSIC") == nullptr && la % 2 == 0 &&
+    // 3 launches per super-block instead of 7.  Option near_classic: one launch after every block (r02).
+    const bool pair_look = lookahead && !opt(OPT_near_classic) && la % 2 == 0 &&
                            (!uni || uni->group <= 0 || 256 % uni->group == 0);
     const int64_t ldE = lookahead ? (int64_t)LA * B : B;
     float* Err0 = reinterpret_cast<float*>(((uintptr_t)ws + 255) & ~(uintptr_t)255);
     float* Wblk = Err0 + (size_t)R * B * (B == LA_B ? 2 * LA : 1);
     bool far_async = lookahead && far_async_shape(R, C, B, la);
-    const int far_wgs = getenv("GQ_FAR_WGS") ? atoi(getenv("GQ_FAR_WGS")) : 192;
+    const int far_wgs = (int)opt(OPT_far_wgs);
     FarHold hold;
     hipStream_t helper = nullptr;
     hipEvent_t ev_small_prev = nullptr, ev_bulk[2] = {nullptr, nullptr}, ev_last = nullptr;
@@ -587,18 +568,6 @@ static int column_loop(float* W, const float* U, int64_t R, int64_t C, int q_typ
         if (far_async && pos == 0 && ev_bulk[sb & 1]) {  // this half of the error buffer: the helper is done with it
             GQ_HIP(hipStreamWaitEvent(st, ev_bulk[sb & 1], 0));
             ev_bulk[sb & 1] = nullptr;
-        }
-        if (left_look && pos > 0) {
-            const int64_t LS0 = sb * la * B, LS1 = (LS0 + la * B < C) ? LS0 + la * B : C;  // this super-block
-            if (pos & 1) {  // the errors of block b - 1 into this block's columns
-                if ((rc = launch_trailing_update(W + c1, C, Err + (pos - 1) * B, ldE, U + (c1 - B) * C + c1, C, R, c2 - c1, B, st)))
-                    return rc;
-            } else {        // the errors of blocks 0 .. b - 1 into the 256-column group that starts here
-                const int64_t n = (c1 + 2 * B < LS1) ? 2 * B : LS1 - c1;
-                ProfScope ps(PT_TRAILING, st);
-                if ((rc = launch_gemm32_ts<false, 0, false, 0, LA_B, 64>(W + c1, C, Err, ldE, U + LS0 * C + c1, C, R, n, pos * B, st)))
-                    return rc;
-            }
         }
         if (uni && uni->group > 0) {  // fast_obq.py:168-171 for every group that starts inside this block
             ProfScope ps(PT_SCALE_SEARCH, st);
@@ -672,11 +641,11 @@ static int column_loop(float* W, const float* U, int64_t R, int64_t C, int q_typ
                 // GQ_NEAR_QUAD=1 (measured, off): a third level -- pair -> the quad's other pair (K = 256, N = 256), quad -> the
                 // rest of the super-block (K = 512, N = 512): same flops, deeper K on fewer tiles: 1.24 vs 1.05 ms of near
                 // launches for 4096 x 14336
-                static const bool quad = getenv("GQ_NEAR_QUAD") != nullptr;
+                const bool quad = opt(OPT_near_quad) != 0;
                 if ((pos & 1) && !quad) {  // end of a 256-group: both blocks' errors, in order, to the rest of the super-block
                     ProfScope ps(PT_TRAILING, st);
                     // up to GQ_NEAR64_MAXN columns: 64x64 tiles with the K = 256 panels whole in LDS (gemm32_near256_kernel)
-                    static const int64_t near64_maxn = getenv("GQ_NEAR64_MAXN") ? atol(getenv("GQ_NEAR64_MAXN")) : 768;
+                    const int64_t near64_maxn = opt(OPT_near64_maxn);
                     if (S1 - c2 <= near64_maxn && R % 64 == 0) {
                         if ((rc = launch_gemm32_near256(W + c2, C, Err + (pos - 1) * B, ldE, U + (c1 - B) * C + c2, C, R, S1 - c2, st)))
                             return rc;
@@ -697,8 +666,7 @@ static int column_loop(float* W, const float* U, int64_t R, int64_t C, int q_typ
                 }
                 continue;
             }
-            if (!left_look &&
-                (rc = launch_trailing_update(W + c2, C, Err + pos * B, ldE, U + c1 * C + c2, C, R, S1 - c2, ncols, st)))
+            if ((rc = launch_trailing_update(W + c2, C, Err + pos * B, ldE, U + c1 * C + c2, C, R, S1 - c2, ncols, st)))
                 return rc;
             continue;
         }

@@ -21,13 +21,6 @@
 
 namespace gq {
 
-// resident workgroups of the persistent SYRK launches enqueued by this host thread (gq_syrk_workgroups)
-static thread_local int g_syrk_wgs = 256;
-int syrk_workgroups(int n) {
-    const int prev = g_syrk_wgs;
-    g_syrk_wgs = (n >= 8 && n <= 256) ? (n & ~7) : 256;
-    return prev;
-}
 
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -130,6 +123,9 @@ struct SyrkGroup {
     // of XCD x that finished a round; a round starts when all of them have, so the 32 tiles an XCD works on at a
     // time stay in step and share their 12 operand panels through the XCD's L2.  nullptr: one tile per workgroup.
     unsigned* bar;
+    // syrk16_256n_kernel: 1 = the second wave of every SIMD (waves 4-7) issues its four LDS-DMA pieces of a step behind the
+    // step's LAST MFMAs instead of its middle, so that the eight waves do not queue at the vector-memory unit together
+    int stagger;
 };
 
 template <bool BF16>
@@ -228,13 +224,8 @@ __global__ __launch_bounds__(256, 2) void syrk16_kernel(const SyrkGroup grp) {
             uint4 a[2], b[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-#ifdef GQ_SYRK_NOLDS
-                a[i] = make_uint4(kc + i, lane, 3, 4); b[i] = make_uint4(5, kc, lane + i, 8);
-                asm volatile("" : "+v"(a[i].x), "+v"(b[i].x));
-#else
                 a[i] = *reinterpret_cast<const uint4*>(base + offA[i] + ((kc ^ swz[0][i]) << 4));
                 b[i] = *reinterpret_cast<const uint4*>(base + offB[i] + ((kc ^ swz[1][i]) << 4));
-#endif
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -249,23 +240,15 @@ __global__ __launch_bounds__(256, 2) void syrk16_kernel(const SyrkGroup grp) {
     __syncthreads();
     for (int64_t t = 0; t < nk; t += 2) {
         // even step: compute stage t (buf 0); stage t+1 sits in the odd set, stage t+2 goes to the even set
-#ifndef GQ_SYRK_NOLOAD
         if (t + 2 < nk) GQ_FETCH(e, t + 2);
-#endif
         compute(0);
-#ifndef GQ_SYRK_NOLOAD
         if (t + 1 < nk) GQ_COMMIT(o, 1);
-#endif
         __syncthreads();
         if (t + 1 < nk) {
             // odd step: compute stage t+1 (buf 1); stage t+2 sits in the even set, stage t+3 goes to the odd set
-#ifndef GQ_SYRK_NOLOAD
             if (t + 3 < nk) GQ_FETCH(o, t + 3);
-#endif
             compute(1);
-#ifndef GQ_SYRK_NOLOAD
             if (t + 2 < nk) GQ_COMMIT(e, 0);
-#endif
             __syncthreads();
         }
     }
@@ -342,11 +325,7 @@ __global__ __launch_bounds__(512, 2) void syrk16_256e_kernel(const SyrkGroup grp
     const unsigned vlast = (unsigned)(nhs - 1) * 8192u + (unsigned)tid * 16u;
     unsigned voff = (unsigned)tid * 16u;
     const unsigned ldsw = lds0 + (unsigned)wid * 1024u;  // + slot * 32 KiB + piece * 8 KiB; hardware adds lane * 16
-#ifdef GQ_D_NOLOAD
-#define GQ_EDL(sp, slot, part) (void)0
-#else
 #define GQ_EDL(sp, slot, part) GQ_EDL_(sp, slot, part)
-#endif
 #define GQ_EDL_(sp, slot, part)                                                                       \
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"                      \
                  :: "v"(voff), "s"(sp), "s"(ldsw + (unsigned)((slot) * S_BUF_BYTES + (part) * 8192)) : "memory")
@@ -500,9 +479,6 @@ __global__ __launch_bounds__(512, 2) void syrk16_256e_kernel(const SyrkGroup grp
 #undef GQ_EMF
 #undef GQ_ESTEP
 #undef GQ_EINTERVAL
-#ifdef GQ_D_NOEPI
-    if (P.alpha != 12345.f) continue;
-#endif
     float* __restrict__ H = P.H;
     const float beta = P.beta, alpha = P.alpha;
     const int64_t i0 = ti * BT + wm * 128 + 4 * lk, j0 = tj * BT + wn * 64 + lr;
@@ -574,6 +550,8 @@ __global__ __launch_bounds__(512, 2) void syrk16_256n_kernel(const SyrkGroup grp
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid >> 2, wn = wid & 3;
+    const bool late = (grp.stagger & 1) && wid >= 4;  // wave-uniform (wid is an SGPR value)
+    if ((grp.stagger & 2) && wid >= 4) __builtin_amdgcn_s_setprio(1);  // static priority for the younger wave of every SIMD
     int round = 0;
     for (int slot = (int)(blockIdx.x >> 3); slot < grp.per_xcd; slot += (int)(gridDim.x >> 3), ++round) {
     if (grp.bar && round > 0) {  // XCD-wide rendezvous between rounds (persistent launch)
@@ -640,11 +618,7 @@ __global__ __launch_bounds__(512, 2) void syrk16_256n_kernel(const SyrkGroup grp
     const unsigned ldsw = lds0 + (unsigned)(op * 16384 + rb * 512);
     int hnext = 0;
     const char* gbase = gsrc;
-#ifdef GQ_D_NOLOAD
-#define GQ_NDL(vo, slot_, u) (void)0
-#else
 #define GQ_NDL(vo, slot_, u) GQ_NDL_(vo, slot_, u)
-#endif
 #define GQ_NDL_(vo, slot_, u)                                                                         \
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"                      \
                  :: "v"(vo), "s"(gbase), "s"(ldsw + (unsigned)((slot_) * S_BUF_BYTES + (u) * 1024)) : "memory")
@@ -726,7 +700,7 @@ __global__ __launch_bounds__(512, 2) void syrk16_256n_kernel(const SyrkGroup grp
         else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(A_), "v"(B_));     \
     } while (0)
 #define GQ_NBAR() asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory")
-#define GQ_NSTEP(X, Y, AC, OFFC, AN, BN, OFFN, L0, L1, L2, L3)                                        \
+#define GQ_NSTEP(X, Y, AC, OFFC, AN, BN, OFFN, L0, L1, L2, L3, M0, M1, M2, M3)                        \
     do {                                                                                              \
         GQ_NWAIT(12, X##a0l, X##a0h);                                                                 \
         GQ_NWAIT(10, X##b0l, X##b0h);                                                                 \
@@ -796,15 +770,21 @@ __global__ __launch_bounds__(512, 2) void syrk16_256n_kernel(const SyrkGroup grp
         GQ_NWAIT(13, la7l, la7h);                                                                     \
         GQ_NRD(Y##a2h, AN, 2, (OFFN) + 2048);                                                         \
         GQ_NMF(c62, la6l, la6h, X##b2l, X##b2h);                                                      \
+        M0;                                                                                           \
         GQ_NMF(c63, la6l, la6h, X##b3l, X##b3h);                                                      \
         GQ_NMF(c70, la7l, la7h, X##b0l, X##b0h);                                                      \
+        M1;                                                                                           \
         GQ_NMF(c71, la7l, la7h, X##b1l, X##b1h);                                                      \
+        M2;                                                                                           \
         GQ_NMF(c72, la7l, la7h, X##b2l, X##b2h);                                                      \
+        M3;                                                                                           \
         GQ_NMF(c73, la7l, la7h, X##b3l, X##b3h);                                                      \
     } while (0)
 #define GQ_NINTERVAL(X, Y, AC, OFFC, AN, BN, OFFN, SLOT3)                                             \
-    GQ_NSTEP(X, Y, AC, OFFC, AN, BN, OFFN, GQ_NDL(voff0, SLOT3, 0), GQ_NDL(voff1, SLOT3, 1),          \
-             GQ_NDL(voff2, SLOT3, 2), GQ_NDL(voff3, SLOT3, 3));                                       \
+    GQ_NSTEP(X, Y, AC, OFFC, AN, BN, OFFN, if (!late) GQ_NDL(voff0, SLOT3, 0), if (!late) GQ_NDL(voff1, SLOT3, 1), \
+             if (!late) GQ_NDL(voff2, SLOT3, 2), if (!late) GQ_NDL(voff3, SLOT3, 3),                  \
+             if (late) GQ_NDL(voff0, SLOT3, 0), if (late) GQ_NDL(voff1, SLOT3, 1),                    \
+             if (late) GQ_NDL(voff2, SLOT3, 2), if (late) GQ_NDL(voff3, SLOT3, 3));                   \
     GQ_NADV();
 
     for (int h = 0; h < 3; ++h) {
@@ -1001,13 +981,13 @@ __global__ __launch_bounds__(256) void syrk32_kernel(float* __restrict__ H, int6
 // 16-bit inputs with C % 256 == 0 and T % 128 == 0 are read in place (syrk16_256n_kernel): only the tile table
 // needs scratch.  Everything else goes through the re-laid-out operand image.
 static inline bool syrk_in_place(int64_t T, int64_t C) {
-    return (C % BT == 0) && (T % (2 * HK) == 0) && getenv("GQ_SYRK_IMAGE") == nullptr && getenv("GQ_SYRK_128") == nullptr;
+    return (C % BT == 0) && (T % (2 * HK) == 0) && !opt(OPT_syrk_image) && !opt(OPT_syrk_128);
 }
 
 // K-split of the last (partial) round of tiles (syrk16_256n_kernel): partial-sum slots a problem may need.
 // Only long token ranges are split (every part is at least 8 turns of the ring); GQ_SYRK_NOSPLIT disables it.
 static inline size_t syrk_partial_slots(int64_t T, size_t ntile) {
-    if (T < 8192 || getenv("GQ_SYRK_NOSPLIT")) return 0;
+    if (T < 8192 || opt(OPT_syrk_nosplit)) return 0;
     return 4 * ntile < 512 ? 4 * ntile : 512;
 }
 
@@ -1059,6 +1039,7 @@ static int syrk16_launch(int kind, const int* idx, int m, float* const* H, const
     grp.aux = nullptr;
     grp.partial = nullptr;
     grp.bar = nullptr;
+    grp.stagger = (int)opt(OPT_syrk_stagger);
     int n_reduce = 0;
     const uint32_t* reduce_list = nullptr;
     std::vector<uint32_t> table;
@@ -1130,7 +1111,7 @@ static int syrk16_launch(int kind, const int* idx, int m, float* const* H, const
         // rendezvous counters of the persistent launch (zeroed by this upload), then the block address lists of the
         // problems whose X arrives in separate blocks, behind the tile table
         // default on: L2-miss reads of a 14336-wide launch 49.6 -> 37.5 GB (rocprofv3 FETCH_SIZE), +0.8 % speed
-        static const bool persist = getenv("GQ_SYRK_PERSIST") == nullptr || getenv("GQ_SYRK_PERSIST")[0] != '0';
+        const bool persist = opt(OPT_syrk_persist) != 0;
         size_t bar_at = 0;
         if (kind == 2 && persist && per_xcd > 32) {
             bar_at = table.size();
@@ -1168,10 +1149,10 @@ static int syrk16_launch(int kind, const int* idx, int m, float* const* H, const
     const bool bf = x_dtype == GQ_BF16;
     if (kind == 2) {
         // one tile per workgroup, or (grp.bar) one workgroup per CU walking its XCD's list in rounds
-        // (GQ_SYRK_WGS, read per call: fewer resident workgroups for a fold that runs NEXT TO a latency-bound chain --
+        // (option syrk_wgs, read per call: fewer resident workgroups for a fold that runs NEXT TO a latency-bound chain --
         // the block schedule's postponed folds -- so that the chain's kernels always find free CUs)
-        int wgs = g_syrk_wgs;
-        if (const char* e = getenv("GQ_SYRK_WGS")) wgs = (atoi(e) >= 8 && atoi(e) <= 256) ? (atoi(e) & ~7) : 256;
+        int wgs = 256;
+        if (const int64_t e = opt(OPT_syrk_wgs)) wgs = (e >= 8 && e <= 256) ? (int)(e & ~7) : 256;
         const dim3 grid((unsigned)(grp.bar ? wgs : 8 * grp.per_xcd)), blk(512);
         if (bf) hipLaunchKernelGGL(syrk16_256n_kernel<true>, grid, blk, S_LDS_BYTES, st, grp);
         else hipLaunchKernelGGL(syrk16_256n_kernel<false>, grid, blk, S_LDS_BYTES, st, grp);
@@ -1311,7 +1292,7 @@ int h_accumulate_grouped(int n, float* const* H, const void* const* X, const int
         need += h_accumulate_workspace_bytes(T[i], C[i]);
         if (segs && segs[i] && nseg[i] > 1) {
             // separate blocks are only read in place: whole ring turns per block, 16-byte aligned rows
-            if (T[i] % nseg[i] || (T[i] / nseg[i]) % (2 * HK) || !syrk_in_place(T[i], C[i]) || getenv("GQ_SYRK_128"))
+            if (T[i] % nseg[i] || (T[i] / nseg[i]) % (2 * HK) || !syrk_in_place(T[i], C[i]) || opt(OPT_syrk_128))
                 GQ_FAIL(GQ_E_UNSUPPORTED, "gq_h_accumulate_segments: %ld blocks of %ld tokens, C=%ld: blocks must hold a "
                         "multiple of 128 tokens and C %% 256 == 0 (stage the rows into one buffer instead)",
                         (long)nseg[i], (long)(T[i] / nseg[i]), (long)C[i]);
@@ -1333,7 +1314,7 @@ int h_accumulate_grouped(int n, float* const* H, const void* const* X, const int
     // Problems are sorted into at most three launches by the kernel they can take (usually all take the first):
     // in place (kind 2), 256x256 on the image (kind 1: T not a multiple of 128), 128x128 (kind 0: C % 256 != 0).
     int idx[3][H_MAX_GROUP], cnt[3] = {0, 0, 0};
-    const bool force128 = getenv("GQ_SYRK_128") != nullptr;
+    const bool force128 = opt(OPT_syrk_128) != 0;
     for (int i = 0; i < n; ++i) {
         const int kind = (force128 || C[i] % BT) ? 0 : (syrk_in_place(T[i], C[i]) ? 2 : 1);
         idx[kind][cnt[kind]++] = i;

@@ -231,13 +231,6 @@ __device__ __forceinline__ void k_search(const float (&x)[NS], const SearchParam
                 GQ_ACC(a0, k, R<RM>(w[k] * R<RM>(diff * diff)));
             }
             const float cand_err = R<RM>(group_sum<LPG, NA>(a0));
-#ifdef GQ_DBG_ITER  // kernel A/B probe: report (cand_err, best_err) of one iteration instead of the result
-            if (i == GQ_DBG_ITER) {
-                scale_out = cand_err;
-                zero_out = best_err;
-                return;
-            }
-#endif
             // :250-252: a group with D <= eps still goes through the formulas as long as SOME group of the panel is
             // valid in this iteration (NaN / inf candidates lose the comparison); when NONE is, the reference skips
             // the iteration for everyone -- detected through `valid`, redone by panel_fixup_kernel.
@@ -598,15 +591,15 @@ static int launch_ss(const void* x, int64_t rows, int64_t ld, int q_type, const 
     // launch is latency-bound (a 4096-row Q4_K panel: 1024 waves, one per SIMD: 23 us against 36 / 31 us for the other
     // two; rows * groups >= 16384); 8 lanes per group for small
     // panels and rows that cannot be read with 16-byte (8-byte for 16-bit inputs) loads.
-    // GQ_SS_WIDE=1 / 0 / 2 forces the 8-lane / 1-lane / 2-lane kernel (A/B measurements, parity test).
+    // option ss_wide = 1 / 0 / 2 forces the 8-lane / 1-lane / 2-lane kernel (A/B measurements, parity test).
     const size_t esz = RM == 0 ? 4 : 2;
     const bool aligned = (reinterpret_cast<uintptr_t>(x) % 16 == 0) && ((size_t)ld * esz) % 16 == 0;
-    const char* wide_env = getenv("GQ_SS_WIDE");
+    const int64_t wide = opt(OPT_ss_wide);
     const int64_t ngroups = rows * (256 / ti.group);
     int lpg = !aligned ? 8 : (ngroups >= 65536 ? 1 : (ngroups >= 16384 ? 2 : 8));
-    if (wide_env && wide_env[0] == '1') lpg = 8;
-    if (wide_env && wide_env[0] == '0' && aligned) lpg = 1;
-    if (wide_env && wide_env[0] == '2' && aligned) lpg = 2;
+    if (wide == 1) lpg = 8;
+    if (wide == 0 && aligned) lpg = 1;
+    if (wide == 2 && aligned) lpg = 2;
     const int rpw = lpg == 8 ? (ti.group == 32 ? 4 : 2) : 64 / ((256 / ti.group) * lpg);
     dim3 grid((unsigned)((rows + rpw - 1) / rpw)), block(lpg == 8 ? 256 : 64);
     ProfScope ps(PT_SCALE_SEARCH, st);

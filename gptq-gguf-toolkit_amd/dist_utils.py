@@ -110,7 +110,7 @@ def allreduce_hessian(H, num_samples=None, dst=None):
 
 
 def _packs_upper(C: int) -> bool:
-    return C % 128 == 0 and C >= 1024 and os.environ.get("GQ_ALLREDUCE_FULL") is None
+    return C % 128 == 0 and C >= 1024
 
 
 def hessian_payload_bytes(C: int) -> int:

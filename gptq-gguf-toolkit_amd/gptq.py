@@ -64,9 +64,7 @@ class GPTQ:
         self._fill = 0                 # pending tokens (kept blocks + staged rows)
         self._staged = 0               # rows of _buf in use
         self._segs = []                # zero-copy: (tensor, version at hook time, batch size) per pending sample
-        self._marks = []               # BlockSchedule: numbers of pending samples at which a fold was postponed
-        self._marked = 0               # ... and the pending tokens those postponed folds cover
-        self._zero_copy = os.environ.get("GQ_STAGE_COPY") != "1"
+        self._zero_copy = True         # False: copy every activation into the staging buffer at hook time
         self._buf_b = 0
         self._U_cache = None
         self._last_U = None
@@ -108,7 +106,7 @@ class GPTQ:
         """Append x [t, C] to the staging buffer (behind the kept zero-copy blocks, which move into it first)."""
         if self._pending_dtype() not in (None, x.dtype):
             self.flush()  # one activation dtype per fold
-        pend, self._segs, self._marks, self._marked = [y for y, _, _ in self._segs], [], [], 0
+        pend, self._segs = [y for y, _, _ in self._segs], []
         need = self._staged + sum(y.shape[0] for y in pend) + x.shape[0]
         if self._buf is not None and (self._buf.dtype != x.dtype or need > self._buf.shape[0]):
             if self._staged:  # the staged rows are exactly the samples counted so far (pend is empty in this mode)
@@ -137,39 +135,25 @@ class GPTQ:
         _ops.h_accumulate(H, X, beta, alpha)
         self._flush_done()
 
-    def _flush_args(self, upto: Optional[int] = None):
+    def _flush_args(self):
         """(H, X, beta, alpha) of the pending fold; X is [T, C] or the list of kept [L, C] blocks.  b samples at
-        once are the telescoped form of b single updates of gptq.py:106-112.  `upto`: only the first `upto` kept
-        blocks (a fold the block schedule postponed; pair with _flush_done(upto))."""
+        once are the telescoped form of b single updates of gptq.py:106-112."""
         n, b = self.num_samples, self._buf_b
         if self._segs:
-            segs = self._segs if upto is None else self._segs[:upto]
-            for x, v, _ in segs:
+            for x, v, _ in self._segs:
                 if x._version != v:
-                    raise RuntimeError("a Linear input was modified in place after its forward hook ran; set "
-                                       "GQ_STAGE_COPY=1 to copy activations at hook time")
-            X = [x for x, _, _ in segs]
-            b = sum(bs for _, _, bs in segs)
+                    raise RuntimeError("a Linear input was modified in place after its forward hook ran; set the handle's "
+                                       "_zero_copy = False to copy activations at hook time")
+            X = [x for x, _, _ in self._segs]
         else:
             X = self._buf[:self._staged]
         return self.H, X, n / (n + b), 2.0 / (n + b)
 
-    def _flush_done(self, upto: Optional[int] = None) -> None:
-        if upto is not None and self._segs:
-            done, self._segs = self._segs[:upto], self._segs[upto:]
-            b = sum(bs for _, _, bs in done)
-            self.num_samples += b
-            self._buf_b -= b
-            t = sum(x.shape[0] for x, _, _ in done)
-            self._fill -= t
-            self._marked = max(0, self._marked - t)
-            return
+    def _flush_done(self) -> None:
         self.num_samples += self._buf_b
         self._fill = 0
         self._staged = 0
         self._segs = []
-        self._marks = []
-        self._marked = 0
         self._buf_b = 0
 
     def reset(self) -> None:
@@ -183,8 +167,6 @@ class GPTQ:
         self._fill = 0
         self._staged = 0
         self._segs = []
-        self._marks = []
-        self._marked = 0
         self._buf_b = 0
         self._reduced = False
         self.shared_H_with = None
@@ -217,6 +199,8 @@ class GPTQ:
             self.H = leader.H
             self._reduced = True
             return
+        if self._reduced:
+            return  # (a non-owner rank has dropped its copy by now: reduce_to)
         if not self.allow_no_samples:
             assert self.H is not None, "One has to process at least one sample of calibration data to run pruning"
         if self.H is None:  # this rank saw no token of this expert: it still takes part in the collective
@@ -234,6 +218,10 @@ class GPTQ:
                 # every dense Linear: the reference's AVG, no host sync (reduce_to: to the one rank that needs it)
                 dist_utils.allreduce_hessian(self.H, dst=self.reduce_to)
             self._reduced = True
+            if self.reduce_to is not None and self.reduce_to != dist_utils.get_rank() and dist_utils.get_world_size() > 1:
+                # reduced to its one owner: this rank's copy (a partial sum now) is dead weight -- 822 MB per 14336-wide
+                # Hessian, eight of them per Mixtral block
+                self.H = None
 
     @torch.no_grad()
     def make_working_copy(self) -> None:
@@ -274,14 +262,17 @@ class GPTQ:
         return bool(self._flag is not None and int(self._flag.item()) != 0)
 
     @torch.no_grad()
-    def compute(self, q_type: GGMLQuantizationType, defer_check: bool = False, own_U: bool = False):
-        """Rank-local numerical body of step() (reference gptq.py:158-276); no communication."""
+    def compute(self, q_type: GGMLQuantizationType, defer_check: bool = False, own_U: bool = False, after_prepare=None):
+        """Rank-local numerical body of step() (reference gptq.py:158-276); no communication.  `after_prepare()` is called
+        between the factorisation and the column loop (the block schedule records an event there)."""
         if q_type == GGMLQuantizationType.Q3_K:  # reference gptq.py:204-206 mutates the handle
             self.act_order = False
             self.static_groups = False
         if self.act_order:
             return self._compute_act_order(q_type)
         U = self._prepare(defer_check, own_U)
+        if after_prepare is not None:
+            after_prepare()
         self._last_U = U  # for inspection (bench.py's cpu_baseline leg re-runs the column loop on the same U); dropped by reset()
         W = self.W
         if self._row_split_active():

@@ -11,6 +11,7 @@ import torch
 
 from . import _cabi
 from ._cabi import F16, F32, BF16, Search, check, lib, type_info
+from ._cabi import option_get, option_set, options  # noqa: F401  (library tuning / test switches)
 
 _DT = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
 
@@ -267,11 +268,6 @@ def uses_helper_stream(R: int, C: int, block_size) -> bool:
 def far_helper_enable(on: bool) -> bool:
     """Allow / forbid the library's helper stream for the column loops enqueued from now on; returns the previous setting."""
     return bool(lib().gq_far_helper_enable(int(bool(on))))
-
-
-def syrk_workgroups(n: int) -> int:
-    """Resident workgroups of this thread's next persistent SYRK launches (gq_syrk_workgroups); returns the previous value."""
-    return int(lib().gq_syrk_workgroups(int(n)))
 
 
 def gptq_quantize_perm(W: torch.Tensor, U: torch.Tensor, q_type: int, perm: torch.Tensor, d, s, dmin, m, block_size=128,

@@ -160,8 +160,9 @@ class _Saver:
     slot out and runs torch.save.  Why a process: torch.save holds the interpreter lock for much of its 0.7 s per GB and
     Llama-3-8B leaves 8.7 GB of data.pth behind -- written from a thread of this process, the launches of the next
     block's forwards stall; why pinned slots: fresh pageable host tensors cost 6-9 s in page faults.
-    GQ_SAVE_MODE=thread keeps everything in-process; `sync=True` (CPU tensors, or GQ_SYNC_SAVE=1) writes in line like
-    the reference."""
+    `_Saver.USE_PROCESS = False` keeps everything in-process; `sync=True` (CPU tensors) writes in line like the reference."""
+
+    USE_PROCESS, KERNEL_COPY, INLINE = True, True, True
 
     def __init__(self, save_dir: str, sync: bool):
         self.save_dir, self.sync = save_dir, sync
@@ -173,9 +174,11 @@ class _Saver:
         self.slots: List[torch.Tensor] = []
         self._writer_dead = False
         self._final = None
-        self.use_process = os.environ.get("GQ_SAVE_MODE", "process") == "process"
-        self._kernel_copy = os.environ.get("GQ_SAVE_MEMCPY") != "1"  # (GQ_SAVE_MEMCPY=1: hipMemcpyAsync, the r02 path)
-        self._inline = os.environ.get("GQ_SAVE_INLINE", "1") != "0"
+        # class-level switches (profiles/ probes flip them; the measured alternatives are in DESIGN.md 6b): torch.save in a
+        # writer PROCESS (False: in this process's copier thread), copy kernels through the slot's device mapping (False:
+        # hipMemcpyAsync), staged by the caller's thread on its own stream (False: by the copier thread on a stream of its own
+        # -- which puts the run into the slow mode of DESIGN.md 6b)
+        self.use_process, self._kernel_copy, self._inline = _Saver.USE_PROCESS, _Saver.KERNEL_COPY, _Saver.INLINE
         self.n_slots = max(2, int(os.environ.get("GQ_SAVE_SLOTS", 3)))
         self._ready = threading.Event()
         self._poll_lock = threading.Lock()
@@ -551,7 +554,7 @@ class Quantizer:
     def quantize(self, quant_config: Dict[str, GGMLQuantizationType]) -> None:
         device = self.device or next(self.model.parameters()).device
         self._save_index = -1
-        self._saver = _Saver(self.save_dir, sync=os.environ.get("GQ_SYNC_SAVE") == "1")
+        self._saver = _Saver(self.save_dir, sync=False)
         if os.environ.get("GQ_SAVE_SKIP") != "1":
             self._saver.warm_up(device)
         self._saved_names: List[str] = []
@@ -666,7 +669,7 @@ class Quantizer:
             # instead of after the whole model, and the host never waits for the device here
             BlockSchedule.verify(wait=False)
             ph.mark("forward2")
-            if os.environ.get("GQ_TRACE_BLOCKS") == "1":  # measurement knob: per-block wall time (synchronises)
+            if "blocks" in os.environ.get("GQ_TRACE", ""):  # measurement knob: per-block wall time (synchronises)
                 torch.cuda.synchronize()
                 now = time.perf_counter()
                 ms = torch.cuda.memory_stats(device)

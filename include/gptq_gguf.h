@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define GQ_ABI_VERSION 3
+#define GQ_ABI_VERSION 4
 
 /* ggml type ids (quant_utils.py:11-16) */
 enum { GQ_Q2_K = 10, GQ_Q3_K = 11, GQ_Q4_K = 12, GQ_Q5_K = 13, GQ_Q6_K = 14 };
@@ -78,6 +78,42 @@ typedef struct {
 
 int gq_abi_version(void);
 const char* gq_last_error(void);
+
+/* ---- environment and options -------------------------------------------------------------------------------------
+   The LIBRARY reads two environment variables:
+     GQ_OPTIONS    "name=value,name=value" (a bare name means 1): initial values of the options below, read once at the
+                   first call; an unknown name aborts (a typo must not silently measure the default)
+     GQ_PROF_DUMP  file that gq_prof_collect2 appends every timed launch interval to (timeline studies)
+   The PYTHON package (host code) reads:
+     GQ_SO_PATH         another build of this library (kernel A/B probes)
+     GQ_CHAIN_STREAMS   lanes of the block schedule (default 4 = the hardware queues the chains of a block share)
+     GQ_ROW_SPLIT       0 / 1: never / always split the widest matrix by rows across ranks (default: from 4 ranks up)
+     GQ_POST_BLOCKS     early | before_last_block (default) | last: where lm_head is quantized (same tensors and files)
+     GQ_FUSED_FORWARD   off | exact | all: overrides the Quantizer's fused_forward argument (A/B runs)
+     GQ_SAVE_SKIP       1: no data.pth is written (measures what saving costs)
+     GQ_SAVE_SLOTS, GQ_SAVE_SLOT_MB   staging slots of the data.pth writer (3 x 704 MB)
+     GQ_TIMING          gpu: HIP-event split of the Quantizer's phases next to the host-side one
+     GQ_TRACE           comma list of "blocks" (per-block wall time, synchronises) and "sched" (the block schedule's enqueue log)
+   (quant.py also sets ROCm's GPU_MAX_HW_QUEUES=16 unless it is set.)  Nothing else is read from the environment.
+
+   Options (gq_option_set / gq_option_get; defaults in brackets) are tuning and test switches: no option changes a result
+   except where noted -- the tests flip them to prove exactly that.
+     syrk_128 [0] 128x128-tile SYRK everywhere | syrk_image [0] re-laid-out operand image instead of reading X in place |
+     syrk_nosplit [0] no K-split of the last round | syrk_persist [1] persistent launch with XCD rendezvous |
+     syrk_wgs [0 = one per CU] resident workgroups of that launch | syrk_stagger [0] waves 4-7 issue their DMA pieces late
+     chol_3p_min [1792] smallest half-node on the image GEMMs (0: never; changes U within the tolerance class) |
+     chol_planes [2] 2 = row-scaled fp16 x 2, 3 = bf16 x 3 (tolerance class) | chol_3b_min [1024] | chol_fp32 [0] fp32 MFMA only
+     (tolerance class) | chol_no_pair [0] | chol_no_equil [0] | chol_poison [0] NaN-fill scratch that must not be read |
+     diag_ref [0] column-by-column leaf kernel (tolerance class)
+     no_lookahead [0] | la [8] blocks per super-block | near_classic [0] | near_quad [0] | near64_maxn [768] | far_sync [0] |
+     far_async_max_rows [8192] | far_async_min_sb [8] | far_wgs [192] | chain_generic [0] | gemm32_64_max [256]
+     ss_wide [-1] scale-search mapping: -1 by size, 1 eight lanes, 0 one lane, 2 a lane pair per group
+     stage_host_wgs [0] workgroups of gq_stage_to_host */
+int gq_option_count(void);
+const char* gq_option_name(int i);                                   /* NULL past the end */
+int gq_option_get(const char* name, int64_t* value);
+int gq_option_default(const char* name, int64_t* value);
+int gq_option_set(const char* name, int64_t value, int64_t* previous); /* previous may be NULL; takes effect for later calls */
 int gq_type_info(int q_type, gq_type_info_t* out_host);
 
 /* Scratch bytes needed by an entry point.  op: one of GQ_WS_*; unused dims = 0. */
@@ -173,10 +209,6 @@ int gq_gptq_uses_helper_stream(int64_t R, int64_t C, int block_size);
 /* Process-wide switch of that helper stream for the calls enqueued from now on (1 = allowed, the default); returns the
    previous setting.  A scheduler with more chains than streams keeps all its streams and switches the helper off. */
 int gq_far_helper_enable(int on);
-/* Resident workgroups (8..256, a multiple of 8; anything else = 256, one per CU) of the persistent gq_h_accumulate*
-   launches the CALLING THREAD enqueues from now on; returns the previous value.  A fold that runs next to a
-   latency-bound chain of another stream leaves CUs free for it this way; results do not depend on it. */
-int gq_syrk_workgroups(int n);
 
 /* GPTQ.step with act_order=True (gptq.py:208-216, 233-235, 272-276; implies static_groups, gptq.py:45-46;
    not for Q3_K, gptq.py:204-206).  The caller permutes: perm = argsort(diag(H), descending) (int32 [C], on the

@@ -4,8 +4,6 @@ it is equilibrated; real activations are strongly correlated, so after the 1 % d
 has a condition number of 1e5-1e7.  `X = Z_r A + eps Z` with rank r << C, plus a few "massive activation" channels.
 Test infrastructure only (GPU tests, bench.py's checker leg, profiles/)."""
 import math
-import os
-from contextlib import contextmanager
 
 import torch
 
@@ -29,29 +27,17 @@ def correlated_x(T, C, rank, eps, seed, massive=6, massive_gain=1e3, mean_shift=
     return X.to(dtype)
 
 
-@contextmanager
 def env(**kv):
-    old = {k: os.environ.get(k) for k in kv}
-    try:
-        for k, v in kv.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = str(v)
-        yield
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+    """Library options for the block (gptq_gguf_toolkit_amd._cabi.options)."""
+    from gptq_gguf_toolkit_amd import ops
+    return ops.options(**kv)
 
 
-# the three forms of the level-3 work of the chain
+# the three forms of the level-3 work of the chain, as library options (`with env(**CHAIN_MODES[mode]):`)
 CHAIN_MODES = {
-    "default": {},                                              # image GEMMs (row-scaled fp16 x 2) on the top levels
-    "bf16x3": {"GQ_CHOL_BF16X3": "1"},                          # image GEMMs, exact 8+8+8 split, six products
-    "fp32": {"GQ_CHOL_3P_MIN": "0", "GQ_CHOL_FP32": "1"},       # v_mfma_f32_32x32x2_f32 everywhere = the reference's precision
+    "default": {},                                   # image GEMMs (row-scaled fp16 x 2) on the top levels
+    "bf16x3": {"chol_planes": 3},                    # image GEMMs, exact 8+8+8 split, six products
+    "fp32": {"chol_3p_min": 0, "chol_fp32": 1},      # v_mfma_f32_32x32x2_f32 everywhere = the reference's precision
 }
 
 

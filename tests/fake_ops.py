@@ -80,10 +80,6 @@ def far_helper_enable(on):
     return True
 
 
-def syrk_workgroups(n):
-    return 256
-
-
 def gptq_quantize_perm(W, U, q_type, perm, d, s, dmin, m, block_size=128, ws=None):
     calls["gptq_quantize"] += 1
     Wd, q = O.gptq_step_perm(W.numpy(), U.numpy(), q_type, perm.numpy(), _bits(d), s.numpy(), _bits(dmin), m.numpy(), block_size)

@@ -43,7 +43,7 @@ def test_cabi_exports_every_declared_symbol():
         assert hasattr(L, sym), f"{sym} declared in gptq_gguf.h but not exported"
     assert set(_cabi.EXPORTS) == declared
     lib = _cabi.lib()
-    assert lib.gq_abi_version() == _cabi.ABI_VERSION == 3
+    assert lib.gq_abi_version() == _cabi.ABI_VERSION == 4
     for t, ts in ((10, 84), (11, 110), (12, 144), (13, 176), (14, 210)):
         assert _cabi.type_info(t)["type_size"] == ts
     with pytest.raises(_cabi.GQError):
@@ -97,3 +97,36 @@ def test_integration_doc_search_struct_matches_the_header(tmp_path):
     from gptq_gguf_toolkit_amd import _cabi
     assert ctypes.sizeof(_cabi.Search) == size
     assert [n for n, _ in S._fields_] == [n for n, _ in _cabi.Search._fields_]
+
+
+def test_environment_variables_are_few_and_documented():
+    """the product reads at most 15 environment variables and include/gptq_gguf.h lists every one of
+    them; the library's tuning / test switches live in ONE option table (csrc/gq_common.hpp) reachable through
+    gq_option_set / GQ_OPTIONS, every option named in the header too; no timing-probe #ifdef is left in the shipped kernels."""
+    import glob
+    hdr = open(os.path.join(ROOT, "include", "gptq_gguf.h")).read()
+    pkg = os.path.join(ROOT, "gptq-gguf-toolkit_amd")
+    names = set()
+    for f in glob.glob(os.path.join(pkg, "*.py")):
+        src = open(f).read()
+        names |= set(re.findall(r"os\.environ(?:\.get|\.setdefault)?\(\s*[\"'](GQ_[A-Z0-9_]+)", src))
+        names |= set(re.findall(r"os\.environ\[\s*[\"'](GQ_[A-Z0-9_]+)", src))
+    for f in glob.glob(os.path.join(pkg, "csrc", "*.h*")):
+        names |= set(re.findall(r"getenv\(\s*\"(GQ_[A-Z0-9_]+)\"", open(f).read()))
+    assert "GQ_OPTIONS" in names and len(names) <= 15, sorted(names)
+    for n in sorted(names):
+        assert n in hdr, f"{n} is read by the product but not documented in include/gptq_gguf.h"
+    from gptq_gguf_toolkit_amd import _cabi
+    opts = _cabi.option_names()
+    assert len(opts) == len(set(opts)) >= 20
+    for o in opts:
+        assert re.search(rf"\b{o}\b", hdr), f"option {o} is not documented in include/gptq_gguf.h"
+        assert _cabi.option_get(o) == _cabi.option_default(o)
+    with _cabi.options(chol_fp32=1, la=4):
+        assert (_cabi.option_get("chol_fp32"), _cabi.option_get("la")) == (1, 4)
+    assert (_cabi.option_get("chol_fp32"), _cabi.option_get("la")) == (0, 8)
+    with pytest.raises(_cabi.GQError):
+        _cabi.option_set("no_such_option", 1)
+    for f in glob.glob(os.path.join(pkg, "csrc", "*.h*")):
+        src = open(f).read()
+        assert not re.findall(r"^\s*#\s*(?:ifdef|ifndef|if)\b", src, re.M), f"{os.path.basename(f)}: preprocessor conditionals in a shipped kernel source"

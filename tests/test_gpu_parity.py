@@ -147,7 +147,7 @@ def test_gptq_step_vs_oracle(ops, oracle, name, R, C, block):
 def test_gptq_lookahead_equals_per_block_updates(ops, R):
     """The look-ahead schedule (near updates inside a 1024-column super-block, ONE chained GEMM for all later
     columns) performs, per element, the same subtractions of the same k-ordered products in the same order as
-    gptq.py:270 applied block by block (GQ_NO_LOOKAHEAD=1): every output and the final W are bit-identical.
+    gptq.py:270 applied block by block (option no_lookahead): every output and the final W are bit-identical.
     R = 256 takes the whole-tile chained kernel, R = 200 the predicated one; C = 3328 = 3.25 super-blocks."""
     torch.manual_seed(R)
     C = 3328
@@ -159,14 +159,10 @@ def test_gptq_lookahead_equals_per_block_updates(ops, R):
     U, flag = ops.h_prepare(H, Wp, 0.01)
     assert int(flag.item()) == 0
     outs = []
-    for env in (None, "1"):
-        if env:
-            os.environ["GQ_NO_LOOKAHEAD"] = env
-        try:
+    for off in (0, 1):
+        with ops.options(no_lookahead=off):
             W = Wp.clone()
             outs.append((W,) + tuple(ops.gptq_quantize(W, U, 12, 128)))
-        finally:
-            os.environ.pop("GQ_NO_LOOKAHEAD", None)
     for a, b in zip(*outs):
         assert torch.equal(a.view(torch.uint8), b.view(torch.uint8))
 
@@ -174,7 +170,7 @@ def test_gptq_lookahead_equals_per_block_updates(ops, R):
 def test_h_prepare_never_reads_unwritten_scratch(ops):
     """gq_h_prepare does not clear its scratch: the inverse factor X is written block by block (diagonal blocks
     whole, with their zeros) and the k-range skips of the GEMMs never leave the written blocks.  With X filled with
-    NaN patterns beforehand (GQ_POISON_X=1; r03: A above its block diagonal too) the result must be the same, bit for
+    NaN patterns beforehand (option chol_poison; r03: A above its block diagonal too) the result must be the same, bit for
     bit, at a size that takes every level of the recursion below the image GEMMs (fp32 and split-bf16 GEMMs, 64- and
     128-tiles; the image levels: tests/test_gpu_round3.py)."""
     torch.manual_seed(4)
@@ -185,11 +181,8 @@ def test_h_prepare_never_reads_unwritten_scratch(ops):
     del X
     W = torch.randn(64, C, device="cuda")
     U0, f0 = ops.h_prepare(H.clone(), W.clone(), 0.01)
-    os.environ["GQ_POISON_X"] = "1"
-    try:
+    with ops.options(chol_poison=1):
         U1, f1 = ops.h_prepare(H.clone(), W.clone(), 0.01)
-    finally:
-        os.environ.pop("GQ_POISON_X", None)
     assert int(f0.item()) == 0 and int(f1.item()) == 0
     assert bool(torch.isfinite(U1).all()) and torch.equal(U0, U1)
 
@@ -198,7 +191,7 @@ def test_far_update_next_to_the_loop_changes_nothing(ops):
     """Many super-blocks, few rows: the far update of a super-block is cut by 1024-column groups -- the next group on
     the caller's stream, the rest on the library's helper stream as persistent launches (gq_gptq.hip) -- and runs next
     to the column loop.  Per element the same subtractions in the same order: bit-identical to the one-stream
-    schedule (GQ_FAR_SYNC=1) and to gptq.py:270 block by block (GQ_NO_LOOKAHEAD=1); C = 9472 = 9.25 super-blocks.
+    schedule (option far_sync) and to gptq.py:270 block by block (option no_lookahead); C = 9472 = 9.25 super-blocks.
     Of two such calls enqueued back to back on two streams only the first holds the helper (one holder per device at
     a time; the other runs the one-stream schedule): neither disturbs the other."""
     torch.manual_seed(9)
@@ -213,15 +206,11 @@ def test_far_update_next_to_the_loop_changes_nothing(ops):
     U, flag = ops.h_prepare(H, Wp, 0.01)
     assert int(flag.item()) == 0
     outs = []
-    for env in ({}, {"GQ_FAR_WGS": "24"}, {"GQ_FAR_SYNC": "1"}, {"GQ_NO_LOOKAHEAD": "1"}):
-        os.environ.update(env)
-        try:
-            assert ops.uses_helper_stream(R, C, 128) == (not env or "GQ_FAR_WGS" in env)
+    for kv in ({}, {"far_wgs": 24}, {"far_sync": 1}, {"no_lookahead": 1}):
+        with ops.options(**kv):
+            assert ops.uses_helper_stream(R, C, 128) == (not kv or "far_wgs" in kv)
             W = Wp.clone()
             outs.append((W,) + tuple(ops.gptq_quantize(W, U, 12, 128)))
-        finally:
-            for k in env:
-                os.environ.pop(k, None)
     torch.cuda.synchronize()
     for other in outs[1:]:
         for a, b in zip(outs[0], other):
@@ -237,12 +226,9 @@ def test_far_update_next_to_the_loop_changes_nothing(ops):
         Wc = Wb.clone()
         rb = ops.gptq_quantize(Wc, U, 14, 128)
     torch.cuda.synchronize()
-    os.environ["GQ_FAR_SYNC"] = "1"
-    try:
+    with ops.options(far_sync=1):
         Wd = Wb.clone()
         rd = ops.gptq_quantize(Wd, U, 14, 128)
-    finally:
-        os.environ.pop("GQ_FAR_SYNC", None)
     assert torch.equal(Wa, outs[0][0]) and all(torch.equal(a, b) for a, b in zip(ra, outs[0][1:]))
     assert torch.equal(Wc, Wd) and all(torch.equal(a, b) for a, b in zip(rb, rd))
 
@@ -387,18 +373,12 @@ def test_h_accumulate_natural_layout_equals_relayout(ops, dt):
     H0 = torch.randn(C, C, device="cuda")
     H0 = H0 + H0.T
     outs = []
-    for env in (None, "1"):
-        if env is None:
-            os.environ.pop("GQ_SYRK_IMAGE", None)
-        else:
-            os.environ["GQ_SYRK_IMAGE"] = env
-        try:
+    for image in (0, 1):
+        with ops.options(syrk_image=image):
             H = H0.clone()
             ops.h_accumulate(H, X[:1024], 0.25, 2.0 / 3)
             ops.h_accumulate(H, X[1024:], 0.5, 0.125)   # T = 512: a single turn of the ring
             outs.append(H)
-        finally:
-            os.environ.pop("GQ_SYRK_IMAGE", None)
     assert torch.equal(outs[0], outs[1])
     Xd = X.double()
     ref = 0.5 * (0.25 * H0.double() + (2.0 / 3) * (Xd[:1024].T @ Xd[:1024])) + 0.125 * (Xd[1024:].T @ Xd[1024:])
@@ -409,7 +389,7 @@ def test_h_accumulate_natural_layout_equals_relayout(ops, dt):
 @pytest.mark.parametrize("dt", [torch.float32, torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("q_type", [10, 11, 12, 13, 14])
 def test_group_search_lane_kernel_equals_wide_kernel(ops, q_type, dt):
-    """The lane-per-group search kernel (GQ_SS_WIDE=0; default for large panels), the lane-pair kernel (2; mid-size panels) and the 8-lanes-per-group kernel (1, also the
+    """The lane-per-group search kernel (option ss_wide = 0; default for large panels), the lane-pair kernel (2; mid-size panels) and the 8-lanes-per-group kernel (1, also the
     fallback for rows that are not 16-B aligned) add in the same order: every output is bit-identical, on ragged
     row counts, constant groups, all-zero rows and a misaligned view (which takes the wide kernel by itself)."""
     torch.manual_seed(31 + q_type)
@@ -421,12 +401,9 @@ def test_group_search_lane_kernel_equals_wide_kernel(ops, q_type, dt):
     x[8, 40:72] = x[8, 40:72].abs()
     x = x.to(dt)
     outs = []
-    for env in ("0", "1", "2"):   # one lane / eight lanes / a lane pair per group
-        os.environ["GQ_SS_WIDE"] = env
-        try:
+    for wide in (0, 1, 2):   # one lane / eight lanes / a lane pair per group
+        with ops.options(ss_wide=wide):
             outs.append(ops.group_search(x, q_type))
-        finally:
-            os.environ.pop("GQ_SS_WIDE", None)
     for other in outs[1:]:
         for a, b in zip(outs[0], other):
             assert torch.equal(a.view(torch.uint8) if a.dtype != torch.float32 else a.view(torch.int32),
@@ -434,11 +411,8 @@ def test_group_search_lane_kernel_equals_wide_kernel(ops, q_type, dt):
     # misaligned rows: a view that starts one element into a wider buffer
     buf = torch.zeros(rows, 264, device="cuda", dtype=dt)
     buf[:, 1:257] = x
-    os.environ["GQ_SS_WIDE"] = "0"
-    try:
+    with ops.options(ss_wide=0):
         mis = ops.group_search(buf[:, 1:257], q_type)
-    finally:
-        os.environ.pop("GQ_SS_WIDE", None)
     for a, b in zip(outs[0], mis):
         assert torch.equal(a.view(torch.uint8) if a.dtype != torch.float32 else a.view(torch.int32),
                            b.view(torch.uint8) if b.dtype != torch.float32 else b.view(torch.int32))
@@ -448,7 +422,7 @@ def test_group_search_lane_kernel_equals_wide_kernel(ops, q_type, dt):
 def test_h_accumulate_k_split_of_the_last_round(ops, Cs):
     """Long token ranges (T >= 8192): the tiles of the last, partial round of 256 CUs are cut into token ranges
     whose raw sums are combined by syrk_reduce_kernel in fixed order.  Checked against fp64 on every element of
-    the smallest Hessian and on sampled elements of the others, against the unsplit schedule (GQ_SYRK_NOSPLIT=1,
+    the smallest Hessian and on sampled elements of the others, against the unsplit schedule (option syrk_nosplit,
     fp32 summation-order tolerance), for exact symmetry, the beta/alpha telescoping and run-to-run determinism."""
     torch.manual_seed(77)
     T = 8192 + 384
@@ -456,15 +430,11 @@ def test_h_accumulate_k_split_of_the_last_round(ops, Cs):
     H0s = [torch.randn(C, C, device="cuda") for C in Cs]
     H0s = [h + h.T for h in H0s]
     outs = []
-    for env in (None, None, "1"):
-        if env:
-            os.environ["GQ_SYRK_NOSPLIT"] = env
-        try:
+    for nosplit in (0, 0, 1):
+        with ops.options(syrk_nosplit=nosplit):
             Hs = [h.clone() for h in H0s]
             ops.h_accumulate_grouped(Hs, Xs, [0.5] * len(Cs), [2.0 / T] * len(Cs))
             outs.append(Hs)
-        finally:
-            os.environ.pop("GQ_SYRK_NOSPLIT", None)
     for a, b, c_, X, H0, C in zip(outs[0], outs[1], outs[2], Xs, H0s, Cs):
         assert torch.equal(a, b)                      # deterministic
         assert torch.equal(a, a.T)

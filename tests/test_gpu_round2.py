@@ -65,11 +65,11 @@ def test_g1_group_search_golden(ops, name, wide):
     x = g[f"{name}_x"]
     G = GROUP[name]
     panels = dev(x.reshape(-1, 256))
-    os.environ["GQ_SS_WIDE"] = wide
+    _opt = ops.options(ss_wide=int(wide)).__enter__()  # the kernel mapping under test
     try:
         gs, gz, *_ = ops.group_search(panels, TYPES[name])
     finally:
-        os.environ.pop("GQ_SS_WIDE", None)
+        _opt.__exit__()
     assert bits_eq(npy(gs).ravel(), g[f"{name}_ieee_scale"]), "group scales differ from the reference"
     assert bits_eq(npy(gz).ravel(), g[f"{name}_ieee_zero"]), "group zeros differ from the reference"
 
@@ -289,45 +289,6 @@ def test_block_schedule_equals_per_handle_quantize(ops):
         assert torch.equal(l.weight.data, dequantize_linear_weight(qt[n], *ref, out_dtype=torch.float16))
 
 
-def test_postponed_narrow_folds_change_nothing(ops):
-    """Single rank: the narrow inputs' SYRK portions are postponed to quantize() and run on a side stream under the
-    widest input's chain (zero-copy references kept meanwhile).  Same portions, same order per Hessian: results
-    are bit-identical to folding as the samples arrive, with and without a tail portion, and when the budget of
-    kept bytes stops the postponement half way."""
-    from gptq_gguf_toolkit_amd.block_schedule import BlockSchedule
-    from gptq_gguf_toolkit_amd.gptq import GPTQ
-    from gptq_gguf_toolkit_amd.quant_utils import GGMLQuantizationType as T
-    qt = {"q_proj": T.Q3_K, "k_proj": T.Q2_K, "v_proj": T.Q4_K, "o_proj": T.Q5_K, "gate_proj": T.Q6_K,
-          "up_proj": T.Q4_K, "down_proj": T.Q4_K}
-    for n_samples, budget in ((6, None), (7, None), (7, 3 * 3 * 128 * 512 * 2)):
-        runs = {}
-        for defer in (False, True):
-            layers, xs = _toy_block(seed=11, L=128, n_samples=n_samples)
-            sched = BlockSchedule(layers, lambda l, n: GPTQ(l, rel_damp=0.01, block_size=128))
-            sched.defer_narrow = defer
-            if budget is not None:
-                sched.defer_bytes = budget  # three samples of the three narrow inputs
-            for h in sched.handles.values():
-                h.flush_tokens = 256  # a fold every two samples
-            for i in range(n_samples):
-                for n in layers:
-                    sched.feed(n, xs[n][i])
-                sched.sample_done()
-            hs = {n: h for n, h in sched.handles.items()}
-            pending = sum(len(h._marks) for h in hs.values())
-            out = sched.quantize(qt, writeback=True)
-            torch.cuda.synchronize()
-            runs[defer] = (out, {n: l.weight.data.clone() for n, l in layers.items()}, sched.stats, pending)
-        assert runs[False][2].get("postponed_folds", 0) == 0 and runs[False][3] == 0
-        # with the budget: postponed after sample 2, over budget at sample 4 (everything folded), postponed again at 6
-        assert runs[True][2]["postponed_folds"] == (3 if budget is None else 2) and runs[True][3] > 0
-        assert runs[True][2]["syrk_launches"] == runs[False][2]["syrk_launches"]
-        for n in qt:
-            for a, b in zip(runs[True][0][n], runs[False][0][n]):
-                assert torch.equal(a, b), f"{n}: postponed folds changed a result"
-            assert torch.equal(runs[True][1][n], runs[False][1][n])
-
-
 def test_block_schedule_follower_with_own_zero_column(ops):
     """A follower whose weight has an all-zero column its leader's does not: the speculative reuse of the leader's
     U is detected (gq_w_prepare flag) and the follower gets its own factorisation (gptq.py:307-313)."""
@@ -524,7 +485,7 @@ def test_panel_wide_continue(ops, oracle, name, wide):
     const[5] = 0.0
     mixed = tiny.copy()
     mixed[17] = (rng.standard_normal(256) * 0.02).astype(np.float32)
-    os.environ["GQ_SS_WIDE"] = wide
+    _opt = ops.options(ss_wide=int(wide)).__enter__()  # the kernel mapping under test
     try:
         outs = {}
         for tag, x in (("tiny", tiny), ("const", const), ("mixed", mixed)):
@@ -542,7 +503,7 @@ def test_panel_wide_continue(ops, oracle, name, wide):
         od, os_, odm, om = oracle.scale_search(tiny, t)
         assert np.array_equal(u16(d), od) and np.array_equal(npy(s), os_) and np.array_equal(npy(m), om)
     finally:
-        os.environ.pop("GQ_SS_WIDE", None)
+        _opt.__exit__()
     keep = np.arange(rows) != 17
     if name != "Q5_K":  # (with 5 bits no candidate of these groups ever wins, skipped or not: oracle, both panels)
         assert not np.array_equal(outs["tiny"][keep], outs["mixed"][keep]), "the panel-wide skip changed nothing"
@@ -597,7 +558,7 @@ def test_mse_quant_scale_golden(ops, oracle, name):
     g = load_golden("g12_mse_scale")
     t = TYPES[name]
     for wide in ("0", "1", "2"):
-        os.environ["GQ_SS_WIDE"] = wide
+        _opt = ops.options(ss_wide=int(wide)).__enter__()
         try:
             for tag in ("w", "mid", "wide"):
                 for mode in ("absmax", "mse"):
@@ -605,7 +566,7 @@ def test_mse_quant_scale_golden(ops, oracle, name):
                     assert np.array_equal(u16(d), g[f"{name}_{tag}_{mode}_d"]), (wide, tag, mode)
                     assert np.array_equal(npy(s), g[f"{name}_{tag}_{mode}_s"]), (wide, tag, mode)
         finally:
-            os.environ.pop("GQ_SS_WIDE", None)
+            _opt.__exit__()
     rng = np.random.default_rng(t)
     R, C = 96, 512
     W = (rng.standard_normal((R, C)) * 20.0).astype(np.float32)

@@ -86,11 +86,8 @@ def test_h_prepare_image_levels_never_read_unwritten_scratch(ops):
     H = _hessian(C, 4)
     W = torch.randn(64, C, device="cuda")
     U0, f0 = ops.h_prepare(H.clone(), W.clone(), 0.01)
-    os.environ["GQ_POISON_X"] = "1"
-    try:
+    with ops.options(chol_poison=1):
         U1, f1 = ops.h_prepare(H.clone(), W.clone(), 0.01)
-    finally:
-        os.environ.pop("GQ_POISON_X", None)
     assert int(f0.item()) == 0 and int(f1.item()) == 0
     assert bool(torch.isfinite(U1).all()) and torch.equal(U0, U1)
 
@@ -102,14 +99,10 @@ def test_equilibration_is_exact_for_the_scale_invariant_kernels(ops):
     C = 4096
     H = _hessian(C, 5)
     W = torch.randn(64, C, device="cuda")
-    os.environ["GQ_CHOL_3P_MIN"] = "0"
-    try:
+    with ops.options(chol_3p_min=0):
         U0, _ = ops.h_prepare(H.clone(), W.clone(), 0.01)
-        os.environ["GQ_CHOL_NO_EQUIL"] = "1"
-        U1, _ = ops.h_prepare(H.clone(), W.clone(), 0.01)
-    finally:
-        os.environ.pop("GQ_CHOL_3P_MIN", None)
-        os.environ.pop("GQ_CHOL_NO_EQUIL", None)
+        with ops.options(chol_no_equil=1):
+            U1, _ = ops.h_prepare(H.clone(), W.clone(), 0.01)
     assert torch.equal(U0, U1)
 
 
@@ -128,13 +121,9 @@ def test_image_chain_accuracy_wide_channel_scales(ops, mode):
     H = H * sig[:, None] * sig[None, :]
     H = (H + H.T) * 0.5
     W = torch.randn(64, C, device="cuda")
-    if mode == "bf16x3":
-        os.environ["GQ_CHOL_BF16X3"] = "1"
-    try:
+    with ops.options(chol_planes=3 if mode == "bf16x3" else 2):
         Hc = H.clone()
         U, flag = ops.h_prepare(Hc, W.clone(), 0.01)
-    finally:
-        os.environ.pop("GQ_CHOL_BF16X3", None)
     assert int(flag.item()) == 0
     Hd = Hc.double()  # damped in place by the call (gptq.py:315-316)
     ref = torch.linalg.cholesky(torch.cholesky_inverse(torch.linalg.cholesky(Hd)), upper=True)
@@ -146,16 +135,13 @@ def test_image_chain_accuracy_wide_channel_scales(ops, mode):
 def test_paired_node_launches_change_nothing(ops):
     """Below the image levels a recursion node issues its SYRK update and L21 X11 as ONE launch of 64-tiles
     (gemm32_pair_kernel); every output element is the same k-ordered fp32 chain as in the two separate launches
-    (GQ_CHOL_NO_PAIR=1), so U is identical bit for bit."""
+    (option chol_no_pair), so U is identical bit for bit."""
     C = 4096 + 896
     H = _hessian(C, 6)
     W = torch.randn(64, C, device="cuda")
     U0, f0 = ops.h_prepare(H.clone(), W.clone(), 0.01)
-    os.environ["GQ_CHOL_NO_PAIR"] = "1"
-    try:
+    with ops.options(chol_no_pair=1):
         U1, f1 = ops.h_prepare(H.clone(), W.clone(), 0.01)
-    finally:
-        os.environ.pop("GQ_CHOL_NO_PAIR", None)
     assert int(f0.item()) == 0 and torch.equal(U0, U1)
 
 
@@ -228,9 +214,13 @@ def test_bench_eight_ranks_one_allgather_per_block(workload):
     n = 8
     backend = "nccl" if torch.cuda.device_count() >= n else "gloo"
     env = dict(os.environ, GQ_BENCH_VERIFY="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if backend == "gloo":
+        # eight ranks SHARE one 288 GB GPU here: two chain lanes per rank instead of four (a Mixtral block holds 30 GB per
+        # rank with four 14336-wide factorisations in flight -- fine on a GPU of its own, too much eight times over)
+        env["GQ_CHAIN_STREAMS"] = "2"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
            "127.0.0.1", "--master-port", str(27000 + os.getpid() % 2000), os.path.join(ROOT, "bench.py"), "--gpus",
-           str(n), "--steps", "1", "--warmup", "1", "--workload", workload, "--backend", backend,
+           str(n), "--steps", "1", "--warmup", "1" if backend == "nccl" else "0", "--workload", workload, "--backend", backend,
            "--no-cpu-baseline", "--no-whole-model", "--no-side-legs"]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=2400, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-3000:]
@@ -289,17 +279,18 @@ print("HASH", h.hexdigest())
 
 
 def test_trailing_update_kernel_choices_are_bit_identical():
-    """The column loop's trailing updates have three kernels that are selected per process (environment read once):
-    the 64-tile near kernel with whole K = 256 panels in LDS (default) vs the 128-tile chained kernel
-    (GQ_NEAR64_MAXN=0), and the far update with DMA'd chunks (GQ_FAR_DMA=1 / 2: four- / two-slot ring, opt-in) vs register-staged chunks.  Every
-    output element is the same k-ordered chain in all of them: W and the quantized tensors hash identically."""
+    """The column loop's trailing updates have several kernels: the 64-tile near kernel with whole K = 256 panels in LDS
+    (default) vs the 128-tile chained kernel (option near64_maxn = 0), the pair form of the near updates vs a launch after
+    every block (near_classic), the dedicated far kernel vs the generic chained one (chain_generic), set through the
+    process's GQ_OPTIONS variable.  Every output element is the same k-ordered chain in all of them: W and the quantized
+    tensors hash identically."""
     import subprocess
     import sys
     from conftest import ROOT
     hashes = {}
-    for tag, extra in (("default", {}), ("near128", {"GQ_NEAR64_MAXN": "0"}), ("far_dma", {"GQ_FAR_DMA": "1"}),
-                       ("far_dma_two_slots", {"GQ_FAR_DMA": "2"}), ("classic", {"GQ_NEAR_CLASSIC": "1"})):
-        env = dict(os.environ, **extra)
+    for tag, opts in (("default", ""), ("near128", "near64_maxn=0"), ("classic", "near_classic"), ("generic_far", "chain_generic=1"),
+                      ("quad", "near_quad=1")):
+        env = dict(os.environ, GQ_OPTIONS=opts)
         p = subprocess.run([sys.executable, "-c", _LOOP_HASH.format(root=ROOT)], env=env, capture_output=True, text=True,
                            timeout=600)
         assert p.returncode == 0, p.stderr[-2000:]

@@ -85,7 +85,7 @@ def test_image_chain_on_correlated_hessians(ops, C, T, rank, eps, massive, mean)
     """X = Z_r A + eps Z (+ 6 channels x 1e3 | + a constant offset): the equilibrated, damped matrix the chain factorises
     has cond 1e1 ... 1.4e7 (profiles/r04_chol_corr_probe.txt lists cond and all three forms per case).
     (i) the default chain's error of U against the fp64 chain -- row-wise and in the max norm -- is at most 1.25 x that of the
-    all-fp32 chain (GQ_CHOL_FP32=1 + image levels off = the reference's precision, linalg_utils.py:8-12) on the same matrix.
+    all-fp32 chain (options chol_fp32 + chol_3p_min = 0: image levels off = the reference's precision, linalg_utils.py:8-12) on the same matrix.
     Measured: 0.1 - 0.7 x everywhere -- the 16-bit MFMAs add 32 exact products per rounding, the fp32 instruction two;
     (ii) both agree on the non-PD flag."""
     X = correlated_x(T, C, rank, eps, seed=C + rank + int(eps * 100), massive=massive, mean_shift=mean)
