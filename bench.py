@@ -651,14 +651,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-whole-model", action="store_true", help="skip the whole-model leg of the block workloads")
     ap.add_argument("--no-side-legs", action="store_true", help="skip trailing_update / tolerance_parity legs")
-    ap.add_argument("--no-stagger", action="store_true", help="A/B: all chains of a block start together (r03's schedule)")
     ap.add_argument("--breakdown", action="store_true", help="one extra profiled step: per-kernel ms to stderr")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend: nccl (= RCCL over xGMI, default); gloo only to exercise the "
                          "N>1 code path with several ranks sharing one GPU")
     args = ap.parse_args()
-    if args.no_stagger:
-        BlockSchedule.stagger_chains = False
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

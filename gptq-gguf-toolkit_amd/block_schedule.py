@@ -99,10 +99,9 @@ def _zero_columns(w: torch.Tensor) -> torch.Tensor:
 
 class BlockSchedule:
     unverified: List[torch.Tensor] = []  # device flags of speculative U reuses, see verify()
-    # r04: the other chains start when the COSTLIEST chain's factorisation is through (an event between its gq_h_prepare
-    # and its column loop) instead of next to it: the widest Hessian's chain of ~560 small dependent launches takes 25 ms
-    # next to three other chains' GEMMs and 14.6 ms alone, and what the others have to do fits under its column loop
-    stagger_chains = True
+    # (Measured and removed, r04: starting the other chains only when the costliest chain's factorisation is through -- it
+    # takes 25 ms next to three other chains' GEMMs and 14.6 ms alone -- 96.4 vs 88.9 ms per step: what the others have to do
+    # does NOT fit under its column loop.)
 
     def __init__(self, layers: Dict[str, nn.Module], make_handle: Callable[[nn.Module, str], GPTQ],
                  n_streams: Optional[int] = None, verbose: bool = False):
@@ -393,7 +392,6 @@ class BlockSchedule:
             results: Dict[str, tuple] = {}
             deq: Dict[str, torch.Tensor] = {}
             lanes = []
-            prepared = None
             trace = "sched" in os.environ.get("GQ_TRACE", "")
             t_host = time.perf_counter()
             # lanes: longest-processing-time-first over all lanes; the costliest chain comes first and lands on lane 0 = the
@@ -411,12 +409,6 @@ class BlockSchedule:
                 lane = _Lane(streams[lane_of[k]] if streams else None, main)
                 lead = handles[names[0]].shared_H_with or handles[names[0]]
                 lane.wait(ready.get(id(lead), start))
-                if k > 0 and prepared is not None:
-                    lane.wait(prepared)  # (chain 0 was enqueued first: the event is recorded by now)
-                mark = None
-                if k == 0 and on_gpu and self.stagger_chains and len(order) > 1 and streams and lane.stream is None:
-                    prepared = torch.cuda.Event()
-                    mark = lambda ev=prepared: ev.record(main)  # noqa: E731
                 born = []
                 with lane.run():
                     # the leader first: it factorises, the followers reuse its U
@@ -427,8 +419,7 @@ class BlockSchedule:
                         h.make_working_copy()
                         # follower with the same zero columns as its leader: reuse (flag kept for verify());
                         # different: own factorisation; unknown (first fed after the first sample): checked below
-                        res = h.compute(qtypes[n], defer_check=True, own_U=own.get(n, False), after_prepare=mark)
-                        mark = None  # once per chain: after the leader's factorisation
+                        res = h.compute(qtypes[n], defer_check=True, own_U=own.get(n, False))
                         if n in own and h._pending_mismatch is not None:
                             BlockSchedule.unverified.append(h._pending_mismatch)
                             h._pending_mismatch = None

@@ -42,7 +42,6 @@ extern thread_local char g_err[512];
     X(syrk_nosplit, 0)      /* 1: no K-split of the last, partial round of tiles */                                     \
     X(syrk_persist, 1)      /* 0: one tile per workgroup instead of the persistent launch with XCD rendezvous */         \
     X(syrk_wgs, 0)          /* resident workgroups of the persistent launch (0: one per CU) */                          \
-    X(syrk_stagger, 0)      /* 1: waves 4-7 issue their LDS-DMA pieces at the end of a k32 step */                       \
     /* K3 Cholesky chain */                                                                                            \
     X(chol_3p_min, 1792)    /* smallest half of a recursion node that runs on the image GEMMs (0: never) */             \
     X(chol_planes, 2)       /* 2: row-scaled fp16 x 2 images, 3: exact bf16 x 3 */                                      \

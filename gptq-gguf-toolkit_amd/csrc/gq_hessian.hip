@@ -123,9 +123,6 @@ struct SyrkGroup {
     // of XCD x that finished a round; a round starts when all of them have, so the 32 tiles an XCD works on at a
     // time stay in step and share their 12 operand panels through the XCD's L2.  nullptr: one tile per workgroup.
     unsigned* bar;
-    // syrk16_256n_kernel: 1 = the second wave of every SIMD (waves 4-7) issues its four LDS-DMA pieces of a step behind the
-    // step's LAST MFMAs instead of its middle, so that the eight waves do not queue at the vector-memory unit together
-    int stagger;
 };
 
 template <bool BF16>
@@ -544,14 +541,14 @@ __global__ __launch_bounds__(512, 2) void syrk16_256e_kernel(const SyrkGroup grp
 // Per k32 step: 32 MFMAs; fragments a0,b0..b3,a1,a2 of the NEXT half-stage are read behind MFMAs 12..25 into the
 // other register set, a3..a7 of the CURRENT one behind MFMAs 0..9 (single set) -- never more than 15 LDS reads in
 // flight (lgkmcnt is 4 bits).  Requires T % 128 == 0 (whole ring turns); other T take the re-layout path.
+// (Measured and removed, r04, profiles/r04_syrk_stagger_ab.txt: waves 4-7 issuing their DMA pieces behind the step's last
+// MFMAs instead of its middle -- 1.21 vs 1.24 PFLOP/s, matrix pipe 76.5 vs 80.2 % busy; s_setprio 1 for waves 4-7: no change.)
 template <bool BF16>
 __global__ __launch_bounds__(512, 2) void syrk16_256n_kernel(const SyrkGroup grp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid >> 2, wn = wid & 3;
-    const bool late = (grp.stagger & 1) && wid >= 4;  // wave-uniform (wid is an SGPR value)
-    if ((grp.stagger & 2) && wid >= 4) __builtin_amdgcn_s_setprio(1);  // static priority for the younger wave of every SIMD
     int round = 0;
     for (int slot = (int)(blockIdx.x >> 3); slot < grp.per_xcd; slot += (int)(gridDim.x >> 3), ++round) {
     if (grp.bar && round > 0) {  // XCD-wide rendezvous between rounds (persistent launch)
@@ -700,7 +697,7 @@ __global__ __launch_bounds__(512, 2) void syrk16_256n_kernel(const SyrkGroup grp
         else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(A_), "v"(B_));     \
     } while (0)
 #define GQ_NBAR() asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory")
-#define GQ_NSTEP(X, Y, AC, OFFC, AN, BN, OFFN, L0, L1, L2, L3, M0, M1, M2, M3)                        \
+#define GQ_NSTEP(X, Y, AC, OFFC, AN, BN, OFFN, L0, L1, L2, L3)                                        \
     do {                                                                                              \
         GQ_NWAIT(12, X##a0l, X##a0h);                                                                 \
         GQ_NWAIT(10, X##b0l, X##b0h);                                                                 \
@@ -770,21 +767,15 @@ __global__ __launch_bounds__(512, 2) void syrk16_256n_kernel(const SyrkGroup grp
         GQ_NWAIT(13, la7l, la7h);                                                                     \
         GQ_NRD(Y##a2h, AN, 2, (OFFN) + 2048);                                                         \
         GQ_NMF(c62, la6l, la6h, X##b2l, X##b2h);                                                      \
-        M0;                                                                                           \
         GQ_NMF(c63, la6l, la6h, X##b3l, X##b3h);                                                      \
         GQ_NMF(c70, la7l, la7h, X##b0l, X##b0h);                                                      \
-        M1;                                                                                           \
         GQ_NMF(c71, la7l, la7h, X##b1l, X##b1h);                                                      \
-        M2;                                                                                           \
         GQ_NMF(c72, la7l, la7h, X##b2l, X##b2h);                                                      \
-        M3;                                                                                           \
         GQ_NMF(c73, la7l, la7h, X##b3l, X##b3h);                                                      \
     } while (0)
 #define GQ_NINTERVAL(X, Y, AC, OFFC, AN, BN, OFFN, SLOT3)                                             \
-    GQ_NSTEP(X, Y, AC, OFFC, AN, BN, OFFN, if (!late) GQ_NDL(voff0, SLOT3, 0), if (!late) GQ_NDL(voff1, SLOT3, 1), \
-             if (!late) GQ_NDL(voff2, SLOT3, 2), if (!late) GQ_NDL(voff3, SLOT3, 3),                  \
-             if (late) GQ_NDL(voff0, SLOT3, 0), if (late) GQ_NDL(voff1, SLOT3, 1),                    \
-             if (late) GQ_NDL(voff2, SLOT3, 2), if (late) GQ_NDL(voff3, SLOT3, 3));                   \
+    GQ_NSTEP(X, Y, AC, OFFC, AN, BN, OFFN, GQ_NDL(voff0, SLOT3, 0), GQ_NDL(voff1, SLOT3, 1),          \
+             GQ_NDL(voff2, SLOT3, 2), GQ_NDL(voff3, SLOT3, 3));                                       \
     GQ_NADV();
 
     for (int h = 0; h < 3; ++h) {
@@ -1039,7 +1030,6 @@ static int syrk16_launch(int kind, const int* idx, int m, float* const* H, const
     grp.aux = nullptr;
     grp.partial = nullptr;
     grp.bar = nullptr;
-    grp.stagger = (int)opt(OPT_syrk_stagger);
     int n_reduce = 0;
     const uint32_t* reduce_list = nullptr;
     std::vector<uint32_t> table;

@@ -108,14 +108,21 @@ class GPTQ:
             self.flush()  # one activation dtype per fold
         pend, self._segs = [y for y, _, _ in self._segs], []
         need = self._staged + sum(y.shape[0] for y in pend) + x.shape[0]
+        cap = self.flush_tokens + x.shape[0]  # a fold is due by then
+        if self._buf is not None and self._buf.dtype == x.dtype and self._buf.shape[0] < need <= cap:
+            # grow geometrically and keep the staged rows: an MoE expert sees a data-dependent share of the tokens (and 1/N of
+            # them on N ranks) -- sizing every expert's buffer for a whole fold up front cost 19 GB per rank on a Mixtral block
+            bigger = torch.empty((min(cap, max(2 * self._buf.shape[0], need)), self.d_col), device=x.device, dtype=x.dtype)
+            if self._staged:
+                _ops.h_stage(bigger, 0, self._buf[:self._staged])
+            self._buf = bigger
         if self._buf is not None and (self._buf.dtype != x.dtype or need > self._buf.shape[0]):
             if self._staged:  # the staged rows are exactly the samples counted so far (pend is empty in this mode)
                 self.flush()
                 need = x.shape[0]
             self._buf = None
         if self._buf is None:
-            self._buf = torch.empty((max(self.flush_tokens + x.shape[0], need), self.d_col), device=x.device,
-                                    dtype=x.dtype)
+            self._buf = torch.empty((max(need, min(cap, 4 * need)), self.d_col), device=x.device, dtype=x.dtype)
         for y in pend + [x]:
             _ops.h_stage(self._buf, self._staged, y)
             self._staged += y.shape[0]
@@ -262,17 +269,14 @@ class GPTQ:
         return bool(self._flag is not None and int(self._flag.item()) != 0)
 
     @torch.no_grad()
-    def compute(self, q_type: GGMLQuantizationType, defer_check: bool = False, own_U: bool = False, after_prepare=None):
-        """Rank-local numerical body of step() (reference gptq.py:158-276); no communication.  `after_prepare()` is called
-        between the factorisation and the column loop (the block schedule records an event there)."""
+    def compute(self, q_type: GGMLQuantizationType, defer_check: bool = False, own_U: bool = False):
+        """Rank-local numerical body of step() (reference gptq.py:158-276); no communication."""
         if q_type == GGMLQuantizationType.Q3_K:  # reference gptq.py:204-206 mutates the handle
             self.act_order = False
             self.static_groups = False
         if self.act_order:
             return self._compute_act_order(q_type)
         U = self._prepare(defer_check, own_U)
-        if after_prepare is not None:
-            after_prepare()
         self._last_U = U  # for inspection (bench.py's cpu_baseline leg re-runs the column loop on the same U); dropped by reset()
         W = self.W
         if self._row_split_active():
