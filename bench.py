@@ -791,13 +791,13 @@ def main():
         # driver's run cannot carry counters: a --pmc run serialises the kernels).  The file names the kernel sources it
         # was measured on; for any other build the field is null -- a stale constant is not a measurement.
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r03_syrk_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r04_syrk_traffic.json")
         if os.path.exists(tpath) and args.workload == "llama3-8b-block-q4k" and world == 1 and not args.calib_seqs \
                 and not args.seq_len:
             try:
                 import glob
                 import hashlib
-                tj = json.load(open(tpath))  # written by profiles/collect_r03.sh
+                tj = json.load(open(tpath))  # written by profiles/collect_r04.sh
                 hsh = hashlib.sha256()
                 for fn in sorted(glob.glob(os.path.join(ROOT, "gptq-gguf-toolkit_amd", "csrc", "*.h*"))):
                     hsh.update(open(fn, "rb").read())
@@ -805,7 +805,7 @@ def main():
                     traffic = {"GB_per_launch": tj["GB_per_launch"], "algorithmic_GB_per_launch": tj.get("algorithmic_GB_per_launch"),
                                "measured_on": tj.get("measured_on"), "launches": tj.get("launches")}
                 else:
-                    traffic = {"GB_per_launch": None, "note": "profiles/r03_syrk_traffic.json was measured on other kernel "
+                    traffic = {"GB_per_launch": None, "note": "profiles/r04_syrk_traffic.json was measured on other kernel "
                                                               "sources than this build's: not reported"}
             except Exception:
                 traffic = None

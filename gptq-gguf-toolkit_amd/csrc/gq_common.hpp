@@ -23,10 +23,15 @@ extern thread_local char g_err[512];
         return (code);                                    \
     } while (0)
 
+// (a failed call leaves the runtime's sticky "last error" set: it is consumed here, so that the NEXT launch check of the
+// process does not report it again for an unrelated kernel)
 #define GQ_HIP(expr)                                                                         \
     do {                                                                                     \
         hipError_t _e = (expr);                                                              \
-        if (_e != hipSuccess) GQ_FAIL(GQ_E_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
+        if (_e != hipSuccess) {                                                              \
+            (void)hipGetLastError();                                                         \
+            GQ_FAIL(GQ_E_HIP, "%s failed: %s", #expr, hipGetErrorString(_e));                \
+        }                                                                                    \
     } while (0)
 
 #define GQ_LAUNCH_CHECK() GQ_HIP(hipGetLastError())
