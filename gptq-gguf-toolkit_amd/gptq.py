@@ -110,9 +110,9 @@ class GPTQ:
         need = self._staged + sum(y.shape[0] for y in pend) + x.shape[0]
         cap = self.flush_tokens + x.shape[0]  # a fold is due by then
         if self._buf is not None and self._buf.dtype == x.dtype and self._buf.shape[0] < need <= cap:
-            # grow geometrically and keep the staged rows: an MoE expert sees a data-dependent share of the tokens (and 1/N of
+            # grow geometrically (x 4: the copies add up to a third of the final size) and keep the staged rows: an MoE expert sees a data-dependent share of the tokens (and 1/N of
             # them on N ranks) -- sizing every expert's buffer for a whole fold up front cost 19 GB per rank on a Mixtral block
-            bigger = torch.empty((min(cap, max(2 * self._buf.shape[0], need)), self.d_col), device=x.device, dtype=x.dtype)
+            bigger = torch.empty((min(cap, max(4 * self._buf.shape[0], need)), self.d_col), device=x.device, dtype=x.dtype)
             if self._staged:
                 _ops.h_stage(bigger, 0, self._buf[:self._staged])
             self._buf = bigger
