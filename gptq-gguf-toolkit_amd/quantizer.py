@@ -428,12 +428,15 @@ class _Saver:
         self.q.put(("copy", name, q_type, tensors, ev, dev))
 
     def close(self):
+        t0 = time.perf_counter()
+        self.close_split = {}
         if self.thread is not None:
             self.q.put(None)
             while self.thread.is_alive():  # the copier never blocks for good (_get_slot polls the writer), but look anyway
                 self.thread.join(timeout=5.0)
                 self._poll_writer()
             self.thread = None
+        self.close_split["copier_drained"] = round(time.perf_counter() - t0, 4)
         if self.proc is not None:
             self._poll_writer()
             status, info = "error", "no answer"
@@ -442,7 +445,7 @@ class _Saver:
                 deadline = time.time() + 600
                 while self._final is None and time.time() < deadline:
                     try:
-                        st, inf = self.outbox.get(timeout=1.0)
+                        st, inf = self.outbox.get(timeout=0.05)
                         if st == "error" and not self._writer_dead:
                             self._writer_failed(inf)
                         self._final = (st, inf)
@@ -455,14 +458,30 @@ class _Saver:
                     info = f"writer process exited with code {self.proc.exitcode}"
             except Exception as e:
                 info = f"writer process did not answer: {e!r}"
-            self.proc.join(timeout=60)
-            for t in getattr(self, "_registered", []):
+            self.close_split["writer_answered"] = round(time.perf_counter() - t0, 4)
+            # every file is on disk once the writer has answered.  What is left -- the child's interpreter exit (it imported
+            # torch: 0.2-0.4 s) and un-pinning three 704 MB slots -- needs nobody's attention: a daemon thread does it, the
+            # slots stay referenced by it until then
+            proc, registered, slots = self.proc, list(getattr(self, "_registered", [])), self.slots
+
+            def _teardown():
                 try:
-                    torch.cuda.cudart().cudaHostUnregister(t.data_ptr())
-                except Exception:
-                    pass
+                    proc.join(timeout=60)
+                finally:
+                    for t in registered:
+                        try:
+                            torch.cuda.cudart().cudaHostUnregister(t.data_ptr())
+                        except Exception:
+                            pass
+                    slots.clear()
+            if status == "ok" and not self._writer_dead:
+                threading.Thread(target=_teardown, daemon=True, name="gq-saver-teardown").start()
+            else:
+                _teardown()
+            self._registered = []
             self.proc = self.inbox = self.outbox = self.freeq = None
             self.slots = []
+            self.close_split["returned"] = round(time.perf_counter() - t0, 4)
             if status == "ok" and not self._writer_dead:
                 self.writer_busy_s = float(info)
             else:
@@ -541,6 +560,7 @@ class Quantizer:
         self.calibration_batch = max(1, int(calibration_batch))
         # forward #1 of a block (quantizer.py:150-151) only feeds the Hessian hooks, its output is discarded: stop it at the
         # last hooked Linear (learned on the block's first sample; BlockSchedule.pre_hook).  Same Hessians, same bytes saved.
+        # The same switch drops forward #2 of the LAST block, whose outputs nothing reads.
         self.interrupt_forward1 = bool(interrupt_forward1)
         # beyond the reference (which runs the HF eager modules, quantizer.py:293): HIP kernels for the elementwise
         # modules of the block forward (forward_fused.py).  "exact" (default): rotary embedding, SwiGLU and RMSNorm, each
@@ -578,6 +598,7 @@ class Quantizer:
                                                 "reserved_GiB": round(ms["reserved_bytes.all.peak"] / 2**30, 1),
                                                 "active_peak_GiB": round(ms["active_bytes.all.peak"] / 2**30, 1)}
                 self.timing["saver_copy_thread_busy_s"] = round(self._saver.busy_s, 4)
+                self.timing["saver_close_split_s"] = getattr(self._saver, "close_split", None)
                 self.timing["saver_writer_process_busy_s"] = round(getattr(self._saver, "writer_busy_s", 0.0), 4)
 
     def _quantize(self, quant_config: Dict[str, GGMLQuantizationType], device) -> None:
@@ -650,7 +671,10 @@ class Quantizer:
             ph.mark("forward1+H")
             self._quant_group(handles, quant_config)
             ph.mark("quant_group")
-            for a, kw in zip(input_args, input_kwargs):  # forward #2: propagate (quantizer.py:161-172)
+            # forward #2: propagate (quantizer.py:161-172).  After the LAST block nothing reads the propagated activations (the
+            # post-block modules are quantized from their weights alone, quantizer.py:181-198): that forward is not run
+            dead = self.interrupt_forward1 and block_id == len(blocks) - 1
+            for a, kw in (() if dead else zip(input_args, input_kwargs)):
                 out = _first(block(*_to(a, device=device), **_to(kw, device=device)))
                 if self.cpu_offload_activations:
                     out = out.cpu()
