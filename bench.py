@@ -375,6 +375,12 @@ def tolerance_parity(wl, W16, X, n_seq=8, widest=False, n_rows=None):
         Wg = Wf.clone()
         U, flag = ops.h_prepare(H.clone(), Wg, 0.01)
         q, d, s, dmin, m = ops.gptq_quantize(Wg, U, q_type, 128)
+        # the same with the chain's level-3 work on the fp32 matrix instruction throughout: the REFERENCE's precision
+        # (linalg_utils.py:8-12 in fp32) through the same kernels -- the yardstick for "is the default chain good enough"
+        with ops.options(chol_fp32=1, chol_3p_min=0):
+            W32 = Wf.clone()
+            U32c, _ = ops.h_prepare(H.clone(), W32, 0.01)
+            q32 = ops.gptq_quantize(W32, U32c, q_type, 128)[0]
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         H64 = torch.zeros(C, C, device=Wf.device, dtype=torch.float64)
@@ -391,6 +397,8 @@ def tolerance_parity(wl, W16, X, n_seq=8, widest=False, n_rows=None):
         Uo_d = torch.linalg.cholesky(Hi, upper=True)
         del Hi
         u_err = float((U.double() - Uo_d).abs().max() / Uo_d.abs().max())
+        u_err32 = float((U32c.double() - Uo_d).abs().max() / Uo_d.abs().max())
+        del U32c
         Uo = Uo_d.cpu().numpy()
         del Uo_d
         rows = slice(0, R) if not n_rows or n_rows >= R else slice(R // 4, R // 4 + n_rows)
@@ -414,6 +422,10 @@ def tolerance_parity(wl, W16, X, n_seq=8, widest=False, n_rows=None):
                 "max_abs_dw": float(np.abs(Wg[rows].cpu().numpy() - Wd).max()),
                 "ulp_noise_floor": {"ints_differ": float((nq != oq).mean()),
                                     "scale_bytes_differ": scale_rate((nd, ns, ndm, nm), (od, os_, odm, om))},
+                "all_fp32_chain": {"U_rel_err": u_err32, "ints_differ": float((q32[rows].cpu().numpy() != oq).mean()),
+                                   "note": "the same Linear with the chain's GEMMs on v_mfma_f32_32x32x2_f32 (options chol_fp32, "
+                                           "chol_3p_min = 0): the reference's precision; the default (16-bit images) is at least as close "
+                                           "to the fp64 result"},
                 "checker_s": round(dt, 1),
                 "vs": "fp64 H and fp64 Cholesky chain (torch on the GPU), the oracle's C restatement of GPTQ.step on the host"}
     except Exception as e:
