@@ -74,6 +74,10 @@ def parse_args(argv=None):
                    help="calibration samples per block forward (the reference runs 1; the Hessians are the same sums)")
     p.add_argument("--non_block_fp32", action="store_true",
                    help="run the embed/lm_head scale search in fp32 (the reference runs it in the model dtype)")
+    p.add_argument("--full_forward1", action="store_true",
+                   help="beyond the reference: by default forward #1 of a block stops at the last hooked Linear (its output is "
+                        "discarded, quantizer.py:150-151) and forward #2 of the last block is not run; this flag runs both in full "
+                        "like the reference -- same saved bytes either way")
     p.add_argument("--fused_forward", nargs="?", const="all", default="exact", choices=["off", "exact", "all"],
                    help="HIP kernels for the elementwise modules of the calibration forward (the reference runs the HF "
                         "eager modules): exact (default) = rotary embedding, SwiGLU and RMSNorm, bit-identical to HF eager "
@@ -162,7 +166,8 @@ def _run(args):
         post_block_modules=args.post_block_modules, quant_non_block_modules=args.quant_non_block_modules,
         cpu_offload_modules=args.cpu_offload_modules, cpu_offload_activations=args.cpu_offload_activations,
         device=device, verbose=args.verbose, save_dir=args.save_dir, non_block_fp32=args.non_block_fp32,
-        calibration_batch=args.calibration_batch, fused_forward=args.fused_forward)
+        calibration_batch=args.calibration_batch, fused_forward=args.fused_forward,
+        interrupt_forward1=not args.full_forward1)
     if dist_utils.is_main():
         os.makedirs(args.save_dir, exist_ok=True)
     dist_utils.barrier()
