@@ -352,10 +352,6 @@ typedef uint32_t g32_u32x4 __attribute__((ext_vector_type(4)));
 #define GQ_C_WAIT(N, s) \
     asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(fa0[s]), "+v"(fa1[s]), "+v"(fb0[s]), "+v"(fb1[s]) : "n"(N))
 
-// timing probes (results wrong): -DGQ_FAR_NOCOMMIT / -DGQ_FAR_NOFETCH / -DGQ_FAR_NOBARRIER drop a piece of the loop
-#define GQ_FAR_AB_COMMIT(x) x
-#define GQ_FAR_AB_FETCH(x) x
-#define GQ_FAR_AB_BARRIER() __builtin_amdgcn_s_barrier()
 template <int CHAIN>
 __device__ __forceinline__ void g32_chain_full_tile(float* Cmat, int64_t ldc, const float* A, int64_t lda, const float* B,
                                                     int64_t ldb, int64_t K, const int64_t m0, const int64_t n0) {
@@ -424,12 +420,12 @@ __device__ __forceinline__ void g32_chain_full_tile(float* Cmat, int64_t ldc, co
         const unsigned na0 = aoff0 + nbuf * STAGE * 4, na1 = aoff1 + nbuf * STAGE * 4, nb = boff + nbuf * STAGE * 4;
 #define GQ_C_GROUP(g)                                                                                        \
     do {                                                                                                     \
-        if ((g) == 6) GQ_FAR_AB_BARRIER(); /* image nbuf is complete: its writes were waited at g = 4 */     \
+        if ((g) == 6) __builtin_amdgcn_s_barrier(); /* image nbuf is complete: its writes were waited at g = 4 */ \
         if ((g) == 3) {                                                                                      \
             GQ_C_WAIT(4, (g) & 3); /* before 6 more LDS operations: lgkmcnt counts to 15 */                  \
             asm volatile("" ::: "memory");                                                                   \
-            GQ_FAR_AB_COMMIT(commit(nbuf, va[PAR], vb[PAR]));                                                \
-            GQ_FAR_AB_FETCH(fetch(t + 3, va[PAR], vb[PAR]));                                                 \
+            commit(nbuf, va[PAR], vb[PAR]);                                                                  \
+            fetch(t + 3, va[PAR], vb[PAR]);                                                                  \
             asm volatile("" ::: "memory");                                                                   \
         }                                                                                                    \
         if ((g) < 6) GQ_C_READS((g) + 2, ((g) + 2) & 3, ca0, ca1, cb);                                       \
