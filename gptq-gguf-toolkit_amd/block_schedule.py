@@ -9,15 +9,11 @@ schedules kernels:
                tensor (q/k/v, gate/up) are detected and share one Hessian.  Activations are buffered by the
                handles; `sample_done()` (after every calibration sample) folds the buffers of ALL distinct
                inputs into their Hessians with grouped SYRK launches once they hold `flush_tokens` tokens:
-               the narrow inputs in one grid, then the widest input alone on the chip.  [N=1, opt-in:
-               GQ_DEFER_NARROW=1] Only the WIDEST input is folded as the samples arrive; the narrow ones
-               (zero-copy references, a few GB) are kept and folded -- in the very same portions -- at
-               quantize() time on a side stream, UNDER the widest input's factorisation and column loop,
-               which are chains of small dependent launches that leave the matrix cores idle (-0.7 % per
-               step for 6 GB of kept activations: off by default).
+               the narrow inputs in one grid, then the widest input alone on the chip.  `pre_hook(name)` is the
+               same feed from a forward PRE-hook; it ends forward #1 at the last hooked Linear (r04).
   quantize()   phase 0  the remaining tokens are folded in;
-                        [N>1] ONE all-reduce per distinct Hessian, widest first (gptq.py:131-132 does one per
-                        handle);
+                        [N>1] ONE collective per distinct Hessian, widest first (gptq.py:131-132 does one all-reduce
+                        per handle): a reduce to the owner when all its Linears belong to one rank, else an all-reduce;
                phase 1  every input group is an independent chain (h_prepare -> per Linear: working copy,
                         column loop, dequantize) and runs on its own HIP stream, widest chain first: the
                         single-workgroup leaves of one factorisation and the 64-CU column-loop kernels overlap

@@ -330,7 +330,7 @@ class _Saver:
                 if self.use_process:
                     self._start_process()
             except BaseException as e:  # no writer process (small /dev/shm, spawn failure): this thread writes, as
-                # GQ_SAVE_MODE=thread does -- a start-up problem of an optimisation is logged, not raised after hours
+                # _Saver.USE_PROCESS = False does -- a start-up problem of an optimisation is logged, not raised after hours
                 dist_utils.print_on_main(f"[gq] data.pth writer process not started ({e}); writing from a thread")
                 self.proc = None
                 self.slots = []
@@ -354,7 +354,7 @@ class _Saver:
         per run) while the launches that hang on cross-stream events do not: the single-workgroup Cholesky leaves take
         574 vs 305 ms, the column-loop kernels 793 vs 590 ms (bench.py, GQ_BENCH_WM_PROF) -- dependent dispatch got slower,
         not the kernels; the cause inside the runtime is not identified (hardware-queue count, copy engine, PCIe and the
-        allocator are ruled out: DESIGN.md 6b).  (GQ_SAVE_INLINE=0: the copier thread copies on its own stream.)"""
+        allocator are ruled out: DESIGN.md 6b).  (_Saver.INLINE = False: the copier thread copies on its own stream.)"""
         if not items:
             return
         if self.sync or not items[0][2][0].is_cuda:
