@@ -134,7 +134,7 @@ def h_prepare(H: torch.Tensor, W: torch.Tensor, rel_damp: float, want_flags: boo
     assert H.dtype == torch.float32 and W.dtype == torch.float32 and H.is_contiguous() and W.is_contiguous()
     R, C = W.shape
     U = torch.empty_like(H)
-    flag = torch.zeros(1, dtype=torch.int32, device=H.device)
+    flag = torch.empty(1, dtype=torch.int32, device=H.device)  # cleared by the call (hipMemsetAsync on its stream)
     cf = torch.empty(2 * C, dtype=torch.uint8, device=H.device) if want_flags else None
     ws = _ws(workspace_bytes(_cabi.WS_H_PREPARE, R, C), H.device)
     fn = lib().gq_obq_h_prepare if obq_order else lib().gq_h_prepare
@@ -148,7 +148,7 @@ def w_prepare(col_flags: torch.Tensor, W: torch.Tensor) -> torch.Tensor:
     (0 => the leader's U is this Linear's U)."""
     _need_cuda(col_flags, W)
     assert W.dtype == torch.float32 and W.is_contiguous() and col_flags.numel() == 2 * W.shape[1]
-    mm = torch.zeros(1, dtype=torch.int32, device=W.device)
+    mm = torch.empty(1, dtype=torch.int32, device=W.device)  # cleared by the call
     check(lib().gq_w_prepare(_ptr(col_flags), _ptr(W), W.shape[0], W.shape[1], _ptr(mm), _stream(W)), "gq_w_prepare")
     return mm
 
