@@ -130,3 +130,33 @@ def test_environment_variables_are_few_and_documented():
     for f in glob.glob(os.path.join(pkg, "csrc", "*.h*")):
         src = open(f).read()
         assert not re.findall(r"^\s*#\s*(?:ifdef|ifndef|if)\b", src, re.M), f"{os.path.basename(f)}: preprocessor conditionals in a shipped kernel source"
+
+
+def test_committed_bench_lines_keep_the_driver_contract():
+    """The five committed lines of the round (profiles/r04_bench_<workload>.json, written by bench.py on the GPU box) carry every
+    key of the driver's contract with the right types, the two objects of the hot-path tier (roofline, cpu_baseline) and the
+    section-8(d) figures added in r04 -- a guard against a bench.py edit that silently drops one."""
+    import glob
+    import json
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r04_bench_*.json")))
+    assert len(files) == 5
+    for f in files:
+        l = json.loads(open(f).read())
+        for k, t in (("metric", str), ("value", (int, float)), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                     ("ms_per_step", (int, float)), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str)):
+            assert isinstance(l[k], t), (f, k)
+        assert l["metric"].startswith("Mparams/s") and l["unit"] == "Mparams/s" and l["vs_baseline"] is None
+        assert l["scaling"] in ("weak", "strong") and l["data"] == "synthetic" and "workload" in l["config"]
+        assert "model" not in l["config"]
+        r = l["roofline"]
+        assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+        assert "traffic" in r
+        c = l["cpu_baseline"]
+        assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == l["unit"] and c["sample"]
+        assert l["encoders"]["bound"] == "hbm" and l["encoders"]["bytes_per_param"] > 5.5 and l["column_loop"]["steps_per_s"] > 0
+        for leg in ("tolerance_parity", "tolerance_parity_widest"):
+            assert "ints_differ" in l[leg] and "all_fp32_chain" in l[leg] and "ulp_noise_floor" in l[leg], (f, leg)
+    d = json.loads(open(os.path.join(ROOT, "profiles", "r04_bench_llama3-8b-block-q4k.json")).read())
+    assert abs(d["value"] - 218.1 / d["ms_per_step"] * 1e3) / d["value"] < 0.01  # 218.1 M params per step
+    assert d["roofline"]["traffic"]["GB_per_launch"] > d["roofline"]["traffic"]["algorithmic_GB_per_launch"] > 0
+    assert d["whole_model"]["wall_s_quantizer_region"] < d["whole_model_hf_eager"]["wall_s_quantizer_region"]
