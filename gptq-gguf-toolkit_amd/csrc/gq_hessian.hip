@@ -17,6 +17,7 @@
 #include <stdlib.h>
 
 #include "gq_common.hpp"
+#include <utility>
 #include <vector>
 
 namespace gq {
@@ -865,6 +866,260 @@ __global__ __launch_bounds__(512, 2) void syrk16_256n_kernel(const SyrkGroup grp
     }  // tile loop
 }
 
+// -------------- 16-bit SYRK, 256x256 tiles, FOUR waves with 128 x 128 wave tiles (option syrk_w4 = 1)
+// The vendor library's shape for this product (hipBLASLt MT256x256x32, MIWT8_8: DESIGN.md K1) on this kernel's ring:
+// same 4-slot LDS ring in the natural activation layout, same DMA pieces, same tile table / K-split / rendezvous and the
+// same k order per accumulator as syrk16_256n_kernel -- results are bit-identical -- but 2 x 2 waves, one per SIMD, each
+// with 8 x 8 accumulators of 16x16 in 256 AGPRs: 16 fragments per 64 MFMAs instead of 12 per 32, i.e. a third fewer LDS
+// read bytes per flop.  Every wave brings token rows 8 w .. 8 w + 7 of BOTH operands (8 DMA pieces per k32 step).
+// Stream of one k32 step (64 MFMAs, row-major over the A fragments; B fragments double-buffered, A fragments single-
+// buffered: a_i of the next step is read right after row i of this step has issued):
+//   MFMA 0,1: reads of a7 (this step's, ring slot n)      MFMA 2: s_waitcnt vmcnt(8) + s_barrier (half-stage n+1 landed,
+//   everybody is through with slot n-1)                    row r: a_(r-1) and b_r of half-stage n+1 behind MFMAs 8r+1,2,4,5
+//   DMA pieces of half-stage n+3 behind MFMAs 6, 14, .., 62.
+// reads issued in a step before MFMA m (issue points: behind MFMAs 0,1,4,5 and 8r+1,8r+2,8r+4,8r+5)
+constexpr int w4_cnt(int m) {
+    int n = 0;
+    for (int q = 0; q < m; ++q) {
+        const int r = q >> 3, o = q & 7;
+        if (r == 0 ? (o == 0 || o == 1 || o == 4 || o == 5) : (o == 1 || o == 2 || o == 4 || o == 5)) ++n;
+    }
+    return n;
+}
+constexpr int w4_min15(int n) { return n < 15 ? n : 15; }
+
+#define GQ_WDL(vo, base, ldsa)                                                                        \
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(vo), "s"(base), "s"(ldsa) : "memory")
+#define GQ_WRD(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
+#define GQ_WWAIT(N, x, y) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(x), "+v"(y) : "n"(N) : "memory")
+
+// registers of one wave of syrk16_256w_kernel (a local object whose members all live in registers: every index below
+// is a template constant)
+template <bool BF16>
+struct W4 {
+    f32x4 c[8][8];                           // accumulators (AGPRs)
+    u32x2 al[8], ah[8], bl[2][8], bh[2][8];  // A fragments (one set), B fragments (two sets); l / h = token rows +0..3 / +4..7
+    unsigned adA[2][8], adB[2][8];           // fragment addresses: [64 KiB half of the ring][fragment]
+    unsigned voff[4];                        // DMA source offsets of the wave's four pieces per operand
+    unsigned ldsw;                           // LDS address of the wave's first piece in ring slot 0
+    const char *gA, *gB;                     // DMA bases of the half-stage to fetch next (wave-uniform)
+
+    __device__ __forceinline__ void mfma(f32x4& acc, const u32x2& xl, const u32x2& xh, const u32x2& yl, const u32x2& yh) {
+        const u32x4 A_ = __builtin_shufflevector(xl, xh, 0, 1, 2, 3), B_ = __builtin_shufflevector(yl, yh, 0, 1, 2, 3);
+        if constexpr (BF16) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(A_), "v"(B_));
+        else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(A_), "v"(B_));
+    }
+    // MFMA M of the k32 step on ring slot SC, and what is issued behind it
+    template <int SC, int M>
+    __device__ __forceinline__ void slot() {
+        constexpr int SN = (SC + 1) & 3, SD = (SC + 3) & 3, PC = SC & 1, PN = PC ^ 1;
+        constexpr int OC = (SC & 1) * 32768, ON = (SN & 1) * 32768;
+        constexpr int i = M >> 3, j = M & 7;
+        // reads still allowed in flight when this operand is needed (LDS returns in order)
+        if constexpr (M < 8) GQ_WWAIT(w4_min15(28 - 4 * j + w4_cnt(M)), bl[PC][j], bh[PC][j]);
+        if constexpr (j == 0 && i < 7) GQ_WWAIT(w4_min15(26 - 4 * i + w4_cnt(M)), al[i], ah[i]);
+        if constexpr (M == 56) GQ_WWAIT(w4_min15(w4_cnt(M) - 2), al[7], ah[7]);
+        mfma(c[i][j], al[i], ah[i], bl[PC][j], bh[PC][j]);
+        if constexpr (M == 0) GQ_WRD(al[7], adA[SC >> 1][7], OC);
+        if constexpr (M == 1) GQ_WRD(ah[7], adA[SC >> 1][7], OC + 2048);
+        if constexpr (M == 2) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+        if constexpr (M == 4) GQ_WRD(bl[PN][0], adB[SN >> 1][0], ON);
+        if constexpr (M == 5) GQ_WRD(bh[PN][0], adB[SN >> 1][0], ON + 2048);
+        if constexpr (i >= 1 && j == 1) GQ_WRD(al[i - 1], adA[SN >> 1][i - 1], ON);
+        if constexpr (i >= 1 && j == 2) GQ_WRD(ah[i - 1], adA[SN >> 1][i - 1], ON + 2048);
+        if constexpr (i >= 1 && j == 4) GQ_WRD(bl[PN][i], adB[SN >> 1][i], ON);
+        if constexpr (i >= 1 && j == 5) GQ_WRD(bh[PN][i], adB[SN >> 1][i], ON + 2048);
+        if constexpr (j == 6) {  // the DMA pieces of half-stage n+3: A pieces in rows 0-3, B pieces in rows 4-7
+            if constexpr (i < 4) GQ_WDL(voff[i], gA, ldsw + (unsigned)(SD * S_BUF_BYTES + i * 1024));
+            else GQ_WDL(voff[i - 4], gB, ldsw + (unsigned)(SD * S_BUF_BYTES + 16384 + (i - 4) * 1024));
+        }
+    }
+    template <int SC, int... M>
+    __device__ __forceinline__ void step_(std::integer_sequence<int, M...>) {
+        (slot<SC, M>(), ...);
+    }
+    template <int SC>
+    __device__ __forceinline__ void step() {
+        step_<SC>(std::make_integer_sequence<int, 64>{});
+    }
+    // what a previous step would have left: a0..a6 and the B set of ring slot 0
+    template <int F>
+    __device__ __forceinline__ void first_a() {
+        GQ_WRD(al[F], adA[0][F], 0);
+        GQ_WRD(ah[F], adA[0][F], 2048);
+    }
+    template <int F>
+    __device__ __forceinline__ void first_b() {
+        GQ_WRD(bl[0][F], adB[0][F], 0);
+        GQ_WRD(bh[0][F], adB[0][F], 2048);
+    }
+    __device__ __forceinline__ void first_fragments() {
+        first_a<0>(); first_a<1>(); first_a<2>(); first_a<3>(); first_a<4>(); first_a<5>(); first_a<6>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        first_b<0>(); first_b<1>(); first_b<2>(); first_b<3>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        first_b<4>(); first_b<5>(); first_b<6>(); first_b<7>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the step's waits count on a whole step of reads behind these
+    }
+    __device__ __forceinline__ void fetch(int h) {  // all eight pieces of a half-stage into ring slot h (prologue)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) GQ_WDL(voff[u], gA, ldsw + (unsigned)(h * S_BUF_BYTES + u * 1024));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) GQ_WDL(voff[u], gB, ldsw + (unsigned)(h * S_BUF_BYTES + 16384 + u * 1024));
+    }
+};
+#undef GQ_WDL
+#undef GQ_WRD
+#undef GQ_WWAIT
+
+template <bool BF16>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void syrk16_256w_kernel(const SyrkGroup grp) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 1, wn = wid & 1;
+    int round = 0;
+    for (int slot = (int)(blockIdx.x >> 3); slot < grp.per_xcd; slot += (int)(gridDim.x >> 3), ++round) {
+    if (grp.bar && round > 0) {  // XCD-wide soft rendezvous between rounds, as in syrk16_256n_kernel
+        if (tid == 0) {
+            unsigned* b = grp.bar + (blockIdx.x & 7);
+            __hip_atomic_fetch_add(b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned want = (unsigned)round * (gridDim.x >> 3);
+            for (int spin = 0; spin < 64 && __hip_atomic_load(b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want; ++spin)
+                __builtin_amdgcn_s_sleep(16);
+        }
+    }
+    const uint32_t ent = (uint32_t)__builtin_amdgcn_readfirstlane((int)grp.table[(blockIdx.x & 7) * grp.per_xcd + slot]);
+    if (ent == 0xffffffffu) {
+        if (grp.bar) continue;
+        break;
+    }
+    const uint32_t aux = grp.aux ? (uint32_t)__builtin_amdgcn_readfirstlane((int)grp.aux[(blockIdx.x & 7) * grp.per_xcd + slot])
+                                 : 0xffffffffu;
+    __syncthreads();
+    const SyrkProblem& P = grp.p[ent >> 24];
+    const int64_t ti = (ent >> 12) & 0xfff, tj = ent & 0xfff;
+    const int64_t C = P.C;
+    int64_t u0 = 0, u1 = P.Tp / (4 * SK);
+    if (aux != 0xffffffffu) {
+        const int64_t np = aux & 63, kp = (aux >> 6) & 63;
+        u0 = kp * u1 / np;
+        u1 = (kp + 1) * (P.Tp / (4 * SK)) / np;
+    }
+    const int nhs = (int)((u1 - u0) * 4);
+    const unsigned lds0 = (unsigned)(uintptr_t)smem;
+    // ---- DMA: wave w owns token rows 8 w .. 8 w + 7 of every half-stage, of both operands: four 1 KiB pieces (two rows
+    // each) of the A image (channels 256 ti ..) and four of the B image (channels 256 tj ..)
+    const int rb = 8 * wid;
+    const int64_t hstride = 32 * C * 2;
+    const int64_t cofA = ti * 512, cofB = tj * 512;
+    const char* gsrc = reinterpret_cast<const char*>(P.Xt) + u0 * 4 * hstride;
+    int hsps = P.hs_per_seg, seg_within = 0;
+    const uint64_t* segp = P.segs;
+    const char* segbase = nullptr;
+    if (hsps) {
+        const int h0 = (int)(u0 * 4);
+        segp += h0 / hsps;
+        seg_within = h0 % hsps;
+        segbase = reinterpret_cast<const char*>(sload64_now(segp));
+        gsrc = segbase + (int64_t)seg_within * hstride;
+    }
+    asm volatile("" : "+s"(hsps), "+s"(segp));
+    W4<BF16> w;
+    {
+        const int hrow = lane >> 5, s16 = lane & 31;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r_ = rb + 2 * u + hrow;
+            const int g_ = (r_ & 3) | (((r_ >> 3) & 1) << 2);
+            w.voff[u] = (unsigned)(r_ * C * 2) + (unsigned)((((s16 >> 1) ^ g_) << 5) + ((s16 & 1) << 4));
+        }
+    }
+    w.ldsw = lds0 + (unsigned)(rb * 512);
+    int hnext = 0;
+    w.gA = gsrc + cofA;
+    w.gB = gsrc + cofB;
+#define GQ_WADV()                                                                                     \
+    do {                                                                                              \
+        if (hnext + 1 < nhs) {                                                                        \
+            ++hnext;                                                                                  \
+            const char* g_;                                                                           \
+            if (hsps) {                                                                               \
+                if (++seg_within == hsps) {                                                           \
+                    seg_within = 0;                                                                   \
+                    ++segp;                                                                           \
+                    segbase = reinterpret_cast<const char*>(sload64_now(segp));                       \
+                }                                                                                     \
+                g_ = segbase + (int64_t)seg_within * hstride;                                         \
+            } else {                                                                                  \
+                g_ = gsrc + (int64_t)hnext * hstride;                                                 \
+            }                                                                                         \
+            w.gA = g_ + cofA;                                                                         \
+            w.gB = g_ + cofB;                                                                         \
+        }                                                                                             \
+    } while (0)
+    // ---- fragment addresses: ring slot s = half s >> 1, offset (s & 1) * 32 KiB
+    {
+        const int kc = lane >> 4, q = (lane & 15) >> 2, ch = lane & 3;
+        const int r = 8 * kc + q, g = q | ((kc & 1) << 2);
+        const unsigned bA = lds0 + (unsigned)(r * 512 + (((wm * 8) ^ g) << 5) + ch * 8);
+        const unsigned bB = lds0 + 16384u + (unsigned)(r * 512 + (((wn * 8) ^ g) << 5) + ch * 8);
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+            w.adA[0][f] = bA ^ ((unsigned)f << 5);
+            w.adB[0][f] = bB ^ ((unsigned)f << 5);
+            w.adA[1][f] = w.adA[0][f] + 65536u;
+            w.adB[1][f] = w.adB[0][f] + 65536u;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w.c[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int h = 0; h < 3; ++h) {
+        w.fetch(h);
+        GQ_WADV();
+    }
+    asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+    w.first_fragments();
+    for (int n = 0; n < nhs; n += 4) {  // nhs % 4 == 0
+        w.template step<0>(); GQ_WADV();
+        w.template step<1>(); GQ_WADV();
+        w.template step<2>(); GQ_WADV();
+        w.template step<3>(); GQ_WADV();
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+#undef GQ_WADV
+    float* __restrict__ H = P.H;
+    const float beta = P.beta, alpha = P.alpha;
+    const int lr = lane & 15, lk = lane >> 4;
+    const int64_t i0 = ti * BT + wm * 128 + 4 * lk, j0 = tj * BT + wn * 128 + lr;
+    float* __restrict__ Pp = (aux != 0xffffffffu) ? grp.partial + (size_t)(aux >> 12) * (BT * BT) : nullptr;
+    const int rl0 = wm * 128 + 4 * lk, cl0 = wn * 128 + lr;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const f32x4 v = w.c[i][j];
+            if (Pp) {  // K-split unit: raw sums, combined in fixed order by syrk_reduce_kernel
+                float* q_ = Pp + (rl0 + i * 16) * BT + cl0 + j * 16;
+                q_[0] = v[0]; q_[BT] = v[1]; q_[2 * BT] = v[2]; q_[3 * BT] = v[3];
+                continue;
+            }
+            const int64_t col = j0 + j * 16, row = i0 + i * 16;
+            float4 h;
+            h.x = beta * H[(row + 0) * C + col] + alpha * v[0];
+            h.y = beta * H[(row + 1) * C + col] + alpha * v[1];
+            h.z = beta * H[(row + 2) * C + col] + alpha * v[2];
+            h.w = beta * H[(row + 3) * C + col] + alpha * v[3];
+            H[(row + 0) * C + col] = h.x; H[(row + 1) * C + col] = h.y;
+            H[(row + 2) * C + col] = h.z; H[(row + 3) * C + col] = h.w;
+            if (ti != tj) *reinterpret_cast<float4*>(H + col * C + row) = h;
+        }
+    }
+    }  // tile loop
+}
+
 // K-split tiles: H tile = beta * H tile + alpha * (P_0 + P_1 + ... + P_{n-1}), partial sums added in index
 // order (deterministic), mirrored below the diagonal.  list[2 i] = tile entry (problem << 24 | ti << 12 | tj),
 // list[2 i + 1] = first slot << 8 | nparts.  Grid (tiles, 16): a block owns 16 rows of a tile.
@@ -1144,7 +1399,10 @@ static int syrk16_launch(int kind, const int* idx, int m, float* const* H, const
         int wgs = 256;
         if (const int64_t e = opt(OPT_syrk_wgs)) wgs = (e >= 8 && e <= 256) ? (int)(e & ~7) : 256;
         const dim3 grid((unsigned)(grp.bar ? wgs : 8 * grp.per_xcd)), blk(512);
-        if (bf) hipLaunchKernelGGL(syrk16_256n_kernel<true>, grid, blk, S_LDS_BYTES, st, grp);
+        if (opt(OPT_syrk_w4)) {  // four waves, 128 x 128 wave tiles (bit-identical)
+            if (bf) hipLaunchKernelGGL(syrk16_256w_kernel<true>, grid, dim3(256), S_LDS_BYTES, st, grp);
+            else hipLaunchKernelGGL(syrk16_256w_kernel<false>, grid, dim3(256), S_LDS_BYTES, st, grp);
+        } else if (bf) hipLaunchKernelGGL(syrk16_256n_kernel<true>, grid, blk, S_LDS_BYTES, st, grp);
         else hipLaunchKernelGGL(syrk16_256n_kernel<false>, grid, blk, S_LDS_BYTES, st, grp);
         if (n_reduce > 0) {
             GQ_LAUNCH_CHECK();
@@ -1299,6 +1557,8 @@ int h_accumulate_grouped(int n, float* const* H, const void* const* X, const int
         GQ_HIP(hipFuncSetAttribute((const void*)syrk16_256e_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES));
         GQ_HIP(hipFuncSetAttribute((const void*)syrk16_256n_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES));
         GQ_HIP(hipFuncSetAttribute((const void*)syrk16_256n_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES));
+        GQ_HIP(hipFuncSetAttribute((const void*)syrk16_256w_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES));
+        GQ_HIP(hipFuncSetAttribute((const void*)syrk16_256w_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES));
         attr_set = true;
     }
     // Problems are sorted into at most three launches by the kernel they can take (usually all take the first):

@@ -160,3 +160,35 @@ def test_down_proj_ints_rate_on_a_correlated_hessian(ops, oracle, massive, mean,
           f"{u_err['default'][1]:.2e} fp32 {u_err['fp32'][1]:.2e}")
     assert rate["default"] <= 1.05 * rate["fp32"] + 2e-3, (rate, floor)
     assert rate["default"] <= 2.0 * floor, (rate, floor)
+
+
+# ----------------------------------------------------------------- K1: the four-wave form of the in-place SYRK
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_h_accumulate_four_wave_form_is_bit_identical(ops, dt):
+    """Option syrk_w4: 2 x 2 waves with 128 x 128 wave tiles (syrk16_256w_kernel) on the same ring, tile table, K-split
+    and k order as the default 2 x 4 waves with 128 x 64 (syrk16_256n_kernel): every Hessian equal BIT FOR BIT -- two
+    problems in one grid, contiguous and per-sample blocks, T >= 8192 (K-split units), a single turn of the ring,
+    beta != 0 -- and close to fp64."""
+    torch.manual_seed(41)
+    shapes = [(2048, 5, 2048), (1280, 40, 256)]  # (C, blocks, tokens per block)
+    Xl = [[(torch.randn(L, C, device="cuda") * torch.exp(torch.randn(C, device="cuda") * 0.5)).to(dt) for _ in range(nb)]
+          for C, nb, L in shapes]
+    Xc = [torch.cat(b) for b in Xl]
+    H0 = [torch.randn(C, C, device="cuda") for C, _, _ in shapes]
+    H0 = [h + h.T for h in H0]
+    outs = []
+    for w4 in (0, 1):
+        with ops.options(syrk_w4=w4):
+            Ha = [h.clone() for h in H0]
+            ops.h_accumulate_grouped(Ha, Xc, [0.25, 0.5], [0.01, 0.02])
+            Hb = [h.clone() for h in H0]
+            ops.h_accumulate_grouped(Hb, Xl, [0.25, 0.5], [0.01, 0.02])
+            Hc = H0[1].clone()
+            ops.h_accumulate(Hc, Xc[1][:128], 0.5, 0.125)   # one turn of the ring
+            outs.append(Ha + Hb + [Hc])
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+        assert torch.equal(b, b.T)
+    ref = 0.25 * H0[0].double() + 0.01 * (Xc[0].double().T @ Xc[0].double())
+    assert (outs[1][0].double() - ref).abs().max().item() <= 5e-6 * ref.abs().max().item()
