@@ -821,7 +821,9 @@ def main():
                                                               "sources than this build's: not reported"}
             except Exception:
                 traffic = None
-        roof = {"bound": "mfma", "kernel": "syrk16_256n_kernel<f16> (gq_h_accumulate_grouped)",
+        roof = {"bound": "mfma",
+                "kernel": ("syrk16_256w_kernel<f16>: 4 waves, 128x128 wave tiles" if ops.option_get("syrk_w4")
+                           else "syrk16_256n_kernel<f16>: 8 waves, 128x64 wave tiles") + " (gq_h_accumulate_grouped)",
                 "achieved": round(ach, 2) if ach else None, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_F16_MFMA_TFLOPS, 4) if ach else None,
                 "traffic": traffic,

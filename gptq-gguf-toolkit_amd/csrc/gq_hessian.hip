@@ -877,16 +877,67 @@ __global__ __launch_bounds__(512, 2) void syrk16_256n_kernel(const SyrkGroup grp
 //   MFMA 0,1: reads of a7 (this step's, ring slot n)      MFMA 2: s_waitcnt vmcnt(8) + s_barrier (half-stage n+1 landed,
 //   everybody is through with slot n-1)                    row r: a_(r-1) and b_r of half-stage n+1 behind MFMAs 8r+1,2,4,5
 //   DMA pieces of half-stage n+3 behind MFMAs 6, 14, .., 62.
-// reads issued in a step before MFMA m (issue points: behind MFMAs 0,1,4,5 and 8r+1,8r+2,8r+4,8r+5)
-constexpr int w4_cnt(int m) {
-    int n = 0;
-    for (int q = 0; q < m; ++q) {
-        const int r = q >> 3, o = q & 7;
-        if (r == 0 ? (o == 0 || o == 1 || o == 4 || o == 5) : (o == 1 || o == 2 || o == 4 || o == 5)) ++n;
+// The order of a step's 32 fragment reads and 8 DMA pieces, as a table the waits are derived from.  Read codes:
+// 0..15 = A fragment code >> 1, half code & 1 (fragment 7: of THIS step's ring slot, the others: of the next one);
+// 16..31 = B fragment (code - 16) >> 1 of the next ring slot.
+// (Measured on this table and removed, profiles/r04_syrk_w4_ab.txt: the whole B set read in rows 0-3, a step without its
+// barrier, a step that never waits for its DMA -- all within 1 % of this order: no wait left that matters, as in the
+// eight-wave kernel.)
+struct W4Sched {
+    signed char rd[64][4];  // reads issued behind MFMA m (-1: none)
+    signed char dma[64];    // DMA piece issued behind MFMA m: 0-3 A pieces, 4-7 B pieces (-1: none)
+    int bar;                // the step's barrier stands behind this MFMA
+};
+constexpr void w4_put(W4Sched& S, int m, int code) {
+    for (int q = 0; q < 4; ++q)
+        if (S.rd[m][q] < 0) {
+            S.rd[m][q] = (signed char)code;
+            return;
+        }
+}
+constexpr W4Sched w4_sched() {
+    W4Sched S{};
+    for (int m = 0; m < 64; ++m) {
+        S.dma[m] = -1;
+        for (int q = 0; q < 4; ++q) S.rd[m][q] = -1;
     }
+    S.bar = 2;
+    w4_put(S, 0, 14);
+    w4_put(S, 1, 15);
+    for (int r = 1; r < 8; ++r) {  // a_(r-1) of the next step once row r-1 has issued
+        w4_put(S, 8 * r + 1, 2 * (r - 1));
+        w4_put(S, 8 * r + 2, 2 * (r - 1) + 1);
+    }
+    for (int r = 0; r < 8; ++r) {  // b_r of the next step in row r
+        w4_put(S, 8 * r + 4, 16 + 2 * r);
+        w4_put(S, 8 * r + 5, 16 + 2 * r + 1);
+    }
+    for (int r = 0; r < 8; ++r) S.dma[8 * r + 6] = (signed char)r;
+    return S;
+}
+// position of read `code` in the step's issue order, reads issued before MFMA m
+constexpr int w4_pos(const W4Sched& S, int code) {
+    int n = 0;
+    for (int m = 0; m < 64; ++m)
+        for (int q = 0; q < 4; ++q) {
+            if (S.rd[m][q] == code) return n;
+            if (S.rd[m][q] >= 0) ++n;
+        }
+    return -1;
+}
+constexpr int w4_before(const W4Sched& S, int m) {
+    int n = 0;
+    for (int k = 0; k < m; ++k)
+        for (int q = 0; q < 4; ++q)
+            if (S.rd[k][q] >= 0) ++n;
     return n;
 }
-constexpr int w4_min15(int n) { return n < 15 ? n : 15; }
+// lgkmcnt that guarantees read `code` (issued in the previous step, or in this one: `same`) has returned before MFMA m:
+// the number of reads issued after it (LDS returns in order), at most 15
+constexpr int w4_wait(const W4Sched& S, int code, int m, bool same) {
+    const int n = same ? w4_before(S, m) - w4_pos(S, code) - 1 : (32 - w4_pos(S, code) - 1) + w4_before(S, m);
+    return n < 15 ? n : 15;
+}
 
 #define GQ_WDL(vo, base, ldsa)                                                                        \
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(vo), "s"(base), "s"(ldsa) : "memory")
@@ -903,35 +954,45 @@ struct W4 {
     unsigned voff[4];                        // DMA source offsets of the wave's four pieces per operand
     unsigned ldsw;                           // LDS address of the wave's first piece in ring slot 0
     const char *gA, *gB;                     // DMA bases of the half-stage to fetch next (wave-uniform)
+    static constexpr W4Sched S = w4_sched();
 
     __device__ __forceinline__ void mfma(f32x4& acc, const u32x2& xl, const u32x2& xh, const u32x2& yl, const u32x2& yh) {
         const u32x4 A_ = __builtin_shufflevector(xl, xh, 0, 1, 2, 3), B_ = __builtin_shufflevector(yl, yh, 0, 1, 2, 3);
         if constexpr (BF16) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(A_), "v"(B_));
         else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(A_), "v"(B_));
     }
+    template <int SC, int CODE>
+    __device__ __forceinline__ void read() {
+        if constexpr (CODE >= 0) {
+            constexpr int SN = (SC + 1) & 3, PN = (SC & 1) ^ 1, f = (CODE & 15) >> 1, hi = CODE & 1;
+            if constexpr (CODE >= 16) {
+                if constexpr (hi) GQ_WRD(bh[PN][f], adB[SN >> 1][f], (SN & 1) * 32768 + 2048);
+                else GQ_WRD(bl[PN][f], adB[SN >> 1][f], (SN & 1) * 32768);
+            } else {
+                constexpr int SS = f == 7 ? SC : SN;
+                if constexpr (hi) GQ_WRD(ah[f], adA[SS >> 1][f], (SS & 1) * 32768 + 2048);
+                else GQ_WRD(al[f], adA[SS >> 1][f], (SS & 1) * 32768);
+            }
+        }
+    }
     // MFMA M of the k32 step on ring slot SC, and what is issued behind it
     template <int SC, int M>
     __device__ __forceinline__ void slot() {
-        constexpr int SN = (SC + 1) & 3, SD = (SC + 3) & 3, PC = SC & 1, PN = PC ^ 1;
-        constexpr int OC = (SC & 1) * 32768, ON = (SN & 1) * 32768;
+        constexpr int SD = (SC + 3) & 3, PC = SC & 1;
         constexpr int i = M >> 3, j = M & 7;
-        // reads still allowed in flight when this operand is needed (LDS returns in order)
-        if constexpr (M < 8) GQ_WWAIT(w4_min15(28 - 4 * j + w4_cnt(M)), bl[PC][j], bh[PC][j]);
-        if constexpr (j == 0 && i < 7) GQ_WWAIT(w4_min15(26 - 4 * i + w4_cnt(M)), al[i], ah[i]);
-        if constexpr (M == 56) GQ_WWAIT(w4_min15(w4_cnt(M) - 2), al[7], ah[7]);
+        if constexpr (M < 8) GQ_WWAIT(w4_wait(S, 16 + 2 * j + 1, M, false), bl[PC][j], bh[PC][j]);
+        if constexpr (j == 0 && i < 7) GQ_WWAIT(w4_wait(S, 2 * i + 1, M, false), al[i], ah[i]);
+        if constexpr (M == 56) GQ_WWAIT(w4_wait(S, 15, M, true), al[7], ah[7]);
         mfma(c[i][j], al[i], ah[i], bl[PC][j], bh[PC][j]);
-        if constexpr (M == 0) GQ_WRD(al[7], adA[SC >> 1][7], OC);
-        if constexpr (M == 1) GQ_WRD(ah[7], adA[SC >> 1][7], OC + 2048);
-        if constexpr (M == 2) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
-        if constexpr (M == 4) GQ_WRD(bl[PN][0], adB[SN >> 1][0], ON);
-        if constexpr (M == 5) GQ_WRD(bh[PN][0], adB[SN >> 1][0], ON + 2048);
-        if constexpr (i >= 1 && j == 1) GQ_WRD(al[i - 1], adA[SN >> 1][i - 1], ON);
-        if constexpr (i >= 1 && j == 2) GQ_WRD(ah[i - 1], adA[SN >> 1][i - 1], ON + 2048);
-        if constexpr (i >= 1 && j == 4) GQ_WRD(bl[PN][i], adB[SN >> 1][i], ON);
-        if constexpr (i >= 1 && j == 5) GQ_WRD(bh[PN][i], adB[SN >> 1][i], ON + 2048);
-        if constexpr (j == 6) {  // the DMA pieces of half-stage n+3: A pieces in rows 0-3, B pieces in rows 4-7
-            if constexpr (i < 4) GQ_WDL(voff[i], gA, ldsw + (unsigned)(SD * S_BUF_BYTES + i * 1024));
-            else GQ_WDL(voff[i - 4], gB, ldsw + (unsigned)(SD * S_BUF_BYTES + 16384 + (i - 4) * 1024));
+        if constexpr (M == S.bar) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+        read<SC, S.rd[M][0]>();
+        read<SC, S.rd[M][1]>();
+        read<SC, S.rd[M][2]>();
+        read<SC, S.rd[M][3]>();
+        if constexpr (S.dma[M] >= 0) {  // a DMA piece of half-stage n+3
+            constexpr int u = S.dma[M];
+            if constexpr (u < 4) GQ_WDL(voff[u], gA, ldsw + (unsigned)(SD * S_BUF_BYTES + u * 1024));
+            else GQ_WDL(voff[u - 4], gB, ldsw + (unsigned)(SD * S_BUF_BYTES + 16384 + (u - 4) * 1024));
         }
     }
     template <int SC, int... M>
@@ -965,7 +1026,7 @@ struct W4 {
 #pragma unroll
         for (int u = 0; u < 4; ++u) GQ_WDL(voff[u], gA, ldsw + (unsigned)(h * S_BUF_BYTES + u * 1024));
 #pragma unroll
-        for (int u = 0; u < 4; ++u) GQ_WDL(voff[u], gB, ldsw + (unsigned)(h * S_BUF_BYTES + 16384 + u * 1024));
+        for (int u = 0; u < 4; ++u) GQ_WDL(voff[u], gB, ldsw + (unsigned)(h * S_BUF_BYTES + 16384 + (u - 0) * 1024));
     }
 };
 #undef GQ_WDL
@@ -1399,7 +1460,7 @@ static int syrk16_launch(int kind, const int* idx, int m, float* const* H, const
         int wgs = 256;
         if (const int64_t e = opt(OPT_syrk_wgs)) wgs = (e >= 8 && e <= 256) ? (int)(e & ~7) : 256;
         const dim3 grid((unsigned)(grp.bar ? wgs : 8 * grp.per_xcd)), blk(512);
-        if (opt(OPT_syrk_w4)) {  // four waves, 128 x 128 wave tiles (bit-identical)
+        if (opt(OPT_syrk_w4)) {  // four waves, 128 x 128 wave tiles (default; bit-identical to the eight-wave form)
             if (bf) hipLaunchKernelGGL(syrk16_256w_kernel<true>, grid, dim3(256), S_LDS_BYTES, st, grp);
             else hipLaunchKernelGGL(syrk16_256w_kernel<false>, grid, dim3(256), S_LDS_BYTES, st, grp);
         } else if (bf) hipLaunchKernelGGL(syrk16_256n_kernel<true>, grid, blk, S_LDS_BYTES, st, grp);

@@ -6,7 +6,7 @@ import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-syrk = [i for i, r in enumerate(rows) if "syrk16_256n" in r["Kernel_Name"]]
+syrk = [i for i, r in enumerate(rows) if "syrk16_256" in r["Kernel_Name"]]
 n_per = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 first = syrk[-n_per]
 # the step starts with the staging copies before its first SYRK: walk back over stage_rows kernels
