@@ -111,6 +111,7 @@ class BlockSchedule:
         self._last_fired: Optional[str] = None
         self._n_samples = 0
         self.n_streams = int(os.environ.get("GQ_CHAIN_STREAMS", 4)) if n_streams is None else n_streams
+        self.stack = os.environ.get("GQ_STACK", "1") != "0"  # Linears that share U walk the columns together
         self.verbose = verbose
         self.stats = {"syrk_launches": 0, "allreduce_bytes": 0, "reused_U": 0, "own_U": 0, "refactorised": 0}
         self.owners: Dict[str, Any] = {}  # name -> owner rank or "rows/<world>" of the last quantize()
@@ -406,31 +407,43 @@ class BlockSchedule:
                 lead = handles[names[0]].shared_H_with or handles[names[0]]
                 lane.wait(ready.get(id(lead), start))
                 born = []
+
+                def computed(n, h, res):
+                    if n in own and h._pending_mismatch is not None:
+                        BlockSchedule.unverified.append(h._pending_mismatch)
+                        h._pending_mismatch = None
+                        self.stats["reused_U"] += 1
+                    elif own.get(n, False):
+                        self.stats["refactorised"] += 1
+                    results[n] = res
+                    born.extend(res)
+                    if world == 1 and writeback:
+                        deq[n] = dequantize_linear_weight(qtypes[n], *res, out_dtype=h.layer.weight.data.dtype)
+                        born.append(deq[n])
+                    if extra is not None:
+                        out = extra(n, h, res)
+                        born.extend(t for t in (out if isinstance(out, (tuple, list)) else (out,)) if torch.is_tensor(t))
+
                 with lane.run():
-                    # the leader first: it factorises, the followers reuse its U
-                    for n in sorted(names, key=lambda n: handles[n].shared_H_with is not None):
-                        h = handles[n]
+                    # the leader first: it factorises, the followers reuse its U.  Linears that are KNOWN to share the
+                    # factorisation (same input, same dead / zero-column sets) and the same grid walk the columns
+                    # together, stacked by rows (GPTQ.compute_stacked): q / k / v and gate / up cost one walk each
+                    for grp in self._stack_groups(sorted(names, key=lambda n: handles[n].shared_H_with is not None), qtypes, own):
                         if self.verbose:
-                            print(f"[rank {rank}] Quantizing {n} with {qtypes[n].name}.")
+                            for n in grp:
+                                print(f"[rank {rank}] Quantizing {n} with {qtypes[n].name}.")
+                        if len(grp) > 1:
+                            hs = [handles[n] for n in grp]
+                            self.stats["stacked"] = self.stats.get("stacked", 0) + len(grp)
+                            for n, h, res in zip(grp, hs, GPTQ.compute_stacked(hs, qtypes[grp[0]])):
+                                computed(n, h, res)
+                            continue
+                        n = grp[0]
+                        h = handles[n]
                         h.make_working_copy()
                         # follower with the same zero columns as its leader: reuse (flag kept for verify());
                         # different: own factorisation; unknown (first fed after the first sample): checked below
-                        res = h.compute(qtypes[n], defer_check=True, own_U=own.get(n, False))
-                        if n in own and h._pending_mismatch is not None:
-                            BlockSchedule.unverified.append(h._pending_mismatch)
-                            h._pending_mismatch = None
-                            self.stats["reused_U"] += 1
-                        elif own.get(n, False):
-                            self.stats["refactorised"] += 1
-                        results[n] = res
-                        born += list(res)
-                        if world == 1 and writeback:
-                            deq[n] = dequantize_linear_weight(qtypes[n], *res, out_dtype=h.layer.weight.data.dtype)
-                            born.append(deq[n])
-                        if extra is not None:
-                            out = extra(n, h, res)
-                            born += [t for t in (out if isinstance(out, (tuple, list)) else (out,))
-                                     if torch.is_tensor(t)]
+                        computed(n, h, h.compute(qtypes[n], defer_check=True, own_U=own.get(n, False)))
                 lanes.append((lane, born))
             for lane, born in lanes:
                 lane.join(born)
@@ -473,6 +486,30 @@ class BlockSchedule:
                 h.layer.weight.data = w
             h.reset()
         return out
+
+    def _stack_groups(self, names: List[str], qtypes, own: Dict[str, bool]) -> List[List[str]]:
+        """The Linears of one chain (one input tensor; the leader first), cut into the groups that walk the columns
+        together: the leader and the followers whose dead / zero-column sets are known to equal the leader's, per grid
+        (GPTQ.stack_key), at most eight to a group.  Everything else -- followers with sets of their own, followers whose
+        sharing became known too late, act_order or row-split matrices -- walks alone, in the old order.
+        GQ_STACK=0 (or BlockSchedule.stack = False): nobody is stacked."""
+        if not self.stack:
+            return [[n] for n in names]
+        groups: List[List[str]] = []
+        open_: Dict[Any, List[str]] = {}
+        for n in names:
+            h = self.handles[n]
+            key = h.stack_key(qtypes[n])
+            known = (h.shared_H_with is None and h._has_followers) or (n in own and not own[n])
+            if key is None or not known:
+                groups.append([n])
+                continue
+            g = open_.get(key)
+            if g is None or len(g) >= 8:
+                g = open_[key] = []
+                groups.append(g)
+            g.append(n)
+        return groups
 
     @staticmethod
     def _piece_layout(q_type, rows: int, cols: int):

@@ -5,7 +5,8 @@ namespace gq {
 thread_local char g_err[512] = "";
 
 int launch_scale_search(const float*, int64_t, int64_t, int, const gq_search_t*, uint16_t*, int64_t, uint8_t*, int64_t,
-                        uint16_t*, int64_t, uint8_t*, int64_t, hipStream_t, unsigned* panel = nullptr);
+                        uint16_t*, int64_t, uint8_t*, int64_t, hipStream_t, unsigned* panel = nullptr,
+                        const int64_t* row_ends = nullptr, int nstack = 1);
 int launch_dequantize(int, const uint8_t*, const uint16_t*, const uint8_t*, const uint16_t*, const uint8_t*, int64_t,
                       int64_t, void*, int, hipStream_t);
 int launch_rtn_elementwise(const void*, int, const uint16_t*, const uint8_t*, const uint16_t*, const uint8_t*, int64_t,
@@ -20,7 +21,7 @@ int launch_trailing_update(float*, int64_t, const float*, int64_t, const float*,
                            hipStream_t);
 size_t gptq_workspace_bytes(int64_t, int64_t, int);
 int gptq_quantize(float*, const float*, int64_t, int64_t, int, int, int, const gq_search_t*, uint8_t*, uint16_t*,
-                  uint8_t*, uint16_t*, uint8_t*, void*, size_t, hipStream_t, const int32_t*);
+                  uint8_t*, uint16_t*, uint8_t*, void*, size_t, hipStream_t, const int32_t*, const int64_t* = nullptr, int = 1);
 size_t h_accumulate_workspace_bytes(int64_t, int64_t);
 int h_accumulate(float*, const void*, int, int64_t, int64_t, float, float, void*, size_t, hipStream_t);
 int h_accumulate_grouped(int, float* const*, const void* const*, const int64_t*, const int64_t*, const float*, const float*,
@@ -248,6 +249,14 @@ int gq_gptq_quantize(float* W, const float* U, int64_t R, int64_t C, int q_type,
                      void* ws, size_t ws_bytes, void* stream) {
     return gptq_quantize(W, U, R, C, q_type, block_size, static_groups, p, qweight, d, s, dmin, m, ws, ws_bytes,
                          (hipStream_t)stream, nullptr);
+}
+
+int gq_gptq_quantize_stacked(float* W, const float* U, int64_t R, int64_t C, int q_type, int block_size, int static_groups,
+                             const gq_search_t* p, uint8_t* qweight, uint16_t* d, uint8_t* s, uint16_t* dmin, uint8_t* m,
+                             const int64_t* row_ends_host, int n_stacked, void* ws, size_t ws_bytes, void* stream) {
+    if (n_stacked < 1 || (n_stacked > 1 && !row_ends_host)) GQ_FAIL(GQ_E_NULL, "gq_gptq_quantize_stacked: n_stacked=%d without row_ends", n_stacked);
+    return gptq_quantize(W, U, R, C, q_type, block_size, static_groups, p, qweight, d, s, dmin, m, ws, ws_bytes,
+                         (hipStream_t)stream, nullptr, row_ends_host, n_stacked);
 }
 
 int gq_gptq_quantize_perm(float* W, const float* U, int64_t R, int64_t C, int q_type, int block_size, const int32_t* perm,

@@ -81,6 +81,8 @@ enum Opt {
 };
 int64_t opt(Opt o);
 
+constexpr int GQ_MAX_STACK = 8;  // row-stacked matrices of one gq_gptq_quantize_stacked call
+
 struct TypeInfo {
     int bits, qmin, qmax, scale_maxq, group, is_signed, k_search, type_size;
 };

@@ -17,7 +17,8 @@ namespace gq {
 
 int launch_scale_search(const float* x, int64_t rows, int64_t ld, int q_type, const gq_search_t* p,
                         uint16_t* d, int64_t d_stride, uint8_t* s, int64_t s_ld, uint16_t* dmin,
-                        int64_t dmin_stride, uint8_t* m, int64_t m_ld, hipStream_t st, unsigned* panel = nullptr);
+                        int64_t dmin_stride, uint8_t* m, int64_t m_ld, hipStream_t st, unsigned* panel = nullptr,
+                        const int64_t* row_ends = nullptr, int nstack = 1);
 
 // ---------------------------------------------------------------- K5 segment
 // Processes columns [a, a+len) (len <= 128, a % 16 == 0, len % 16 == 0) of the
@@ -464,7 +465,10 @@ struct UniformSpec {
 
 static int column_loop(float* W, const float* U, int64_t R, int64_t C, int q_type, int block_size, int static_groups,
                        const gq_search_t* p, uint8_t* qweight, uint16_t* d, uint8_t* s, uint16_t* dmin, uint8_t* m,
-                       void* ws, size_t ws_bytes, hipStream_t st, const int32_t* perm, const UniformSpec* uni) {
+                       void* ws, size_t ws_bytes, hipStream_t st, const int32_t* perm, const UniformSpec* uni,
+                       const int64_t* row_ends = nullptr, int nstack = 1) {
+    // row_ends / nstack: W is several matrices that share U, one under the other (rows never mix: gptq.py:222-270);
+    // only the scale searches need to know where one ends and the next begins (their panel-wide `continue`)
     TypeInfo ti;
     if (uni) {
         ti = TypeInfo{};
@@ -529,7 +533,7 @@ static int column_loop(float* W, const float* U, int64_t R, int64_t C, int q_typ
     // one device word shared by all scale-search launches of this call (each leaves it at zero)
     unsigned* panel = reinterpret_cast<unsigned*>(
         (reinterpret_cast<uintptr_t>(Wblk + ((B > SEG) ? (size_t)R * B : 0)) + 255) & ~(uintptr_t)255);
-    if (ti.k_search && static_groups != 2) GQ_HIP(hipMemsetAsync(panel, 0, 8, st));
+    if (ti.k_search && static_groups != 2) GQ_HIP(hipMemsetAsync(panel, 0, 8 * (size_t)(nstack > 1 ? nstack : 1), st));
     const int64_t ng = C / ti.group, nsg = C / 256;
     const int gps = uni ? 1 : 256 / ti.group;
     auto uniform_params = [&](int64_t col, int G, int64_t g) {
@@ -544,7 +548,7 @@ static int column_loop(float* W, const float* U, int64_t R, int64_t C, int q_typ
     if (static_groups == 1) {  // gptq.py:184-196: all scales from the ORIGINAL W
         for (int64_t c = 0; c < C; c += 256)
             if ((rc = launch_scale_search(W + c, R, C, q_type, p, d + c / 256, nsg, s + (c / 256) * gps, ng,
-                                          dmin + c / 256, nsg, m + (c / 256) * gps, ng, st, panel)))
+                                          dmin + c / 256, nsg, m + (c / 256) * gps, ng, st, panel, row_ends, nstack)))
                 return rc;
     }
     const dim3 seg_grid((unsigned)((R + 63) / 64)), seg_block(SEG_WAVES * 64);
@@ -592,7 +596,7 @@ static int column_loop(float* W, const float* U, int64_t R, int64_t C, int q_typ
                 // are stale by design
                 const int64_t sg = a / 256;
                 if ((rc = launch_scale_search(W + a, R, C, q_type, p, d + sg, nsg, s + sg * gps, ng, dmin + sg, nsg,
-                                              m + sg * gps, ng, st, panel)))
+                                              m + sg * gps, ng, st, panel, row_ends, nstack)))
                     return rc;
             }
             // an even block of a 256-group: its partner's columns are updated in this kernel's epilogue
@@ -714,9 +718,10 @@ static int column_loop(float* W, const float* U, int64_t R, int64_t C, int q_typ
 
 int gptq_quantize(float* W, const float* U, int64_t R, int64_t C, int q_type, int block_size, int static_groups,
                   const gq_search_t* p, uint8_t* qweight, uint16_t* d, uint8_t* s, uint16_t* dmin, uint8_t* m,
-                  void* ws, size_t ws_bytes, hipStream_t st, const int32_t* perm) {
+                  void* ws, size_t ws_bytes, hipStream_t st, const int32_t* perm, const int64_t* row_ends, int nstack) {
+    if (nstack > 1 && perm) GQ_FAIL(GQ_E_UNSUPPORTED, "gq_gptq_quantize_stacked: act_order matrices are not stacked");
     return column_loop(W, U, R, C, q_type, block_size, static_groups, p, qweight, d, s, dmin, m, ws, ws_bytes, st, perm,
-                       nullptr);
+                       nullptr, row_ends, nstack);
 }
 
 // EvoPress FastOBQ.step for one bit width (evopress/src/fast_obq.py:146-200) given U.

@@ -133,7 +133,18 @@ struct SearchParams {
     int nstep;
     int mse_n;       // quant_scale == "mse": candidates of the grid search, int(maxshrink * grid) + 1; 0: absmax
     double mse_den;  // maxshrink * grid
+    // Row-stacked matrices (gq_gptq_quantize_stacked: several Linears that share U, one under the other): matrix k is
+    // rows [row_end[k-1], row_end[k]), every boundary a multiple of 64.  The one cross-row dependence of the path -- the
+    // panel-wide `continue` of quant_utils.py:250-252 -- is per MATRIX: one pair of panel words per stacked matrix.
+    int nstack;      // <= 1: one matrix
+    int row_end[GQ_MAX_STACK];
 };
+
+__device__ __forceinline__ int stack_of(const SearchParams& sp, int64_t row) {
+    int k = 0;
+    for (int i = 0; i + 1 < sp.nstack; ++i) k += row >= sp.row_end[i] ? 1 : 0;
+    return k;
+}
 
 // quant_utils.py:199-274 for one group spread over LPG lanes; NS = G/LPG values per lane.
 // `skip`: iterations the WHOLE panel skips (bit i); `valid`: bit i set when this group has D > eps in iteration i;
@@ -354,7 +365,7 @@ __global__ __launch_bounds__(256) void scale_search_kernel(
     if constexpr (KSEARCH) {
         unsigned valid = 0, accepted = 0;
         k_search<NS, BITS, RM, 8>(xv, sp, gscale, gzero, 0u, valid, accepted);
-        if (panel_valid) publish_valid(panel_valid, valid, live ? accepted : 0u);
+        if (panel_valid) publish_valid(panel_valid + 2 * stack_of(sp, live ? row : rows - 1), live ? valid : 0u, live ? accepted : 0u);
     } else {
         absmax_search<NS, BITS, RM, 8>(xv, sp, gscale, gzero);
     }
@@ -439,7 +450,7 @@ __global__ __launch_bounds__(64) void scale_search_lane_kernel(
     if constexpr (KSEARCH) {
         unsigned valid = 0, accepted = 0;
         k_search<NS, BITS, RM, LPG>(xv, sp, gscale, gzero, 0u, valid, accepted);
-        if (panel_valid) publish_valid(panel_valid, valid, live ? accepted : 0u);
+        if (panel_valid) publish_valid(panel_valid + 2 * stack_of(sp, live ? row : rows - 1), live ? valid : 0u, live ? accepted : 0u);
     } else {
         absmax_search<NS, BITS, RM, LPG>(xv, sp, gscale, gzero);
     }
@@ -481,13 +492,22 @@ __global__ __launch_bounds__(64) void scale_search_lane_kernel(
 // groups, never a weight matrix -- Q5_K panels take the no-search branch every time).  One lane per group, plain loads: the slow path only has to be right.  Leaves the panel word at 0.
 template <int GSZ, int BITS, bool SIGNED, int SMQ, int RM>
 __global__ __launch_bounds__(256) void panel_fixup_kernel(
-    const void* __restrict__ x, int64_t rows, int64_t ld, SearchParams sp,
-    uint16_t* __restrict__ d, int64_t d_stride, uint8_t* __restrict__ s, int64_t s_ld,
-    uint16_t* __restrict__ dmin, int64_t dmin_stride, uint8_t* __restrict__ m, int64_t m_ld,
-    float* __restrict__ gs_out, float* __restrict__ gz_out, unsigned* panel_valid) {
+    const void* x, int64_t rows, int64_t ld, SearchParams sp,
+    uint16_t* d, int64_t d_stride, uint8_t* s, int64_t s_ld,
+    uint16_t* dmin, int64_t dmin_stride, uint8_t* m, int64_t m_ld,
+    float* gs_out, float* gz_out, unsigned* panel_valid) {
     constexpr int NG = 256 / GSZ;
     constexpr int RPB = 256 / NG;  // rows per pass of the workgroup
     __shared__ unsigned sh_valid, sh_acc;
+    if (sp.nstack > 1) {  // workgroup k = stacked matrix k: its rows, its panel words
+        const int64_t r0 = blockIdx.x ? sp.row_end[blockIdx.x - 1] : 0;
+        rows = sp.row_end[blockIdx.x] - r0;
+        x = RM == 0 ? (const void*)(reinterpret_cast<const float*>(x) + r0 * ld)
+                    : (const void*)(reinterpret_cast<const uint16_t*>(x) + r0 * ld);
+        d += r0 * d_stride; dmin += r0 * dmin_stride; s += r0 * s_ld; m += r0 * m_ld;
+        if (gs_out) { gs_out += r0 * NG; gz_out += r0 * NG; }
+        panel_valid += 2 * blockIdx.x;
+    }
     const unsigned full = (2u << sp.nstep) - 1u;
     unsigned V = panel_valid[0] & full, A = panel_valid[1] & full;
     unsigned skip = 0;
@@ -558,18 +578,27 @@ template <int RM>
 static int launch_ss(const void* x, int64_t rows, int64_t ld, int q_type, const gq_search_t* p, uint16_t* d,
                      int64_t d_stride, uint8_t* s, int64_t s_ld, uint16_t* dmin, int64_t dmin_stride, uint8_t* m,
                      int64_t m_ld, hipStream_t st, float* gs_out = nullptr, float* gz_out = nullptr,
-                     unsigned* panel = nullptr) {
+                     unsigned* panel = nullptr, const int64_t* row_ends = nullptr, int nstack = 1) {
     // `panel`: one zeroed device word per call chain (left at zero again); nullptr: taken from the stream's pool
     TypeInfo ti;
     if (!type_info(q_type, ti)) GQ_FAIL(GQ_E_BAD_TYPE, "gq_scale_search: unknown q_type %d", q_type);
     if (rows <= 0 || ld < 256) GQ_FAIL(GQ_E_BAD_SHAPE, "gq_scale_search: rows=%ld ld=%ld", (long)rows, (long)ld);
     void* own = nullptr;
+    if (nstack > 1) {
+        if (nstack > GQ_MAX_STACK || !row_ends) GQ_FAIL(GQ_E_UNSUPPORTED, "gq_scale_search: %d stacked matrices (at most %d)", nstack, GQ_MAX_STACK);
+        for (int k = 0; k < nstack; ++k)
+            if (row_ends[k] % 64 || row_ends[k] <= (k ? row_ends[k - 1] : 0) || row_ends[k] > rows || row_ends[k] > INT32_MAX)
+                GQ_FAIL(GQ_E_BAD_SHAPE, "gq_scale_search: stacked row boundary %ld (ascending multiples of 64 up to rows=%ld)", (long)row_ends[k], (long)rows);
+        if (row_ends[nstack - 1] != rows) GQ_FAIL(GQ_E_BAD_SHAPE, "gq_scale_search: the last stacked matrix ends at %ld, rows=%ld", (long)row_ends[nstack - 1], (long)rows);
+    }
     if (ti.k_search && !panel && (!p || p->nstep >= 1)) {
         GQ_HIP(hipMallocAsync(&own, 256, st));
-        GQ_HIP(hipMemsetAsync(own, 0, 8, st));
+        GQ_HIP(hipMemsetAsync(own, 0, 8 * (size_t)(nstack > 1 ? nstack : 1), st));
         panel = reinterpret_cast<unsigned*>(own);
     }
     SearchParams sp;
+    sp.nstack = nstack > 1 ? nstack : 1;
+    for (int k = 0; k < GQ_MAX_STACK; ++k) sp.row_end[k] = (nstack > 1 && k < nstack) ? (int)row_ends[k] : 0;
     sp.nstep = p ? p->nstep : 20;
     if (sp.nstep > 23) GQ_FAIL(GQ_E_UNSUPPORTED, "gq_scale_search: nstep=%d > 23", sp.nstep);
     const double rmin = p ? p->rmin : -1.0, rdelta = p ? p->rdelta : 0.1;
@@ -615,7 +644,7 @@ static int launch_ss(const void* x, int64_t rows, int64_t ld, int q_type, const 
             hipLaunchKernelGGL((scale_search_kernel<G, B, K, S, Q, RM>), grid, block, 0, st, x, rows, ld, sp, d,   \
                                d_stride, s, s_ld, dmin, dmin_stride, m, m_ld, gs_out, gz_out, panel);              \
         if (K && panel && sp.nstep >= 1)                                                                           \
-            hipLaunchKernelGGL((panel_fixup_kernel<G, B, S, Q, RM>), dim3(1), dim3(256), 0, st, x, rows, ld, sp,   \
+            hipLaunchKernelGGL((panel_fixup_kernel<G, B, S, Q, RM>), dim3((unsigned)sp.nstack), dim3(256), 0, st, x, rows, ld, sp, \
                                d, d_stride, s, s_ld, dmin, dmin_stride, m, m_ld, gs_out, gz_out, panel);           \
     } while (0)
     switch (q_type) {
@@ -633,9 +662,10 @@ static int launch_ss(const void* x, int64_t rows, int64_t ld, int q_type, const 
 
 int launch_scale_search(const float* x, int64_t rows, int64_t ld, int q_type, const gq_search_t* p,
                         uint16_t* d, int64_t d_stride, uint8_t* s, int64_t s_ld, uint16_t* dmin,
-                        int64_t dmin_stride, uint8_t* m, int64_t m_ld, hipStream_t st, unsigned* panel) {
+                        int64_t dmin_stride, uint8_t* m, int64_t m_ld, hipStream_t st, unsigned* panel,
+                        const int64_t* row_ends, int nstack) {
     return launch_ss<0>(x, rows, ld, q_type, p, d, d_stride, s, s_ld, dmin, dmin_stride, m, m_ld, st, nullptr, nullptr,
-                        panel);
+                        panel, row_ends, nstack);
 }
 
 // make_k_quants / make_quants outputs (per-group fp32 scale and zero) of one [rows,256] panel in

@@ -8,7 +8,7 @@ Same constructor, same `update / quantize / reset` protocol and return order
   step                  -> gq_gptq_quantize  (K4 + K5 + K6)
 """
 import os
-from typing import Optional, Tuple
+from typing import Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -231,8 +231,14 @@ class GPTQ:
                 self.H = None
 
     @torch.no_grad()
-    def make_working_copy(self) -> None:
+    def make_working_copy(self, out: Optional[Tensor] = None) -> None:
+        """`out`: fp32 [d_row, d_col] rows of a buffer that stacks the Linears of one input (compute_stacked)."""
         W = self.layer.weight.detach()
+        if out is not None:
+            assert out.shape == (self.d_row, self.d_col) and out.dtype == torch.float32 and out.is_contiguous()
+            out.copy_(W.flatten(1, -1) if isinstance(self.layer, _ConvNd) else W)  # the same fp32 values as .float()
+            self.W = out
+            return
         W = W.clone() if W.dtype == torch.float32 else W.float()  # gptq.py:138 (clone().float(): one pass, not two)
         if isinstance(self.layer, _ConvNd):
             W = W.flatten(1, -1)
@@ -287,6 +293,44 @@ class GPTQ:
             W = self.W[r0:r1]
         return _ops.gptq_quantize(W, U, int(q_type), self.block_size, self.static_groups, self.rmin,
                                   self.rdelta, self.nstep, quant_scale=self.quant_scale.value, grid=self.grid)
+
+    def stack_key(self, q_type: GGMLQuantizationType):
+        """Handles with equal keys that share a factorisation may be quantized in ONE walk over the columns
+        (compute_stacked); None: this handle walks alone."""
+        if self.act_order and q_type != GGMLQuantizationType.Q3_K:
+            return None
+        if self._row_split_active() or self.d_row % 64 or self.layer.weight.dtype not in (torch.float16, torch.bfloat16, torch.float32):
+            return None
+        return (int(q_type), self.d_col, self.block_size, bool(self.static_groups) and q_type != GGMLQuantizationType.Q3_K,
+                self.rmin, self.rdelta, self.nstep, self.quant_scale, self.grid, self.rel_damp, str(self.W_device))
+
+    @staticmethod
+    @torch.no_grad()
+    def compute_stacked(hs: Sequence["GPTQ"], q_type: GGMLQuantizationType):
+        """compute() of several handles that share U -- the leader of an input tensor first, then followers whose dead /
+        zero-column sets equal the leader's (q / k / v, gate / up, an expert's w1 / w3) -- as ONE column loop over their
+        working copies stacked by rows (gq_gptq_quantize_stacked).  Rows never mix in gptq.py:222-270 and the loop is
+        bound by its C dependent steps, so three Linears cost one walk; the scale search's one look across rows
+        (quant_utils.py:250-252) is kept per Linear: every result equals compute()'s bit for bit.  Returns the handles'
+        result tuples (row slices of the stacked outputs); follower flags stay on the device (_pending_mismatch)."""
+        assert len(hs) > 1 and all(h.stack_key(q_type) == hs[0].stack_key(q_type) is not None for h in hs)
+        rows = [h.d_row for h in hs]
+        ends = [sum(rows[:i + 1]) for i in range(len(rows))]
+        Wf = torch.empty((ends[-1], hs[0].d_col), device=hs[0].W_device, dtype=torch.float32)
+        U = None
+        for h, r1, n in zip(hs, ends, rows):
+            if q_type == GGMLQuantizationType.Q3_K:
+                h.act_order = False
+                h.static_groups = False
+            h.make_working_copy(out=Wf[r1 - n:r1])
+            Uh = h._prepare(defer_check=True)  # the leader factorises; a follower masks its dead columns and leaves a flag
+            assert U is None or Uh is U, "stacked handles must share one factorisation"
+            U = Uh
+            h._last_U = U
+        h0 = hs[0]
+        res = _ops.gptq_quantize(Wf, U, int(q_type), h0.block_size, h0.static_groups, h0.rmin, h0.rdelta, h0.nstep,
+                                 quant_scale=h0.quant_scale.value, grid=h0.grid, row_ends=ends)
+        return [tuple(t[r1 - n:r1] for t in res) for r1, n in zip(ends, rows)]
 
     def _row_split_active(self) -> bool:
         return bool(self.row_split) and not self.act_order and dist_utils.get_world_size() > 1

@@ -5,7 +5,7 @@ a kernel of libgptqgguf_hip.so.  All functions enqueue on torch's current stream
 return without synchronising.
 """
 import ctypes
-from typing import Optional, Tuple
+from typing import Optional, Sequence, Tuple
 
 import torch
 
@@ -209,9 +209,15 @@ def _streams(device, n):
 
 
 def gptq_quantize(W: torch.Tensor, U: torch.Tensor, q_type: int, block_size=128, static_groups=False, rmin=-1.0,
-                  rdelta=0.1, nstep=20, ws: Optional[torch.Tensor] = None, row_chunks: Optional[int] = None, **mq):
+                  rdelta=0.1, nstep=20, ws: Optional[torch.Tensor] = None, row_chunks: Optional[int] = None,
+                  row_ends: Optional[Sequence[int]] = None, **mq):
     """GPTQ.step body.  W (fp32, contiguous) is updated IN PLACE to the dequantized matrix.
     Returns (qweight, d, s, dmin, m).
+
+    `row_ends` (gq_gptq_quantize_stacked): W holds several Linears that share U, one under the other -- matrix k is rows
+    [row_ends[k-1], row_ends[k]), multiples of 64, the last one == R.  One walk over the columns instead of one per
+    Linear; every output row equals the separate calls bit for bit (the scale search's panel-wide `continue`,
+    quant_utils.py:250-252, is evaluated per stacked matrix).
 
     Rows of W are independent given U (gptq.py:222-270 never mixes rows), so a tall matrix is cut into
     `row_chunks` contiguous row ranges, each a separate gq_gptq_quantize call on its own HIP stream: the
@@ -227,6 +233,18 @@ def gptq_quantize(W: torch.Tensor, U: torch.Tensor, q_type: int, block_size=128,
         row_chunks = 1
     if row_chunks > 1 and (R % (64 * row_chunks) or ws is not None):
         row_chunks = 1
+
+    if row_ends is not None and len(row_ends) > 1:
+        ends = (ctypes.c_int64 * len(row_ends))(*[int(e) for e in row_ends])
+        need = workspace_bytes(_cabi.WS_GPTQ_QUANTIZE, R, C, 0, bs)
+        if ws is None or ws.numel() < need:
+            ws = _ws(need, W.device)
+        check(lib().gq_gptq_quantize_stacked(_ptr(W), _ptr(U), R, C, int(q_type), bs, int(bool(static_groups)),
+                                             _search(rmin, rdelta, nstep, **mq), _ptr(q), _ptr(d), _ptr(s), _ptr(dmin),
+                                             _ptr(m), ends, len(row_ends), _ptr(ws), ws.numel(), _stream(W)),
+              "gq_gptq_quantize_stacked")
+        t = _idt(q_type)
+        return q.view(t), d, s.view(t), dmin, m.view(t)
 
     def one(r0, r1, wsbuf):
         n = r1 - r0

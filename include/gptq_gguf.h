@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define GQ_ABI_VERSION 4
+#define GQ_ABI_VERSION 5
 
 /* ggml type ids (quant_utils.py:11-16) */
 enum { GQ_Q2_K = 10, GQ_Q3_K = 11, GQ_Q4_K = 12, GQ_Q5_K = 13, GQ_Q6_K = 14 };
@@ -88,6 +88,8 @@ const char* gq_last_error(void);
      GQ_SO_PATH         another build of this library (kernel A/B probes)
      GQ_CHAIN_STREAMS   lanes of the block schedule (default 4 = the hardware queues the chains of a block share)
      GQ_ROW_SPLIT       0 / 1: never / always split the widest matrix by rows across ranks (default: from 4 ranks up)
+     GQ_STACK           0: every Linear walks its columns alone (default 1: Linears that share a factorisation are stacked by
+                        rows into one gq_gptq_quantize_stacked call; same results)
      GQ_POST_BLOCKS     early | before_last_block (default) | last: where lm_head is quantized (same tensors and files)
      GQ_FUSED_FORWARD   off | exact | all: overrides the Quantizer's fused_forward argument (A/B runs)
      GQ_SAVE_SKIP       1: no data.pth is written (measures what saving costs)
@@ -198,6 +200,19 @@ int gq_gptq_quantize(float* W, const float* U, int64_t R, int64_t C, int q_type,
                      int block_size, int static_groups, const gq_search_t* p_host,
                      uint8_t* qweight, uint16_t* d, uint8_t* s, uint16_t* dmin, uint8_t* m,
                      void* ws, size_t ws_bytes, void* stream);
+
+/* The same call on SEVERAL Linears that share U -- the Linears of one input tensor whose dead / zero-column sets agree:
+   q / k / v, gate / up, an expert's w1 / w3 (gptq.py:304-324 gives them the same H and therefore the same U) -- stacked
+   by rows into one [R, C] working copy: matrix k is rows [row_ends[k-1], row_ends[k]) (host array of n_stacked ascending
+   multiples of 64, the last one == R; n_stacked <= 8).  Rows never mix in gptq.py:222-270, and the column loop is bound
+   by its C dependent steps, not by its rows: one walk over the columns instead of n_stacked.  The one place where the
+   reference looks across the rows of a matrix -- the panel-wide `continue` of quant_utils.py:250-252 inside
+   get_scale_and_zero -- is evaluated per stacked matrix, so every output row is bit-identical to the separate calls. */
+int gq_gptq_quantize_stacked(float* W, const float* U, int64_t R, int64_t C, int q_type,
+                             int block_size, int static_groups, const gq_search_t* p_host,
+                             uint8_t* qweight, uint16_t* d, uint8_t* s, uint16_t* dmin, uint8_t* m,
+                             const int64_t* row_ends_host, int n_stacked,
+                             void* ws, size_t ws_bytes, void* stream);
 
 /* 1 if gq_gptq_quantize / gq_gptq_quantize_perm / gq_obq_quantize on an R x C matrix MAY put the bulk of its far
    trailing updates (gptq.py:270 beyond the current 1024-column super-block) on the library's own helper HIP stream,

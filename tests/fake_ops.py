@@ -6,7 +6,7 @@ import torch
 
 from oracle import oracle as O
 
-calls = {"h_accumulate": 0, "h_prepare": 0, "w_prepare": 0, "gptq_quantize": 0}
+calls = {"h_accumulate": 0, "h_prepare": 0, "w_prepare": 0, "gptq_quantize": 0, "gptq_quantize_stacked": 0}
 
 
 def _f16(bits):
@@ -63,8 +63,19 @@ def _mode(mq):
     O.set_quant_scale(mq.get("quant_scale", "absmax"), mq.get("grid", 100), mq.get("maxshrink", 0.8))
 
 
-def gptq_quantize(W, U, q_type, block_size=128, static_groups=False, rmin=-1.0, rdelta=0.1, nstep=20, ws=None, **mq):
+def gptq_quantize(W, U, q_type, block_size=128, static_groups=False, rmin=-1.0, rdelta=0.1, nstep=20, ws=None,
+                  row_ends=None, **mq):
     calls["gptq_quantize"] += 1
+    if row_ends is not None and len(row_ends) > 1:
+        # row-stacked Linears that share U (gq_gptq_quantize_stacked): the oracle, matrix by matrix
+        calls["gptq_quantize_stacked"] += 1
+        assert row_ends[-1] == W.shape[0] and all(e % 64 == 0 for e in row_ends)
+        parts, r0 = [], 0
+        for r1 in row_ends:
+            calls["gptq_quantize"] -= 1
+            parts.append(gptq_quantize(W[r0:r1], U, q_type, block_size, static_groups, rmin, rdelta, nstep, **mq))
+            r0 = r1
+        return tuple(torch.cat([p[i] for p in parts]) for i in range(5))
     _mode(mq)
     Wd, q, d, s, dmin, m = O.gptq_step(W.numpy(), U.numpy(), q_type, block_size, static_groups, rmin, rdelta, nstep)
     _mode({})

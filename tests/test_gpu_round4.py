@@ -192,3 +192,86 @@ def test_h_accumulate_four_wave_form_is_bit_identical(ops, dt):
         assert torch.equal(b, b.T)
     ref = 0.25 * H0[0].double() + 0.01 * (Xc[0].double().T @ Xc[0].double())
     assert (outs[1][0].double() - ref).abs().max().item() <= 5e-6 * ref.abs().max().item()
+
+
+# ----------------------------------------------------------------- stacked column loops (gq_gptq_quantize_stacked)
+def _same(a, b):
+    return all(torch.equal(x.view(torch.uint8) if x.dtype != torch.float16 else x.view(torch.int16),
+                           y.view(torch.uint8) if y.dtype != torch.float16 else y.view(torch.int16)) for x, y in zip(a, b))
+
+
+@pytest.mark.parametrize("q_type", [10, 11, 12, 13, 14])
+@pytest.mark.parametrize("static_groups", [False, True])
+def test_stacked_column_loop_equals_the_separate_calls(ops, q_type, static_groups):
+    """Three matrices that share U, stacked by rows (320 + 64 + 128 rows, 768 columns), through gq_gptq_quantize_stacked:
+    every output and the dequantized working copy equal the three gq_gptq_quantize calls BIT FOR BIT -- including the
+    one place where the reference looks across the rows of a matrix: the middle matrix's first 256-column stripe holds ~1e-7
+    values (no group of it is `valid` in any search iteration, quant_utils.py:250-252 skips them all for THAT Linear only),
+    which a stacked call with ONE set of panel words gets wrong (checked: the un-segmented call differs there)."""
+    torch.manual_seed(5 + q_type)
+    C, rows = 768, [320, 64, 128]
+    Ws = [torch.randn(r, C, device="cuda") * 0.02 for r in rows]
+    Ws[1][:, :256] = torch.randn(64, 256, device="cuda") * 1e-7   # the first stripe: no error feedback reaches it
+    U = torch.triu(torch.randn(C, C, device="cuda") * 0.01, 1) + torch.eye(C, device="cuda")
+    kw = dict(block_size=128, static_groups=static_groups)
+    sep, Wd = [], []
+    for w in Ws:
+        w = w.clone()
+        sep.append(ops.gptq_quantize(w, U, q_type, **kw))
+        Wd.append(w)
+    Wf = torch.cat(Ws)
+    ends = [320, 384, 512]
+    st = ops.gptq_quantize(Wf, U, q_type, row_ends=ends, **kw)
+    r0 = 0
+    for k, r1 in enumerate(ends):
+        assert _same([t[r0:r1] for t in st], sep[k]), f"matrix {k}"
+        assert torch.equal(Wf[r0:r1], Wd[k])
+        r0 = r1
+    if q_type == 10 and not static_groups:  # the K-quant search where a skipped iteration's candidate would have won (Q2_K)
+        Wu = torch.cat(Ws)
+        un = ops.gptq_quantize(Wu, U, q_type, **kw)   # one matrix of 512 rows: the panel-wide `continue` sees all rows
+        assert not _same([t[320:384] for t in un], sep[1]), "the per-matrix panel words were not needed here"
+    with pytest.raises(Exception):
+        ops.gptq_quantize(torch.cat(Ws), U, q_type, row_ends=[300, 384, 512], **kw)   # boundaries are multiples of 64
+    with pytest.raises(Exception):
+        ops.gptq_quantize(torch.cat(Ws), U, q_type, row_ends=[320, 384], **kw)        # the last one is R
+
+
+def test_block_schedule_stacked_equals_unstacked_on_the_gpu(ops):
+    """One Llama-shaped block (hidden 512: q 512, k / v 128 rows; gate / up 1024 rows) through BlockSchedule with and
+    without stacking: identical results for every Linear, 4 column loops' worth of launches instead of 7."""
+    import torch.nn as nn
+    from gptq_gguf_toolkit_amd.block_schedule import BlockSchedule
+    from gptq_gguf_toolkit_amd.gptq import GPTQ
+    from gptq_gguf_toolkit_amd.quant_utils import GGMLQuantizationType as T
+    torch.manual_seed(3)
+    shapes = {"q": (512, 512), "k": (128, 512), "v": (128, 512), "o": (512, 512), "gate": (1024, 512), "up": (1024, 512),
+              "down": (512, 1024)}
+    w0 = {n: (torch.randn(r, c, device="cuda") * 0.02).half() for n, (r, c) in shapes.items()}
+    xs, xo, xm = ([torch.randn(1, 256, 512, device="cuda").half() for _ in range(4)] for _ in range(3))
+    xd = [torch.randn(1, 256, 1024, device="cuda").half() for _ in range(4)]
+    outs = []
+    for stack in (False, True):
+        layers = {n: nn.Linear(c, r, bias=False, device="cuda", dtype=torch.float16) for n, (r, c) in shapes.items()}
+        for n, l in layers.items():
+            l.weight.data.copy_(w0[n])
+        sch = BlockSchedule(layers, lambda l, n: GPTQ(l, block_size=128))
+        sch.stack = stack
+        for a, b, c, e in zip(xs, xo, xm, xd):
+            for n in ("q", "k", "v"):
+                sch.feed(n, a)      # one tensor: one Hessian, one factorisation
+            sch.feed("o", b)
+            for n in ("gate", "up"):
+                sch.feed(n, c)
+            sch.feed("down", e)
+            sch.sample_done()
+        res = sch.quantize({n: T.Q4_K for n in shapes})
+        torch.cuda.synchronize()
+        outs.append(({n: tuple(t.clone() for t in r) for n, r in res.items()}, {n: l.weight.data.clone() for n, l in layers.items()},
+                     dict(sch.stats)))
+    (r0, w_0, s0), (r1, w_1, s1) = outs
+    for n in shapes:
+        assert _same(r0[n], r1[n]), n
+        assert torch.equal(w_0[n], w_1[n]), n
+    assert s0.get("stacked", 0) == 0 and s1["stacked"] >= 3
+    BlockSchedule.verify()
