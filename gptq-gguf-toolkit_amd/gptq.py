@@ -109,20 +109,21 @@ class GPTQ:
         pend, self._segs = [y for y, _, _ in self._segs], []
         need = self._staged + sum(y.shape[0] for y in pend) + x.shape[0]
         cap = self.flush_tokens + x.shape[0]  # a fold is due by then
-        if self._buf is not None and self._buf.dtype == x.dtype and self._buf.shape[0] < need <= cap:
+        room = self._buf.shape[0] - self._PAD if self._buf is not None else 0  # rows the buffer offers (+ _PAD rows of slack)
+        if self._buf is not None and self._buf.dtype == x.dtype and room < need <= cap:
             # grow geometrically (x 4: the copies add up to a third of the final size) and keep the staged rows: an MoE expert sees a data-dependent share of the tokens (and 1/N of
             # them on N ranks) -- sizing every expert's buffer for a whole fold up front cost 19 GB per rank on a Mixtral block
-            bigger = torch.empty((min(cap, max(4 * self._buf.shape[0], need)), self.d_col), device=x.device, dtype=x.dtype)
+            bigger = torch.empty((min(cap, max(4 * room, need)) + self._PAD, self.d_col), device=x.device, dtype=x.dtype)
             if self._staged:
                 _ops.h_stage(bigger, 0, self._buf[:self._staged])
             self._buf = bigger
-        if self._buf is not None and (self._buf.dtype != x.dtype or need > self._buf.shape[0]):
+        if self._buf is not None and (self._buf.dtype != x.dtype or need > self._buf.shape[0] - self._PAD):
             if self._staged:  # the staged rows are exactly the samples counted so far (pend is empty in this mode)
                 self.flush()
                 need = x.shape[0]
             self._buf = None
         if self._buf is None:
-            self._buf = torch.empty((max(need, min(cap, 4 * need)), self.d_col), device=x.device, dtype=x.dtype)
+            self._buf = torch.empty((max(need, min(cap, 4 * need)) + self._PAD, self.d_col), device=x.device, dtype=x.dtype)
         for y in pend + [x]:
             _ops.h_stage(self._buf, self._staged, y)
             self._staged += y.shape[0]
@@ -153,8 +154,26 @@ class GPTQ:
                                        "_zero_copy = False to copy activations at hook time")
             X = [x for x, _, _ in self._segs]
         else:
-            X = self._buf[:self._staged]
+            # A ragged fold (MoE experts, odd sequence lengths) is padded with zero rows to whole turns of the SYRK's ring
+            # (128 tokens): zero tokens add exact zeros to every sum, and the fold takes the kernel that reads X in place
+            # (no re-layout pass, four-wave form) instead of the operand-image path
+            pad = (-self._staged) % self._PAD
+            if pad and self._buf.dtype in (torch.float16, torch.bfloat16) and self.d_col % 256 == 0 and self._buf.is_cuda:
+                _ops.h_stage(self._buf, self._staged, self._zero_rows(pad))
+            else:
+                pad = 0
+            X = self._buf[:self._staged + pad]
         return self.H, X, n / (n + b), 2.0 / (n + b)
+
+    _PAD = 128  # tokens per turn of the SYRK's four-slot ring; the staging buffer keeps this many rows of slack
+    _zeros: dict = {}
+
+    def _zero_rows(self, n: int) -> Tensor:
+        key = (self._buf.device, self._buf.dtype, self.d_col)
+        z = GPTQ._zeros.get(key)
+        if z is None:
+            z = GPTQ._zeros[key] = torch.zeros((self._PAD, self.d_col), device=self._buf.device, dtype=self._buf.dtype)
+        return z[:n]
 
     def _flush_done(self) -> None:
         self.num_samples += self._buf_b

@@ -275,3 +275,35 @@ def test_block_schedule_stacked_equals_unstacked_on_the_gpu(ops):
         assert torch.equal(w_0[n], w_1[n]), n
     assert s0.get("stacked", 0) == 0 and s1["stacked"] >= 3
     BlockSchedule.verify()
+
+
+def test_ragged_folds_are_padded_to_whole_ring_turns(ops):
+    """A handle fed ragged inputs (an MoE expert's data-dependent token counts) stages them and pads the fold with zero
+    rows to a multiple of 128 tokens: the fold then takes the kernel that reads X in place (no re-layout pass).  Zero
+    tokens add exact zeros: H equals the operand-image path on the unpadded rows bit for bit, and fp64 to tolerance."""
+    import torch.nn as nn
+    from gptq_gguf_toolkit_amd.gptq import GPTQ
+    torch.manual_seed(8)
+    C = 512
+    lin = nn.Linear(C, 64, bias=False, device="cuda", dtype=torch.float16)
+    h = GPTQ(lin)
+    xs = [torch.randn(1, t, C, device="cuda").half() for t in (100, 37, 300, 1)]
+    for x in xs:
+        h.update(x)
+    assert h._staged == 438 and h._buf.shape[0] >= 438 + 74
+    h.flush()
+    X = torch.cat([x[0] for x in xs])
+    with ops.options(syrk_image=1):
+        ref = torch.zeros(C, C, device="cuda")
+        ops.h_accumulate(ref, X, 0.0, 2.0 / 4)
+    assert torch.equal(h.H, ref)
+    d = 0.5 * (X.double().T @ X.double())
+    assert (h.H.double() - d).abs().max().item() <= 3e-6 * d.abs().max().item()
+    # a second, ragged fold on top (beta != 0), then one that needs no padding
+    ys = [torch.randn(1, t, C, device="cuda").half() for t in (5, 250)]
+    for y in ys:
+        h.update(y)
+    h.flush()
+    h.update(torch.randn(1, 130, C, device="cuda").half()[:, :128].contiguous())
+    h.flush()
+    assert h.num_samples == 7 and torch.equal(h.H, h.H.T)
