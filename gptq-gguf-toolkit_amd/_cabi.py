@@ -16,7 +16,7 @@ F32, F16, BF16 = 0, 1, 2
 WS_H_ACCUMULATE, WS_H_PREPARE, WS_GPTQ_QUANTIZE, WS_CHOL_GEMM = 1, 2, 3, 4
 
 EXPORTS = (
-    "gq_abi_version", "gq_last_error", "gq_option_count", "gq_option_name", "gq_option_get", "gq_option_default", "gq_option_set", "gq_type_info", "gq_workspace_bytes", "gq_h_accumulate", "gq_h_accumulate_grouped", "gq_h_accumulate_segments", "gq_h_stage", "gq_h_prepare", "gq_w_prepare", "gq_h_pack_upper", "gq_h_unpack_upper",
+    "gq_abi_version", "gq_last_error", "gq_option_count", "gq_option_name", "gq_option_get", "gq_option_default", "gq_option_set", "gq_type_info", "gq_workspace_bytes", "gq_h_accumulate", "gq_h_accumulate_grouped", "gq_h_accumulate_segments", "gq_h_stage", "gq_h_stage_many", "gq_h_prepare", "gq_w_prepare", "gq_h_pack_upper", "gq_h_unpack_upper",
     "gq_scale_search", "gq_group_search", "gq_gptq_quantize", "gq_gptq_quantize_stacked", "gq_gptq_quantize_perm", "gq_gptq_uses_helper_stream", "gq_far_helper_enable", "gq_obq_h_prepare", "gq_obq_quantize", "gq_rtn_quantize", "gq_dequantize", "gq_pack", "gq_trailing_update", "gq_chol_gemm", "gq_stage_to_host", "gq_fwd_rmsnorm", "gq_fwd_rmsnorm_ordered", "gq_fwd_rope", "gq_fwd_silu_mul",
     "gq_prof_enable", "gq_prof_ntags", "gq_prof_name", "gq_prof_collect", "gq_prof_collect2",
 )
@@ -80,6 +80,7 @@ def lib():
     L.gq_h_accumulate_grouped.argtypes = [ci, vp, vp, vp, vp, vp, vp, ci, vp, sz, vp]
     L.gq_h_accumulate_segments.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp, ci, vp, sz, vp]
     L.gq_h_stage.argtypes = [vp, vp, i64, vp]
+    L.gq_h_stage_many.argtypes = [vp, vp, vp, ci, vp, sz, vp]
     L.gq_h_prepare.argtypes = [vp, vp, i64, i64, cf, vp, vp, vp, vp, sz, vp]
     L.gq_w_prepare.argtypes = [vp, vp, i64, i64, vp, vp]
     L.gq_h_pack_upper.argtypes = [vp, i64, vp, vp]

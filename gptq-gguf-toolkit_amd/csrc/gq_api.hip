@@ -36,6 +36,7 @@ int w_prepare(const uint8_t*, float*, int64_t, int64_t, int*, hipStream_t);
 int h_pack_upper(const float*, int64_t, float*, hipStream_t);
 int h_unpack_upper(const float*, int64_t, float*, hipStream_t);
 int h_stage(void*, const void*, int64_t, hipStream_t, int max_wgs = 0);
+int h_stage_many(void*, const void* const*, const int64_t*, int, void*, size_t, hipStream_t);
 size_t chol_gemm_workspace_bytes(int64_t, int64_t, int64_t);
 int chol_gemm(float*, int64_t, const float*, int64_t, const float*, int64_t, int64_t, int64_t, int64_t, int, int, int, int, int,
               void*, size_t, hipStream_t);
@@ -227,6 +228,10 @@ int gq_w_prepare(const uint8_t* col_flags, float* W, int64_t R, int64_t C, int* 
 }
 
 int gq_h_stage(void* dst, const void* src, int64_t nbytes, void* stream) { return h_stage(dst, src, nbytes, (hipStream_t)stream); }
+int gq_h_stage_many(void* dst, const void* const* srcs_host, const int64_t* nbytes_host, int n, void* ws, size_t ws_bytes,
+                    void* stream) {
+    return h_stage_many(dst, srcs_host, nbytes_host, n, ws, ws_bytes, (hipStream_t)stream);
+}
 int gq_h_pack_upper(const float* H, int64_t C, float* buf, void* stream) { return h_pack_upper(H, C, buf, (hipStream_t)stream); }
 int gq_h_unpack_upper(const float* buf, int64_t C, float* H, void* stream) { return h_unpack_upper(buf, C, H, (hipStream_t)stream); }
 

@@ -64,6 +64,7 @@ class GPTQ:
         self._fill = 0                 # pending tokens (kept blocks + staged rows)
         self._staged = 0               # rows of _buf in use
         self._segs = []                # zero-copy: (tensor, version at hook time, batch size) per pending sample
+        self._rag = []                 # ragged blocks kept by reference until the fold gathers them: (tensor, version)
         self._zero_copy = True         # False: copy every activation into the staging buffer at hook time
         self._buf_b = 0
         self._U_cache = None
@@ -91,10 +92,18 @@ class GPTQ:
         # Zero-copy: the hook's tensor is kept (a reference, no copy) and the SYRK reads it where the forward left
         # it (gq_h_accumulate_segments) -- as long as every pending sample is one contiguous 16-bit [L, C] block of
         # the same L (a multiple of 128 tokens).  Anything else is staged into one buffer (gq_h_stage).
-        if self._zero_copy and self._staged == 0 and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) \
-                and x.is_contiguous() and t % 128 == 0 and self.d_col % 256 == 0 and x.data_ptr() % 16 == 0 \
+        keepable = self._zero_copy and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and x.is_contiguous() \
+            and x.data_ptr() % 16 == 0 and t > 0
+        if keepable and self._staged == 0 and not self._rag and t % 128 == 0 and self.d_col % 256 == 0 \
                 and (not self._segs or (self._segs[0][0].shape == x.shape and self._segs[0][0].dtype == x.dtype)):
             self._segs.append((x, x._version, batch_size))
+        elif keepable and self.d_col % 8 == 0 and self._pending_dtype() in (None, x.dtype):
+            # Ragged (an MoE expert's data-dependent token count, odd sequence lengths): the tensor is kept by reference
+            # too, and ONE gather launch brings every pending block into the staging buffer when the fold is due
+            # (gq_h_stage_many) -- a copy per hook call is a latency-bound launch per sample and Linear
+            self._rag += [(y, v) for y, v, _ in self._segs]
+            self._segs = []
+            self._rag.append((x, x._version))
         else:
             self._stage(x)
         self._fill += t
@@ -102,10 +111,31 @@ class GPTQ:
         if self._fill >= self.flush_tokens and not self._scheduled:
             self.flush()
 
+    def _gather(self) -> None:
+        """The kept ragged blocks move into the staging buffer, behind the rows already there, in ONE launch."""
+        if not self._rag:
+            return
+        for x, v in self._rag:
+            if x._version != v:
+                raise RuntimeError("a Linear input was modified in place after its forward hook ran; set the handle's "
+                                   "_zero_copy = False to copy activations at hook time")
+        xs = [x for x, _ in self._rag]
+        need = self._staged + sum(x.shape[0] for x in xs)
+        if self._buf is None or self._buf.dtype != xs[0].dtype or self._buf.shape[0] - self._PAD < need:
+            assert self._buf is None or self._buf.dtype == xs[0].dtype or self._staged == 0
+            bigger = torch.empty((need + self._PAD, self.d_col), device=xs[0].device, dtype=xs[0].dtype)
+            if self._staged:
+                _ops.h_stage(bigger, 0, self._buf[:self._staged])
+            self._buf = bigger
+        _ops.h_stage_many(self._buf, self._staged, xs)
+        self._staged = need
+        self._rag = []
+
     def _stage(self, x: Tensor) -> None:
         """Append x [t, C] to the staging buffer (behind the kept zero-copy blocks, which move into it first)."""
         if self._pending_dtype() not in (None, x.dtype):
             self.flush()  # one activation dtype per fold
+        self._gather()
         pend, self._segs = [y for y, _, _ in self._segs], []
         need = self._staged + sum(y.shape[0] for y in pend) + x.shape[0]
         cap = self.flush_tokens + x.shape[0]  # a fold is due by then
@@ -129,10 +159,14 @@ class GPTQ:
             self._staged += y.shape[0]
 
     def _pending_dtype(self):
-        return self._segs[0][0].dtype if self._segs else (self._buf.dtype if self._buf is not None else None)
+        if self._segs or self._rag:
+            return (self._segs or self._rag)[0][0].dtype
+        return self._buf.dtype if self._buf is not None and self._staged else None
 
     def _pending_device(self):
-        return self._segs[0][0].device if self._segs else (self._buf.device if self._buf is not None else None)
+        if self._segs or self._rag:
+            return (self._segs or self._rag)[0][0].device
+        return self._buf.device if self._buf is not None else None
 
     @torch.no_grad()
     def flush(self) -> None:
@@ -147,6 +181,7 @@ class GPTQ:
         """(H, X, beta, alpha) of the pending fold; X is [T, C] or the list of kept [L, C] blocks.  b samples at
         once are the telescoped form of b single updates of gptq.py:106-112."""
         n, b = self.num_samples, self._buf_b
+        self._gather()
         if self._segs:
             for x, v, _ in self._segs:
                 if x._version != v:
@@ -180,6 +215,7 @@ class GPTQ:
         self._fill = 0
         self._staged = 0
         self._segs = []
+        self._rag = []
         self._buf_b = 0
 
     def reset(self) -> None:
@@ -193,6 +229,7 @@ class GPTQ:
         self._fill = 0
         self._staged = 0
         self._segs = []
+        self._rag = []
         self._buf_b = 0
         self._reduced = False
         self.shared_H_with = None

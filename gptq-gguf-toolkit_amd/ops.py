@@ -126,6 +126,22 @@ def h_stage(buf: torch.Tensor, fill: int, x: torch.Tensor):
           "gq_h_stage")
 
 
+def h_stage_many(buf: torch.Tensor, fill: int, xs: Sequence[torch.Tensor]):
+    """buf[fill : fill + sum T_k] = cat(xs) in ONE launch (xs: [T_k, C] contiguous blocks of the buffer's dtype, 16-byte
+    aligned rows): the staging copies of a whole fold (gq_h_stage_many)."""
+    _need_cuda(buf, *xs)
+    row = buf.shape[1] * buf.element_size()
+    total = sum(x.shape[0] for x in xs)
+    assert buf.is_contiguous() and fill + total <= buf.shape[0] and row % 16 == 0
+    assert all(x.dtype == buf.dtype and x.dim() == 2 and x.shape[1] == buf.shape[1] and x.is_contiguous() for x in xs)
+    n = len(xs)
+    srcs = (ctypes.c_void_p * n)(*[x.data_ptr() for x in xs])
+    nb = (ctypes.c_int64 * n)(*[x.shape[0] * row for x in xs])
+    ws = _ws((2 * n + 1) * 8 + 512, buf.device)
+    check(lib().gq_h_stage_many(ctypes.c_void_p(buf.data_ptr() + fill * row), srcs, nb, n, _ptr(ws), ws.numel(), _stream(buf)),
+          "gq_h_stage_many")
+
+
 def h_prepare(H: torch.Tensor, W: torch.Tensor, rel_damp: float, want_flags: bool = False, obq_order: bool = False):
     """In-place dead-channel fix / masking / damping of (H, W); returns (U, not_invertible[int32 tensor])
     (+ col_flags uint8[2*C] if want_flags: the dead / zero-column sets U depends on).  obq_order: damping before

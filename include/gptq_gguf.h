@@ -152,6 +152,13 @@ int gq_h_accumulate_segments(int n, float* const* H_host, const void* const* con
    up to 64 Ki tokens and folds them into H with ONE gq_h_accumulate -- the telescoped form of the per-sample
    updates of gptq.py:106-112. */
 int gq_h_stage(void* dst, const void* src, int64_t nbytes, void* stream);
+/* The staging copies of a whole fold in one launch: n blocks (host arrays of device addresses and byte counts; every
+   block 16-byte aligned and a multiple of 16 bytes) are laid one behind the other at dst.  The handle of a Linear with
+   ragged inputs -- an MoE expert sees a data-dependent handful of tokens per calibration sample -- keeps references to the
+   hooks' tensors (as the zero-copy path does) and gathers them when the fold is due, instead of one latency-bound copy
+   per sample.  ws: (2 n + 1) * 8 + 512 bytes of device scratch. */
+int gq_h_stage_many(void* dst, const void* const* srcs_host, const int64_t* nbytes_host, int n, void* ws, size_t ws_bytes,
+                    void* stream);
 
 /* replaces gptq.py:134-135,141 (dead channels) + gptq.py:304-324 (_prepare) +
    linalg_utils.py:8-12: zero-column masking, damping, U = chol_upper(inv(H)).

@@ -29,6 +29,12 @@ def h_stage(buf, fill, x):
     buf[fill:fill + x.shape[0]].copy_(x)
 
 
+def h_stage_many(buf, fill, xs):
+    for x in xs:
+        buf[fill:fill + x.shape[0]] = x
+        fill += x.shape[0]
+
+
 def h_accumulate_grouped(Hs, Xs, betas, alphas, ws=None):
     calls["h_accumulate_grouped"] = calls.get("h_accumulate_grouped", 0) + 1
     for H, X, b, a in zip(Hs, Xs, betas, alphas):

@@ -451,14 +451,15 @@ def test_handle_zero_copy_and_staged_paths_agree(ops):
     a.flush()
     b.flush()
     assert torch.equal(a.H, b.H) and a.num_samples == b.num_samples == 5
-    # ragged tail: 3 kept blocks, then a 100-token sample -> everything moves into the staging buffer, in order
+    # ragged tail: 3 kept blocks, then a 100-token sample -> everything goes through the staging buffer, in order
     c, d = GPTQ(lin), GPTQ(lin)
     d._zero_copy = False
     tail = torch.randn(1, 100, 1024, device="cuda").half()
     for x in xs[:3] + [tail] + xs[3:]:
         c.update(x)
         d.update(x)
-    assert not c._segs and c._staged == 5 * 256 + 100
+    # (r04: kept by reference, in order, and gathered by ONE launch when the fold is due -- gq_h_stage_many)
+    assert not c._segs and len(c._rag) == 6 and c._staged == 0 and c._fill == 5 * 256 + 100 and d._staged == 5 * 256 + 100
     c.flush()
     d.flush()
     assert torch.equal(c.H, d.H)

@@ -278,8 +278,9 @@ def test_block_schedule_stacked_equals_unstacked_on_the_gpu(ops):
 
 
 def test_ragged_folds_are_padded_to_whole_ring_turns(ops):
-    """A handle fed ragged inputs (an MoE expert's data-dependent token counts) stages them and pads the fold with zero
-    rows to a multiple of 128 tokens: the fold then takes the kernel that reads X in place (no re-layout pass).  Zero
+    """A handle fed ragged inputs (an MoE expert's data-dependent token counts) keeps them by reference, gathers them into
+    its staging buffer with ONE launch when the fold is due (gq_h_stage_many) and pads the fold with zero rows to a
+    multiple of 128 tokens: the fold then takes the kernel that reads X in place (no re-layout pass).  Zero
     tokens add exact zeros: H equals the operand-image path on the unpadded rows bit for bit, and fp64 to tolerance."""
     import torch.nn as nn
     from gptq_gguf_toolkit_amd.gptq import GPTQ
@@ -290,8 +291,9 @@ def test_ragged_folds_are_padded_to_whole_ring_turns(ops):
     xs = [torch.randn(1, t, C, device="cuda").half() for t in (100, 37, 300, 1)]
     for x in xs:
         h.update(x)
-    assert h._staged == 438 and h._buf.shape[0] >= 438 + 74
+    assert len(h._rag) == 4 and h._staged == 0 and h._fill == 438   # kept by reference: one gather launch at the fold
     h.flush()
+    assert not h._rag and h._buf.shape[0] >= 438 + 74
     X = torch.cat([x[0] for x in xs])
     with ops.options(syrk_image=1):
         ref = torch.zeros(C, C, device="cuda")
