@@ -164,8 +164,12 @@ class BlockSchedule:
         self._fired = []
         if self._sharing is None:
             self._publish_sharing()
-        if any(h._fill >= h.flush_tokens for h in self.handles.values()):
-            self.flush()
+        # only the inputs that hold a fold's worth of tokens are folded: an MoE expert sees top_k / experts of the tokens and
+        # reaches 64 Ki four times later than the attention inputs of its block -- folding it along with them made its SYRK
+        # launches four times as many and a quarter as long (tile prologue / epilogue and the read-modify-write of H per flop)
+        due = [h for h in self.leaders() if h._fill >= h.flush_tokens]
+        if due:
+            self.flush(only=due)
 
     def _publish_sharing(self) -> None:
         """After the block's first sample: for every follower, "its weight's all-zero columns differ from its
@@ -251,13 +255,13 @@ class BlockSchedule:
             for h in grp:
                 h._flush_done()
 
-    def flush(self) -> None:
+    def flush(self, only: Optional[List[GPTQ]] = None) -> None:
         """Fold every leader's buffered activations into its Hessian: grouped SYRK launches (<= 8 problems per
         grid, one activation dtype per grid), the narrow inputs first and the widest input alone -- its tiles
         fill the chip for ~5 ms per 64 Ki tokens, nothing is gained by mixing it with the others.
         (Measured and removed, r02 / r04: postponing the narrow inputs' folds to quantize(), next to the widest chain --
         0.7-1 % per step for 6 GB of kept activations)"""
-        todo = [h for h in self.leaders() if h._fill > 0]
+        todo = [h for h in self.leaders() if h._fill > 0 and (only is None or any(h is o for o in only))]
         if not todo:
             return
         todo.sort(key=lambda h: (-h.d_col, id(h)))
