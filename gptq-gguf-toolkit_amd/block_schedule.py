@@ -408,7 +408,8 @@ class BlockSchedule:
                 # many chains per lane (a Mixtral block: eight 14336-wide w2 chains -- long strings of small dependent
                 # launches -- and eight stacked w1 / w3 chains -- short and GEMM-heavy): the upper half of the lanes walk
                 # their chains cheapest first, so that at any time half the lanes are in latency-bound chains and half in
-                # GEMM-bound ones instead of all in the same kind (measured, same box: 306.7 against 311.3 ms per block)
+                # GEMM-bound ones instead of all in the same kind (measured, same box: 306.7 against 311.3 ms per block; a lane of its own
+                # for the GEMM-heavy chains and three for the others: 318.7)
                 per = [[k for k in range(len(order)) if lane_of[k] == i] for i in range(len(streams))]
                 for i in range(len(streams) // 2, len(streams)):
                     per[i].reverse()
