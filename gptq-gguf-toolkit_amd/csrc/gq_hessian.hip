@@ -1380,7 +1380,7 @@ static int syrk16_launch(int kind, const int* idx, int m, float* const* H, const
             if (slots == 0) can_split = false;
             cap_units += slots;
         }
-        if (cap_units > 512) cap_units = 512;
+        if (cap_units > 512) cap_units = 512;  // (measured, r04: 1024 -- s = 5 instead of 3 for the three 4096-wide inputs of a dense block, 1.6 rounds instead of 1.667 -- is 1-2 % SLOWER: partial-sum traffic and a longer reduce)
         if (can_split) {
             double best = 1.0;
             for (int c = 2; c <= 8 && R * c <= cap_units; ++c) {
