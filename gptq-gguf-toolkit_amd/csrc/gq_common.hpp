@@ -66,6 +66,7 @@ extern thread_local char g_err[512];
     X(far_sync, 0)          /* 1: far updates on the caller's stream (no helper stream) */                              \
     X(far_async_max_rows, 8192) X(far_async_min_sb, 8) /* shape window of the helper-stream form */                     \
     X(far_wgs, 192)         /* resident workgroups of the helper's persistent far GEMM */                               \
+    X(far_bdma, 1)          /* 0: the far GEMM B operand through registers + ds_write instead of LDS-DMA */             \
     X(chain_generic, 0)     /* 1: the generic chained kernel instead of the dedicated far kernel */                     \
     X(gemm32_64_max, 256)   /* problems with fewer 128-tiles than this take 64x64 tiles (0: never) */                   \
     /* K4 */                                                                                                           \

@@ -352,11 +352,14 @@ typedef uint32_t g32_u32x4 __attribute__((ext_vector_type(4)));
 #define GQ_C_WAIT(N, s) \
     asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(fa0[s]), "+v"(fa1[s]), "+v"(fb0[s]), "+v"(fb1[s]) : "n"(N))
 
-template <int CHAIN>
+template <int CHAIN, bool BDMA>
 __device__ __forceinline__ void g32_chain_full_tile(float* Cmat, int64_t ldc, const float* A, int64_t lda, const float* B,
                                                     int64_t ldb, int64_t K, const int64_t m0, const int64_t n0) {
     extern __shared__ __attribute__((aligned(16))) float g32_smem[];
-    constexpr int TS = 128, NT = 512, NV = 2, STAGE = G32<TS>::STAGE_FLOATS, AF = G32<TS>::A_FLOATS, LDB = G32<TS>::LDB;
+    // BDMA: the B chunk ([32 k][128 n], 512-byte rows as they lie in memory) goes global -> LDS by global_load_lds (two 1 KiB
+    // pieces per wave and chunk, issued two chunks ahead), no VGPR round trip and no ds_write; A keeps the register-staged
+    // transposing commit.  Same fragments, same MFMA order: bit-identical.
+    constexpr int TS = 128, NT = 512, NV = 2, STAGE = G32<TS>::STAGE_FLOATS, AF = G32<TS>::A_FLOATS, LDB = BDMA ? TS : G32<TS>::LDB;
     constexpr int SPC = CHAIN / TK;  // chunks per chain
     static_assert(SPC == 4 && TK == 32, "the loop body is written for 4 chunks of 32 k per chain");
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -377,16 +380,29 @@ __device__ __forceinline__ void g32_chain_full_tile(float* Cmat, int64_t ldc, co
     auto fetch = [&](int64_t t, float4 (&a)[NV], float4 (&b)[NV]) {
         const int64_t k0 = ((t < nk) ? t : nk - 1) * TK;  // past the end: the last chunk again (never consumed)
         g32_load_rows_full<NV, NT>(a, A, lda, m0, k0, tid);
-        g32_load_kn_full<NV, NT>(b, B, ldb, n0, k0, tid);
+        if constexpr (!BDMA) g32_load_kn_full<NV, NT>(b, B, ldb, n0, k0, tid);
     };
     auto commit = [&](int buf, const float4 (&a)[NV], const float4 (&b)[NV]) {
         float* As = g32_smem + buf * STAGE;
         g32_store_rows<NV, NT>(a, As, LDA_S, tid);
-        g32_store_kn<NV, NT>(b, As + AF, tid);
+        if constexpr (!BDMA) g32_store_kn<NV, NT>(b, As + AF, tid);
     };
     // LDS byte addresses of this lane's fragments in image 0 (the dynamic LDS segment starts at address 0
     // of the workgroup's allocation: no static __shared__ in this kernel)
     const unsigned lds0 = (unsigned)(uintptr_t)g32_smem;
+    // BDMA: wave w brings k-rows 4 w .. 4 w + 3 of every B chunk: piece p = rows 4 w + 2 p (lanes 0-31) and + 1 (lanes 32-63)
+    const int wu = __builtin_amdgcn_readfirstlane(wid);
+    const unsigned vb0 = (unsigned)(((4 * wu + (lane >> 5)) * ldb + (lane & 31) * 4) * 4), vb1 = vb0 + (unsigned)(2 * ldb * 4);
+    const unsigned ldsb = lds0 + (unsigned)(AF * 4 + 4 * wu * 512);
+    auto dma_b = [&](int64_t t, int buf) {
+        if constexpr (BDMA) {
+            const int64_t k0 = ((t < nk) ? t : nk - 1) * TK;
+            const float* src = B + k0 * ldb + n0;
+            const unsigned d0 = ldsb + (unsigned)(buf * STAGE * 4);
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(vb0), "s"(src), "s"(d0) : "memory");
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(vb1), "s"(src), "s"(d0 + 1024u) : "memory");
+        }
+    };
     const unsigned aoff0 = lds0 + ((wm * 64 + li) * LDA_S + lk) * 4, aoff1 = aoff0 + 32 * LDA_S * 4;
     const unsigned boff = lds0 + (AF + lk * LDB + wn * 32 + li) * 4;
     f32x2 fa0[4], fa1[4];  // [set]: A tile 0 / 1, k-steps (4g, 4g+2)
@@ -399,10 +415,13 @@ __device__ __forceinline__ void g32_chain_full_tile(float* Cmat, int64_t ldc, co
         GQ_C_RD1(fb0[s], pb, (4 * (g)) * LDB * 4);      \
         GQ_C_RD1(fb1[s], pb, (4 * (g) + 2) * LDB * 4);  \
     } while (0)
+    dma_b(0, 0);
     fetch(0, va[0], vb[0]);
+    dma_b(1, 1);
     commit(0, va[0], vb[0]);
     fetch(1, va[1], vb[1]);
     fetch(2, va[0], vb[0]);
+    if constexpr (BDMA) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // B chunk 0 has landed (behind it: B 1, A 1, A 2)
     __syncthreads();
     unsigned ca0 = aoff0, ca1 = aoff1, cb = boff;  // fragment bases of the current image
     int buf = 0;
@@ -420,7 +439,12 @@ __device__ __forceinline__ void g32_chain_full_tile(float* Cmat, int64_t ldc, co
         const unsigned na0 = aoff0 + nbuf * STAGE * 4, na1 = aoff1 + nbuf * STAGE * 4, nb = boff + nbuf * STAGE * 4;
 #define GQ_C_GROUP(g)                                                                                        \
     do {                                                                                                     \
-        if ((g) == 6) __builtin_amdgcn_s_barrier(); /* image nbuf is complete: its writes were waited at g = 4 */ \
+        if ((g) == 0) dma_b(t + 2, (buf == 0) ? 2 : buf - 1); /* image (t + 2) % 3: everybody left it before barrier t - 1 */ \
+        if ((g) == 6) {                                                                                      \
+            /* B of chunk t + 1 (issued in chunk t - 1) has landed; behind it: A t+2, B t+2, A t+3 = 6 loads */  \
+            if constexpr (BDMA) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                              \
+            __builtin_amdgcn_s_barrier(); /* image nbuf is complete: its writes were waited at g = 4 */       \
+        }                                                                                                    \
         if ((g) == 3) {                                                                                      \
             GQ_C_WAIT(4, (g) & 3); /* before 6 more LDS operations: lgkmcnt counts to 15 */                  \
             asm volatile("" ::: "memory");                                                                   \
@@ -466,7 +490,7 @@ __device__ __forceinline__ void g32_chain_full_tile(float* Cmat, int64_t ldc, co
     chunk(F_{}, P1{});
     chunk(F_{}, P0{});
     chain_end();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the prefetched (unused) fragments of the image after the last
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the prefetched (unused) fragments / B pieces of the images after the last
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -474,24 +498,27 @@ __device__ __forceinline__ void g32_chain_full_tile(float* Cmat, int64_t ldc, co
 }
 #undef GQ_C_READS
 
-template <int CHAIN>
+template <int CHAIN, bool BDMA = false>
 __global__ __launch_bounds__(512, 2) void gemm32_chain_full_kernel(float* Cmat, int64_t ldc, const float* A, int64_t lda,
                                                                    const float* B, int64_t ldb, int64_t K) {
-    g32_chain_full_tile<CHAIN>(Cmat, ldc, A, lda, B, ldb, K, (int64_t)blockIdx.y * 128, (int64_t)blockIdx.x * 128);
+    g32_chain_full_tile<CHAIN, BDMA>(Cmat, ldc, A, lda, B, ldb, K, (int64_t)blockIdx.y * 128, (int64_t)blockIdx.x * 128);
 }
 // The same tiles walked by a FIXED number of workgroups (gridDim.x of them, tile t = blockIdx.x + i gridDim.x, column
 // tile fastest): the launch never holds more CUs than that, whatever its size -- the look-ahead far update of the
 // GPTQ column loop runs next to the loop's own kernels this way (gq_gptq.hip).  Same arithmetic per element.
-template <int CHAIN>
+template <int CHAIN, bool BDMA = false>
 __global__ __launch_bounds__(512, 2) void gemm32_chain_full_persistent_kernel(float* Cmat, int64_t ldc, const float* A,
                                                                               int64_t lda, const float* B, int64_t ldb,
                                                                               int64_t K, int64_t ntx, int64_t ntiles) {
     for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        g32_chain_full_tile<CHAIN>(Cmat, ldc, A, lda, B, ldb, K, (t / ntx) * 128, (t % ntx) * 128);
+        g32_chain_full_tile<CHAIN, BDMA>(Cmat, ldc, A, lda, B, ldb, K, (t / ntx) * 128, (t % ntx) * 128);
         __syncthreads();  // every wave is done with the LDS ring before the next tile's first image is written
     }
 }
 
+// r04, default (option far_bdma): the B chunk by LDS-DMA, A through registers -- the hybrid of the two forms: far alone 0.752 ->
+// 0.761 of the fp32 peak, the 4096 x 14336 column loop 11.8 -> 11.5 ms, the far launches inside a step 0.416 -> 0.44 (sum of
+// durations), bit-identical (test_trailing_update_kernel_choices_are_bit_identical).
 // (Measured and removed, r03/r04: two LDS-DMA forms of the far update -- a four-slot ring with one workgroup per CU,
 // 6 % slower than the register-staged chunks above although it issues a tenth of the staging instructions, and a
 // two-slot ring with two workgroups per CU, +1.6 % -- DESIGN.md K6; they live in the git history.)
@@ -507,12 +534,28 @@ inline int launch_gemm32_chain_full(float* Cmat, int64_t ldc, const float* A, in
         attr_set = true;
     }
     const int64_t ntx = N / 128, ntiles = ntx * (M / 128);
+    // option far_bdma: the B operand by LDS-DMA (16-byte aligned rows: ldb % 4 == 0 and a 16-byte aligned B)
+    const bool bdma = opt(OPT_far_bdma) != 0 && ldb % 4 == 0 && (reinterpret_cast<uintptr_t>(B) % 16 == 0) && 31 * ldb * 4 < (int64_t)1 << 31;
+    if (bdma) {
+        static std::atomic<bool> attr_b{false};
+        if (!attr_b) {
+            GQ_HIP(hipFuncSetAttribute((const void*)gemm32_chain_full_kernel<CHAIN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+            GQ_HIP(hipFuncSetAttribute((const void*)gemm32_chain_full_persistent_kernel<CHAIN, true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+            attr_b = true;
+        }
+    }
     if (max_wgs > 0 && ntiles > max_wgs) {
-        hipLaunchKernelGGL((gemm32_chain_full_persistent_kernel<CHAIN>), dim3((unsigned)max_wgs), dim3(512), LDS, st, Cmat, ldc,
-                           A, lda, B, ldb, K, ntx, ntiles);
+        if (bdma)
+            hipLaunchKernelGGL((gemm32_chain_full_persistent_kernel<CHAIN, true>), dim3((unsigned)max_wgs), dim3(512), LDS, st, Cmat,
+                               ldc, A, lda, B, ldb, K, ntx, ntiles);
+        else
+            hipLaunchKernelGGL((gemm32_chain_full_persistent_kernel<CHAIN>), dim3((unsigned)max_wgs), dim3(512), LDS, st, Cmat, ldc,
+                               A, lda, B, ldb, K, ntx, ntiles);
     } else {
         dim3 grid((unsigned)ntx, (unsigned)(M / 128)), block(512);
-        hipLaunchKernelGGL((gemm32_chain_full_kernel<CHAIN>), grid, block, LDS, st, Cmat, ldc, A, lda, B, ldb, K);
+        if (bdma) hipLaunchKernelGGL((gemm32_chain_full_kernel<CHAIN, true>), grid, block, LDS, st, Cmat, ldc, A, lda, B, ldb, K);
+        else hipLaunchKernelGGL((gemm32_chain_full_kernel<CHAIN>), grid, block, LDS, st, Cmat, ldc, A, lda, B, ldb, K);
     }
     GQ_LAUNCH_CHECK();
     return GQ_OK;
