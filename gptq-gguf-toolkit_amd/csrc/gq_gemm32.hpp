@@ -352,10 +352,25 @@ typedef uint32_t g32_u32x4 __attribute__((ext_vector_type(4)));
 #define GQ_C_WAIT(N, s) \
     asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(fa0[s]), "+v"(fa1[s]), "+v"(fb0[s]), "+v"(fb1[s]) : "n"(N))
 
-template <int CHAIN, bool BDMA>
+// CG: the group behind which a chunk's commit + fetch block stands.  Cycle stamps (profiles/r04_far_stamps.txt): the two waves of
+// a SIMD do not alternate -- the older one wins the matrix pipe, runs ~3 groups ahead and parks ~770 cycles per chunk at the
+// barrier (behind group 5) until its partner arrives; a commit block behind group 3 puts the PARTNER's stores and loads -- no
+// MFMAs -- exactly into that window.  Behind group 1: far alone 0.762 -> 0.775 of the fp32 peak in the bench (r03: group 3).
+// STAMP (profiles/micro/far_stamps.hip only; the library never instantiates it): every wave of the workgroup accumulates
+// the shader-clock cycles it spends (a) between arriving at the chunk's vmcnt + barrier and leaving it, (b) in the chunk's
+// commit + fetch block, and writes {loop cycles, barrier cycles, commit cycles, chunks} to stamps[4 wave ..].
+template <int CHAIN, bool BDMA, bool STAMP = false, int CG = 1>
 __device__ __forceinline__ void g32_chain_full_tile(float* Cmat, int64_t ldc, const float* A, int64_t lda, const float* B,
-                                                    int64_t ldb, int64_t K, const int64_t m0, const int64_t n0) {
+                                                    int64_t ldb, int64_t K, const int64_t m0, const int64_t n0,
+                                                    unsigned long long* stamps = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float g32_smem[];
+    // a stamp drains the LDS counter (SMEM returns out of order with LDS: the counted waits below must never see one in flight)
+    auto now = [&]() -> unsigned long long {
+        unsigned long long t_;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");
+        return t_;
+    };
+    unsigned long long st_bar = 0, st_commit = 0, st_t0 = 0, st_a = 0;
     // BDMA: the B chunk ([32 k][128 n], 512-byte rows as they lie in memory) goes global -> LDS by global_load_lds (two 1 KiB
     // pieces per wave and chunk, issued two chunks ahead), no VGPR round trip and no ds_write; A keeps the register-staged
     // transposing commit.  Same fragments, same MFMA order: bit-identical.
@@ -441,16 +456,20 @@ __device__ __forceinline__ void g32_chain_full_tile(float* Cmat, int64_t ldc, co
     do {                                                                                                     \
         if ((g) == 0) dma_b(t + 2, (buf == 0) ? 2 : buf - 1); /* image (t + 2) % 3: everybody left it before barrier t - 1 */ \
         if ((g) == 6) {                                                                                      \
+            if constexpr (STAMP) st_a = now();                                                               \
             /* B of chunk t + 1 (issued in chunk t - 1) has landed; behind it: A t+2, B t+2, A t+3 = 6 loads */  \
             if constexpr (BDMA) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                              \
             __builtin_amdgcn_s_barrier(); /* image nbuf is complete: its writes were waited at g = 4 */       \
+            if constexpr (STAMP) st_bar += now() - st_a;                                                     \
         }                                                                                                    \
-        if ((g) == 3) {                                                                                      \
+        if ((g) == CG) {                                                                                     \
+            if constexpr (STAMP) st_a = now();                                                               \
             GQ_C_WAIT(4, (g) & 3); /* before 6 more LDS operations: lgkmcnt counts to 15 */                  \
             asm volatile("" ::: "memory");                                                                   \
             commit(nbuf, va[PAR], vb[PAR]);                                                                  \
             fetch(t + 3, va[PAR], vb[PAR]);                                                                  \
             asm volatile("" ::: "memory");                                                                   \
+            if constexpr (STAMP) st_commit += now() - st_a;                                                  \
         }                                                                                                    \
         if ((g) < 6) GQ_C_READS((g) + 2, ((g) + 2) & 3, ca0, ca1, cb);                                       \
         else GQ_C_READS((g) - 6, ((g) + 2) & 3, na0, na1, nb);                                               \
@@ -478,6 +497,7 @@ __device__ __forceinline__ void g32_chain_full_tile(float* Cmat, int64_t ldc, co
     using P0 = std::integral_constant<int, 0>;
     using P1 = std::integral_constant<int, 1>;
     const int64_t nchain = nk / SPC;
+    if constexpr (STAMP) st_t0 = now();
     chunk(T_{}, P1{});  // chunk 0 (even): the next one is odd
     chunk(F_{}, P0{});
     for (int64_t c = 1; c < nchain; ++c) {
@@ -490,6 +510,13 @@ __device__ __forceinline__ void g32_chain_full_tile(float* Cmat, int64_t ldc, co
     chunk(F_{}, P1{});
     chunk(F_{}, P0{});
     chain_end();
+    if constexpr (STAMP) {
+        const unsigned long long t1 = now();
+        if (stamps && lane == 0) {
+            stamps[4 * wid + 0] = t1 - st_t0; stamps[4 * wid + 1] = st_bar; stamps[4 * wid + 2] = st_commit;
+            stamps[4 * wid + 3] = (unsigned long long)nk;
+        }
+    }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the prefetched (unused) fragments / B pieces of the images after the last
 #pragma unroll
     for (int i = 0; i < 2; ++i)
