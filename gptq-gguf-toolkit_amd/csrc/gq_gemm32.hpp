@@ -561,6 +561,8 @@ inline int launch_gemm32_chain_full(float* Cmat, int64_t ldc, const float* A, in
         attr_set = true;
     }
     const int64_t ntx = N / 128, ntiles = ntx * (M / 128);
+    // (measured and removed, r04: EVERY far GEMM as a persistent launch of 256 workgroups -- no workgroup dispatch between tiles --:
+    // far alone 0.766-0.770 against 0.760-0.767, the step 91.2-91.8 against 90.0-90.8 ms, the Mixtral block 317 against 314 ms)
     // option far_bdma: the B operand by LDS-DMA (16-byte aligned rows: ldb % 4 == 0 and a 16-byte aligned B)
     const bool bdma = opt(OPT_far_bdma) != 0 && ldb % 4 == 0 && (reinterpret_cast<uintptr_t>(B) % 16 == 0) && 31 * ldb * 4 < (int64_t)1 << 31;
     if (bdma) {
