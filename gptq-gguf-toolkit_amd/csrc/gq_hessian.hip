@@ -880,6 +880,9 @@ __global__ __launch_bounds__(512, 2) void syrk16_256n_kernel(const SyrkGroup grp
 // The order of a step's 32 fragment reads and 8 DMA pieces, as a table the waits are derived from.  Read codes:
 // 0..15 = A fragment code >> 1, half code & 1 (fragment 7: of THIS step's ring slot, the others: of the next one);
 // 16..31 = B fragment (code - 16) >> 1 of the next ring slot.
+// (Tried and removed, r04: on DIAGONAL tiles the lower-left wave idle -- its quadrant is the transpose of the upper-right one, a
+// quarter of those tiles' MFMA energy, ~1 % of a launch -- as a second, MFMA-free loop for that wave: the extra path pushed the
+// register allocation over the edge, scratch reloads inside the hand-counted loop, half the speed.)
 // (Measured on this table and removed, profiles/r04_syrk_w4_ab.txt: the whole B set read in rows 0-3, a step without its
 // barrier, a step that never waits for its DMA -- all within 1 % of this order: no wait left that matters, as in the
 // eight-wave kernel.)
