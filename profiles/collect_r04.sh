@@ -26,7 +26,9 @@ with open("$OUT/r04_syrk_fetch_dispatches.csv", "w") as f:
 if rows:
     per = sum(v for _, _, v in rows) * 2048 / 1e9 / len(rows)
     T, n4, n14 = 65536, 3, 1
-    alg = (4 * (n4 * (T * 4096 * 2 + 2 * 4096 * 4096 * 4)) + 4 * (T * 14336 * 2 + 2 * 14336 * 14336 * 4)) / 8 / 1e9
+    # algorithmic bytes of a step's four folds (X once, H read + written), over the launches a step makes (r04: one grid per fold)
+    lps = len(rows) / 4  # the pass runs 4 steps (1 warm-up + 2 timed + the latency step)
+    alg = (4 * (n4 * (T * 4096 * 2 + 2 * 4096 * 4096 * 4)) + 4 * (T * 14336 * 2 + 2 * 14336 * 14336 * 4)) / lps / 1e9
     h = hashlib.sha256()
     for fn in sorted(glob.glob("$R/gptq-gguf-toolkit_amd/csrc/*.h*")):
         h.update(open(fn, "rb").read())
