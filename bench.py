@@ -34,7 +34,11 @@ The same JSON line carries, measured AFTER the timed region:
 Other workloads (`--workload`): tinyllama-block-q4k, llama3-8b-block-mixed (configs[2]), llama3-70b-block-q4k
 (configs[3] shapes), mixtral-block (configs[4] shapes), llama3-8b-model-q4k (a step = the whole model).
 
-Prints ONE JSON line on rank 0 (see the driver contract).
+`python bench.py --gpus N` with N > 1 and no launcher re-executes itself under torch.distributed.run (one rank per GPU,
+RCCL); under a launcher it reads RANK / LOCAL_RANK / WORLD_SIZE.  A rank count other than --gpus is fatal.
+
+Rank 0 prints the full result dict on one line and then, LAST, the compact headline line (<= 2 KB: the driver contract's
+keys with `roofline` and `cpu_baseline` flattened to scalars).
 """
 import argparse
 import json
@@ -648,6 +652,99 @@ def whole_model_run(wl, dev, world, rank, save_root=None, nseq=None, L=None, lay
 
 
 # ----------------------------------------------------------------------------- main
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) without a launcher: re-exec under torch.distributed.run with one rank per GPU,
+    the way the reference's run_quant.sh:15 starts its own ranks (torchrun --nnodes=1 --nproc-per-node=$NUM_GPUS) and
+    quant.py:149-155 joins them.  nccl (= RCCL) needs N visible GPUs; fewer is refused unless --backend gloo was asked for."""
+    import socket
+    n_dev = torch.cuda.device_count()
+    if args.backend != "gloo" and n_dev < args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but {n_dev} GPU(s) visible: RCCL needs one GPU per rank "
+                 f"(pass --backend gloo to run {args.gpus} ranks that share the visible GPUs: a code-path check, not a measurement)")
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    argv = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execvpe(sys.executable, argv, env)
+
+
+def _get(d, *path):
+    for k in path:
+        if not isinstance(d, dict) or k not in d:
+            return None
+        d = d[k]
+    return d
+
+
+def compact_line(line):
+    """The headline as ONE short JSON line (<= 2 KB, scalars only inside `roofline` / `cpu_baseline` / `config`): the
+    last line of stdout.  Everything else the run measured is on the line before it and in
+    gpurun_out/bench_detail_<workload>_n<N>.json."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "step_latency_ms", "ranks_seen", "collective_backend")
+    out = {k: line.get(k) for k in keep if k in line}
+    cfg = line.get("config", {})
+    out["config"] = {"workload": str(cfg.get("workload", ""))[:118], "parallelism": cfg.get("parallelism"),
+                     "calib_seqs_per_rank": cfg.get("calib_seqs_per_rank")}
+    r = dict(line.get("roofline") or {})
+    t = r.pop("traffic", None)
+    if isinstance(r.get("kernel"), str):
+        r["kernel"] = r["kernel"][:118]
+    if isinstance(t, dict) and t.get("GB_per_launch"):
+        # HBM-side bytes per launch from the separate --pmc pass (profiles/r05_syrk_traffic.json), GB
+        r["traffic"] = t["GB_per_launch"]
+        r["traffic_unit"] = "GB/launch, L2-miss reads (--pmc pass)"
+        if t.get("algorithmic_GB_per_launch"):
+            r["traffic_algorithmic"] = t["algorithmic_GB_per_launch"]
+            r["traffic_ratio"] = round(t["GB_per_launch"] / t["algorithmic_GB_per_launch"], 2)
+    else:
+        r["traffic"] = None
+    tu = line.get("trailing_update") or {}
+    for k_out, path in (("trailing_far_alone_frac", ("far_alone", "frac")), ("trailing_whole_alone_frac", ("whole_alone", "frac")),
+                        ("trailing_far_in_region_frac", ("far_in_region", "frac")),
+                        ("trailing_far_in_region_frac_over_busy_time", ("far_in_region", "frac_over_busy_time")),
+                        ("trailing_loop_ms_as_run", ("loop_ms", "as_run"))):
+        r[k_out] = _get(tu, *path)
+    r["trailing_peak_TFLOPs_f32"] = PEAK_F32_MFMA_TFLOPS
+    r["column_loop_ns_per_step"] = _get(line, "column_loop", "ns_per_step")
+    r["encoders_frac_of_hbm"] = _get(line, "encoders", "frac")
+    out["roofline"] = r
+    c = dict(line.get("cpu_baseline") or {})
+    if c:
+        st = c.pop("stages_s_per_block", None) or {}
+        so = c.pop("step_only", None) or {}
+        c["sample"] = str(c.get("sample", ""))[:90]
+        c.update({f"stage_{k}": v for k, v in st.items()})
+        c["step_only_value"] = so.get("value")
+        out["cpu_baseline"] = c
+    for key in ("whole_model", "whole_model_hf_eager", "whole_model_batch4"):
+        out[f"{key}_wall_s"] = _get(line, key, "wall_s_quantizer_region")
+    out["collectives_per_step"] = line.get("collectives_per_step")
+    out["allreduce_probe_ms"] = _get(line, "allreduce_probe", "ms")
+    out["tolerance_ints_differ"] = _get(line, "tolerance_parity", "ints_differ")
+    out["tolerance_noise_floor"] = _get(line, "tolerance_parity", "ulp_noise_floor", "ints_differ")
+    out["detail"] = "previous stdout line"
+    return out
+
+
+def emit(line, args, world):
+    """Two stdout lines on rank 0: the full dict (everything measured), then the compact headline LAST."""
+    full = json.dumps(line)
+    print(full)
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", f"bench_detail_{args.workload}_n{world}.json"), "w") as f:
+            f.write(full + "\n")
+    except OSError:
+        pass
+    print(json.dumps(compact_line(line)))
+    sys.stdout.flush()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -664,11 +761,14 @@ def main():
     ap.add_argument("--no-whole-model", action="store_true", help="skip the whole-model leg of the block workloads")
     ap.add_argument("--no-side-legs", action="store_true", help="skip trailing_update / tolerance_parity legs")
     ap.add_argument("--breakdown", action="store_true", help="one extra profiled step: per-kernel ms to stderr")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+    ap.add_argument("--backend", default=None, choices=["nccl", "gloo"],
                     help="torch.distributed backend: nccl (= RCCL over xGMI, default); gloo only to exercise the "
-                         "N>1 code path with several ranks sharing one GPU")
+                         "N>1 code path with several ranks sharing one GPU (must be asked for explicitly)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)  # does not return: `python bench.py --gpus N` starts its N ranks itself (run_quant.sh:15)
+    args.backend = args.backend or "nccl"
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -687,7 +787,11 @@ def main():
         dist.all_reduce(one)  # proves the collective backend is alive: every rank contributed
         ranks_seen = int(one.item())
         assert ranks_seen == dist.get_world_size() == world
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # a rank mismatch is fatal: a line that says n_gpus = 1 under --gpus 8 is not a measurement of 8 GPUs
+    assert ranks_seen == world == args.gpus, f"--gpus {args.gpus} but {ranks_seen} rank(s) answered (WORLD_SIZE={world})"
+    if world > 1 and args.backend == "nccl":
+        assert torch.cuda.device_count() >= world, (f"--backend nccl needs one GPU per rank: {torch.cuda.device_count()} "
+                                                    f"visible, {world} ranks")
     wl = WORKLOADS[args.workload]
     nseq, L = args.calib_seqs or wl["nseq"], args.seq_len or wl["L"]
 
@@ -704,14 +808,14 @@ def main():
         dt = sum(r["wall_s_quantizer_region"] for r in timed)
         if rank == 0:
             params = timed[-1]["params_quantized_M"] * 1e6
-            print(json.dumps({
+            emit({
                 "metric": "Mparams/s GPTQ-quantized", "value": round(params * args.steps / dt / 1e6, 2),
                 "unit": "Mparams/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(dt / args.steps * 1e3, 1), "higher_is_better": True, "scaling": "strong",
                 "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": f"{args.workload}: Quantizer.quantize of the whole model, {nseq}x{L}-token "
                                        f"calibration", "parallelism": f"calib-dp{world}+matrix-fanout"},
-                "ranks_seen": ranks_seen, "whole_model": timed[-1]}))
+                "ranks_seen": ranks_seen, "whole_model": timed[-1]}, args, world)
         if world > 1:
             dist.destroy_process_group()
         return
@@ -874,7 +978,7 @@ def main():
         if rank == 0:
             line.update(wm)
     if rank == 0:
-        print(json.dumps(line))
+        emit(line, args, world)
     if world > 1:
         dist.destroy_process_group()
 

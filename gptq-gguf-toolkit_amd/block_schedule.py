@@ -109,6 +109,7 @@ class BlockSchedule:
         self._seen: Dict[Any, Any] = {}  # per block call: input identity -> (leader handle, tensor kept alive)
         self._fired: List[str] = []      # pre_hook(): the handles fed in the current sample, in order
         self._last_fired: Optional[str] = None
+        self._other_after = False        # an UN-hooked Linear of the block ran after the last hooked one (other_pre_hook)
         self._n_samples = 0
         self.n_streams = int(os.environ.get("GQ_CHAIN_STREAMS", 4)) if n_streams is None else n_streams
         self.stack = os.environ.get("GQ_STACK", "1") != "0"  # Linears that share U walk the columns together
@@ -128,14 +129,29 @@ class BlockSchedule:
         and for a Llama block the last Linear is down_proj, 27 % of the layer's GEMM flops (+ the residual add).  Which
         Linear is last is LEARNED: the block's first sample runs to its end; if every handle fired exactly once there, the
         later samples raise ForwardInterrupt right after feeding the Linear that fired last -- provided every other handle
-        has fired in that sample too (MoE experts fire data-dependently: then the forward just continues)."""
+        has fired in that sample too (MoE experts fire data-dependently: then the forward just continues) AND no Linear
+        outside the hooked set ran after it in that first sample (other_pre_hook: with a --quantizable_modules regex that
+        leaves out the block's structurally last Linear, forward #1 runs in full, as in the reference).
+        What a caller can see of the interrupt: modules after the last Linear (for a Llama block: the residual add) do not
+        run in forward #1, whose output the reference discards; Quantizer additionally skips forward #2 of the LAST block, so
+        the data_loader's tensors hold the input of the last block instead of its output afterwards (nothing in the reference
+        reads them: quantizer.py:181-198 quantizes the post-block modules from their weights).  `--full_forward1` runs both."""
         def _hook(_, inp):
             self.feed(name, inp[0])
             self._fired.append(name)
+            self._other_after = False
             if interrupt and name == self._last_fired and len(self._fired) == len(self.handles) \
                     and len(set(self._fired)) == len(self._fired):
                 self.stats["forward1_interrupts"] = self.stats.get("forward1_interrupts", 0) + 1
                 raise ForwardInterrupt
+        return _hook
+
+    def other_pre_hook(self):
+        """Forward pre-hook for the block's Linears that are NOT quantized (not matched by --quantizable_modules): the first
+        sample records whether one of them runs after the last hooked Linear; if so forward #1 is never interrupted."""
+        def _hook(_, inp):
+            if self._n_samples == 0:
+                self._other_after = True
         return _hook
 
     def feed(self, name: str, x: torch.Tensor) -> None:
@@ -158,7 +174,8 @@ class BlockSchedule:
     def sample_done(self) -> None:
         """Called after every calibration sample (one forward of the block)."""
         self._seen.clear()
-        if self._n_samples == 0 and len(self._fired) == len(self.handles) and len(set(self._fired)) == len(self._fired):
+        if self._n_samples == 0 and len(self._fired) == len(self.handles) and len(set(self._fired)) == len(self._fired) \
+                and not self._other_after:
             self._last_fired = self._fired[-1]  # every Linear fired once: later samples may stop there (pre_hook)
         self._n_samples += 1
         self._fired = []

@@ -53,24 +53,39 @@ int fwd_silu_mul(const void*, const void*, void*, int64_t, int, hipStream_t);
 #include <vector>
 
 #include <atomic>
+#include <cerrno>
 #include <cstdlib>
 #include <cstring>
 
 namespace gq {
 // ---- the option table (gq_common.hpp GQ_OPTION_LIST) ----
 namespace {
-struct OptEntry { const char* name; int64_t def; };
+struct OptEntry { const char* name; int64_t def, lo, hi; };
 const OptEntry g_opt_table[OPT_COUNT] = {
-#define GQ_X(name, def) {#name, (int64_t)(def)},
+#define GQ_X(name, def, lo, hi) {#name, (int64_t)(def), (int64_t)(lo), (int64_t)(hi)},
     GQ_OPTION_LIST(GQ_X)
 #undef GQ_X
 };
 std::atomic<int64_t> g_opt[OPT_COUNT];
 std::once_flag g_opt_once;
+char g_opt_init_err[256];  // why GQ_OPTIONS did not parse ("" = fine); reported by every entry point through options_ok()
 int opt_index(const char* name) {
     for (int i = 0; i < OPT_COUNT; ++i)
         if (!strcmp(g_opt_table[i].name, name)) return i;
     return -1;
+}
+// nullptr when `v` is acceptable for option i, else the reason
+const char* opt_range_error(int i, int64_t v, char* buf, size_t n) {
+    const OptEntry& e = g_opt_table[i];
+    if (v < e.lo || v > e.hi) {
+        snprintf(buf, n, "option '%s' = %lld is outside %lld..%lld", e.name, (long long)v, (long long)e.lo, (long long)e.hi);
+        return buf;
+    }
+    if (i == OPT_la && (v & 1)) {
+        snprintf(buf, n, "option 'la' = %lld must be even", (long long)v);
+        return buf;
+    }
+    return nullptr;
 }
 void opt_init() {
     for (int i = 0; i < OPT_COUNT; ++i) g_opt[i].store(g_opt_table[i].def, std::memory_order_relaxed);
@@ -87,17 +102,41 @@ void opt_init() {
         if (item.empty()) continue;
         const std::string key = eq == std::string::npos ? item : item.substr(0, eq);
         const int i = opt_index(key.c_str());
+        // a typo must not silently measure the default: the first error is kept and EVERY entry point fails with it
+        // (GQ_E_UNSUPPORTED + gq_last_error -> a Python exception with a traceback; no abort() inside a host process)
         if (i < 0) {
-            fprintf(stderr, "gq: GQ_OPTIONS names an unknown option '%s'\n", key.c_str());
-            abort();  // a typo must not silently measure the default
+            if (!g_opt_init_err[0]) snprintf(g_opt_init_err, sizeof(g_opt_init_err), "GQ_OPTIONS names an unknown option '%s'", key.c_str());
+            continue;
         }
-        g_opt[i].store(eq == std::string::npos ? 1 : strtoll(item.c_str() + eq + 1, nullptr, 0), std::memory_order_relaxed);
+        int64_t v = 1;
+        if (eq != std::string::npos) {
+            const char* txt = item.c_str() + eq + 1;
+            char* endp = nullptr;
+            errno = 0;
+            v = strtoll(txt, &endp, 0);
+            if (endp == txt || *endp != '\0' || errno == ERANGE) {
+                if (!g_opt_init_err[0])
+                    snprintf(g_opt_init_err, sizeof(g_opt_init_err), "GQ_OPTIONS: '%s' is not an integer value for option '%s'", txt, key.c_str());
+                continue;
+            }
+        }
+        char why[200];
+        if (opt_range_error(i, v, why, sizeof(why))) {
+            if (!g_opt_init_err[0]) snprintf(g_opt_init_err, sizeof(g_opt_init_err), "GQ_OPTIONS: %s", why);
+            continue;
+        }
+        g_opt[i].store(v, std::memory_order_relaxed);
     }
 }
 }  // namespace
 int64_t opt(Opt o) {
     std::call_once(g_opt_once, opt_init);
     return g_opt[o].load(std::memory_order_relaxed);
+}
+int options_ok() {
+    std::call_once(g_opt_once, opt_init);
+    if (g_opt_init_err[0]) GQ_FAIL(GQ_E_UNSUPPORTED, "%s", g_opt_init_err);
+    return GQ_OK;
 }
 
 unsigned g_prof_mask = 0;
@@ -128,6 +167,11 @@ void prof_end(int tag, hipStream_t st) {
 
 using namespace gq;
 
+#define GQ_OPTIONS_OK()                               \
+    do {                                              \
+        if (int _rc = options_ok()) return _rc;       \
+    } while (0)
+
 extern "C" {
 
 int gq_abi_version(void) { return GQ_ABI_VERSION; }
@@ -137,6 +181,7 @@ const char* gq_option_name(int i) { return (i >= 0 && i < OPT_COUNT) ? g_opt_tab
 int gq_option_get(const char* name, int64_t* value) {
     const int i = name ? opt_index(name) : -1;
     if (i < 0 || !value) GQ_FAIL(GQ_E_UNSUPPORTED, "gq_option_get: unknown option '%s'", name ? name : "(null)");
+    GQ_OPTIONS_OK();
     *value = opt((Opt)i);
     return GQ_OK;
 }
@@ -144,6 +189,8 @@ int gq_option_set(const char* name, int64_t value, int64_t* previous) {
     const int i = name ? opt_index(name) : -1;
     if (i < 0) GQ_FAIL(GQ_E_UNSUPPORTED, "gq_option_set: unknown option '%s'", name ? name : "(null)");
     const int64_t old = opt((Opt)i);  // (also runs the one-time initialisation)
+    char why[200];
+    if (opt_range_error(i, value, why, sizeof(why))) GQ_FAIL(GQ_E_UNSUPPORTED, "gq_option_set: %s", why);
     g_opt[i].store(value, std::memory_order_relaxed);
     if (previous) *previous = old;
     return GQ_OK;
@@ -177,12 +224,14 @@ size_t gq_workspace_bytes(int op, int64_t R, int64_t C, int64_t T, int block_siz
 
 int gq_h_accumulate(float* H, const void* X, int x_dtype, int64_t T, int64_t C, float beta, float alpha, void* ws,
                     size_t ws_bytes, void* stream) {
+    GQ_OPTIONS_OK();
     return h_accumulate(H, X, x_dtype, T, C, beta, alpha, ws, ws_bytes, (hipStream_t)stream);
 }
 
 int gq_h_accumulate_grouped(int n, float* const* H_host, const void* const* X_host, const int64_t* T_host,
                             const int64_t* C_host, const float* beta_host, const float* alpha_host, int x_dtype,
                             void* ws, size_t ws_bytes, void* stream) {
+    GQ_OPTIONS_OK();
     return h_accumulate_grouped(n, H_host, X_host, T_host, C_host, beta_host, alpha_host, x_dtype, ws, ws_bytes,
                                 (hipStream_t)stream, nullptr, nullptr);
 }
@@ -190,6 +239,7 @@ int gq_h_accumulate_grouped(int n, float* const* H_host, const void* const* X_ho
 int gq_h_accumulate_segments(int n, float* const* H_host, const void* const* const* blocks_host, const int64_t* nblocks_host,
                              const int64_t* block_tokens_host, const int64_t* C_host, const float* beta_host,
                              const float* alpha_host, int x_dtype, void* ws, size_t ws_bytes, void* stream) {
+    GQ_OPTIONS_OK();
     if (n <= 0 || n > 8) GQ_FAIL(GQ_E_BAD_SHAPE, "gq_h_accumulate_segments: n=%d not in 1..8", n);
     if (!blocks_host || !nblocks_host || !block_tokens_host) GQ_FAIL(GQ_E_NULL, "gq_h_accumulate_segments: null pointer");
     const void* X[8];
@@ -206,6 +256,7 @@ int gq_h_accumulate_segments(int n, float* const* H_host, const void* const* con
 
 int gq_h_prepare(float* H, float* W, int64_t R, int64_t C, float rel_damp, float* U, int* not_invertible,
                  uint8_t* col_flags_out, void* ws, size_t ws_bytes, void* stream) {
+    GQ_OPTIONS_OK();
     return h_prepare(H, W, R, C, rel_damp, U, not_invertible, col_flags_out, ws, ws_bytes, (hipStream_t)stream, false);
 }
 
@@ -214,11 +265,13 @@ int gq_far_helper_enable(int on) { return far_helper_enable(on); }
 
 int gq_obq_h_prepare(float* H, float* W, int64_t R, int64_t C, float rel_damp, float* U, int* not_invertible,
                      uint8_t* col_flags_out, void* ws, size_t ws_bytes, void* stream) {
+    GQ_OPTIONS_OK();
     return h_prepare(H, W, R, C, rel_damp, U, not_invertible, col_flags_out, ws, ws_bytes, (hipStream_t)stream, true);
 }
 
 int gq_obq_quantize(float* W, const float* U, int64_t R, int64_t C, int bits, int group_size, int sym, int block_size,
                     uint8_t* qweight, float* scale, float* zero, void* ws, size_t ws_bytes, void* stream) {
+    GQ_OPTIONS_OK();
     return obq_quantize(W, U, R, C, bits, group_size, sym, block_size, qweight, scale, zero, ws, ws_bytes,
                         (hipStream_t)stream);
 }
@@ -238,6 +291,7 @@ int gq_h_unpack_upper(const float* buf, int64_t C, float* H, void* stream) { ret
 int gq_scale_search(const float* x, int64_t rows, int64_t ld, int q_type, const gq_search_t* p, uint16_t* d,
                     int64_t d_stride, uint8_t* s, int64_t s_ld, uint16_t* dmin, int64_t dmin_stride, uint8_t* m,
                     int64_t m_ld, void* stream) {
+    GQ_OPTIONS_OK();
     if (!x || !d || !s || !dmin || !m) GQ_FAIL(GQ_E_NULL, "gq_scale_search: null pointer");
     return launch_scale_search(x, rows, ld, q_type, p, d, d_stride, s, s_ld, dmin, dmin_stride, m, m_ld,
                                (hipStream_t)stream);
@@ -246,12 +300,14 @@ int gq_scale_search(const float* x, int64_t rows, int64_t ld, int q_type, const 
 int gq_group_search(const void* x, int x_dtype, int64_t rows, int64_t ld, int q_type, const gq_search_t* p,
                     float* group_scale, float* group_zero, uint16_t* d, uint8_t* s, uint16_t* dmin, uint8_t* m,
                     void* stream) {
+    GQ_OPTIONS_OK();
     return group_search(x, x_dtype, rows, ld, q_type, p, group_scale, group_zero, d, s, dmin, m, (hipStream_t)stream);
 }
 
 int gq_gptq_quantize(float* W, const float* U, int64_t R, int64_t C, int q_type, int block_size, int static_groups,
                      const gq_search_t* p, uint8_t* qweight, uint16_t* d, uint8_t* s, uint16_t* dmin, uint8_t* m,
                      void* ws, size_t ws_bytes, void* stream) {
+    GQ_OPTIONS_OK();
     return gptq_quantize(W, U, R, C, q_type, block_size, static_groups, p, qweight, d, s, dmin, m, ws, ws_bytes,
                          (hipStream_t)stream, nullptr);
 }
@@ -259,6 +315,7 @@ int gq_gptq_quantize(float* W, const float* U, int64_t R, int64_t C, int q_type,
 int gq_gptq_quantize_stacked(float* W, const float* U, int64_t R, int64_t C, int q_type, int block_size, int static_groups,
                              const gq_search_t* p, uint8_t* qweight, uint16_t* d, uint8_t* s, uint16_t* dmin, uint8_t* m,
                              const int64_t* row_ends_host, int n_stacked, void* ws, size_t ws_bytes, void* stream) {
+    GQ_OPTIONS_OK();
     if (n_stacked < 1 || (n_stacked > 1 && !row_ends_host)) GQ_FAIL(GQ_E_NULL, "gq_gptq_quantize_stacked: n_stacked=%d without row_ends", n_stacked);
     return gptq_quantize(W, U, R, C, q_type, block_size, static_groups, p, qweight, d, s, dmin, m, ws, ws_bytes,
                          (hipStream_t)stream, nullptr, row_ends_host, n_stacked);
@@ -267,6 +324,7 @@ int gq_gptq_quantize_stacked(float* W, const float* U, int64_t R, int64_t C, int
 int gq_gptq_quantize_perm(float* W, const float* U, int64_t R, int64_t C, int q_type, int block_size, const int32_t* perm,
                           const uint16_t* d, const uint8_t* s, const uint16_t* dmin, const uint8_t* m, uint8_t* qweight,
                           void* ws, size_t ws_bytes, void* stream) {
+    GQ_OPTIONS_OK();
     if (!perm) GQ_FAIL(GQ_E_NULL, "gq_gptq_quantize_perm: null perm");
     return gptq_quantize(W, U, R, C, q_type, block_size, 1, nullptr, qweight, const_cast<uint16_t*>(d), const_cast<uint8_t*>(s),
                          const_cast<uint16_t*>(dmin), const_cast<uint8_t*>(m), ws, ws_bytes, (hipStream_t)stream, perm);
@@ -274,6 +332,7 @@ int gq_gptq_quantize_perm(float* W, const float* U, int64_t R, int64_t C, int q_
 
 int gq_rtn_quantize(const void* W, int w_dtype, int64_t R, int64_t C, int q_type, const gq_search_t* p,
                     uint8_t* qweight, uint16_t* d, uint8_t* s, uint16_t* dmin, uint8_t* m, void* stream) {
+    GQ_OPTIONS_OK();
     TypeInfo ti;
     if (!type_info(q_type, ti)) GQ_FAIL(GQ_E_BAD_TYPE, "gq_rtn_quantize: unknown q_type %d", q_type);
     if (R <= 0 || C <= 0 || C % 256) GQ_FAIL(GQ_E_BAD_SHAPE, "gq_rtn_quantize: R=%ld C=%ld", (long)R, (long)C);
@@ -308,17 +367,20 @@ int gq_pack(int q_type, const uint8_t* qweight, const uint16_t* d, const uint8_t
 
 int gq_trailing_update(float* Cmat, int64_t ldc, const float* A, int64_t lda, const float* B, int64_t ldb, int64_t M,
                        int64_t N, int64_t K, void* stream) {
+    GQ_OPTIONS_OK();
     if (!Cmat || !A || !B) GQ_FAIL(GQ_E_NULL, "gq_trailing_update: null pointer");
     return launch_trailing_update(Cmat, ldc, A, lda, B, ldb, M, N, K, (hipStream_t)stream);
 }
 
 int gq_chol_gemm(float* Cmat, int64_t ldc, const float* A, int64_t lda, const float* B, int64_t ldb, int64_t M, int64_t N,
                  int64_t K, int trans_b, int mode, int k_range, int lower, int planes, void* ws, size_t ws_bytes, void* stream) {
+    GQ_OPTIONS_OK();
     return chol_gemm(Cmat, ldc, A, lda, B, ldb, M, N, K, trans_b, mode, k_range, lower, planes, ws, ws_bytes,
                      (hipStream_t)stream);
 }
 
 int gq_stage_to_host(void* host_dst, const void* src, int64_t nbytes, void* stream) {
+    GQ_OPTIONS_OK();
     if (nbytes == 0) return GQ_OK;
     if (!host_dst || !src) GQ_FAIL(GQ_E_NULL, "gq_stage_to_host: null pointer");
     void* dptr = nullptr;

@@ -39,50 +39,55 @@ extern thread_local char g_err[512];
 // ---- library options: every tuning / test switch of the library in ONE table (include/gptq_gguf.h documents them).
 // Set through gq_option_set() or, once at load, from the single environment variable
 //   GQ_OPTIONS="name=value,name=value"
-// and read per call with opt() (a relaxed atomic load).  X(name, default).
-#define GQ_OPTION_LIST(X)                                                                                              \
-    /* K1 SYRK */                                                                                                      \
-    X(syrk_128, 0)          /* 1: the 128x128-tile kernel for every shape */                                            \
-    X(syrk_image, 0)        /* 1: re-laid-out operand image + syrk16_256e_kernel instead of reading X in place */       \
-    X(syrk_nosplit, 0)      /* 1: no K-split of the last, partial round of tiles */                                     \
-    X(syrk_persist, 1)      /* 0: one tile per workgroup instead of the persistent launch with XCD rendezvous */         \
-    X(syrk_wgs, 0)          /* resident workgroups of the persistent launch (0: one per CU) */                          \
-    X(syrk_w4, 1)           /* 0: eight waves with 128x64 wave tiles (syrk16_256n_kernel) instead of four with 128x128 */ \
-    /* K3 Cholesky chain */                                                                                            \
-    X(chol_3p_min, 1792)    /* smallest half of a recursion node that runs on the image GEMMs (0: never) */             \
-    X(chol_planes, 2)       /* 2: row-scaled fp16 x 2 images, 3: exact bf16 x 3 */                                      \
-    X(chol_3b_min, 1024)    /* smallest half that runs on the on-the-fly split-bf16 GEMM */                             \
-    X(chol_fp32, 0)         /* 1: v_mfma_f32_32x32x2_f32 everywhere below the image levels */                           \
-    X(chol_no_pair, 0)      /* 1: SYRK update and L21 X11 of a small node as two launches */                            \
-    X(chol_no_equil, 0)     /* 1: no power-of-two equilibration */                                                      \
-    X(chol_poison, 0)       /* 1: NaN-fill the scratch the chain must never read (tests) */                             \
-    X(diag_ref, 0)          /* 1: the column-by-column 128x128 leaf kernel (reference for tests) */                      \
-    /* K5/K6 column loop */                                                                                            \
-    X(no_lookahead, 0)      /* 1: trailing update after every block, no chained far update */                           \
-    X(la, 8)                /* blocks per look-ahead super-block (even, 2..8) */                                        \
-    X(near_classic, 0)      /* 1: a near launch after every block instead of the pair form */                           \
-    X(near_quad, 0)         /* 1: near launches after every second pair */                                              \
-    X(near64_maxn, 768)     /* widest near update that takes gemm32_near256_kernel */                                   \
-    X(far_sync, 0)          /* 1: far updates on the caller's stream (no helper stream) */                              \
-    X(far_async_max_rows, 8192) X(far_async_min_sb, 8) /* shape window of the helper-stream form */                     \
-    X(far_wgs, 192)         /* resident workgroups of the helper's persistent far GEMM */                               \
-    X(far_bdma, 1)          /* 0: the far GEMM B operand through registers + ds_write instead of LDS-DMA */             \
-    X(chain_generic, 0)     /* 1: the generic chained kernel instead of the dedicated far kernel */                     \
-    X(gemm32_64_max, 256)   /* problems with fewer 128-tiles than this take 64x64 tiles (0: never) */                   \
-    /* K4 */                                                                                                           \
-    X(ss_wide, -1)          /* scale-search mapping: -1 by size, 1 eight lanes, 0 one lane, 2 a lane pair per group */  \
-    /* saver */                                                                                                        \
-    X(stage_host_wgs, 0)    /* workgroups of gq_stage_to_host (0: default) */
+// and read per call with opt() (a relaxed atomic load).  X(name, default, smallest, largest accepted value).
+#define GQ_OPTION_LIST(X)                                                                                                         \
+    /* K1 SYRK */                                                                                                                 \
+    X(syrk_128, 0, 0, 1)          /* 1: the 128x128-tile kernel for every shape */                                                \
+    X(syrk_image, 0, 0, 1)        /* 1: re-laid-out operand image + syrk16_256e_kernel instead of reading X in place */           \
+    X(syrk_nosplit, 0, 0, 1)      /* 1: no K-split of the last, partial round of tiles */                                         \
+    X(syrk_persist, 1, 0, 1)      /* 0: one tile per workgroup instead of the persistent launch with XCD rendezvous */            \
+    X(syrk_wgs, 0, 0, 4096)          /* resident workgroups of the persistent launch (0: one per CU) */                           \
+    X(syrk_w4, 1, 0, 1)           /* 0: eight waves with 128x64 wave tiles (syrk16_256n_kernel) instead of four with 128x128 */   \
+    /* K3 Cholesky chain */                                                                                                       \
+    X(chol_3p_min, 1792, 0, 1048576)    /* smallest half of a recursion node that runs on the image GEMMs (0: never) */           \
+    X(chol_planes, 2, 2, 3)       /* 2: row-scaled fp16 x 2 images, 3: exact bf16 x 3 */                                          \
+    X(chol_3b_min, 1024, 0, 1048576)    /* smallest half that runs on the on-the-fly split-bf16 GEMM */                           \
+    X(chol_fp32, 0, 0, 1)         /* 1: v_mfma_f32_32x32x2_f32 everywhere below the image levels */                               \
+    X(chol_no_pair, 0, 0, 1)      /* 1: SYRK update and L21 X11 of a small node as two launches */                                \
+    X(chol_no_equil, 0, 0, 1)     /* 1: no power-of-two equilibration */                                                          \
+    X(chol_poison, 0, 0, 1)       /* 1: NaN-fill the scratch the chain must never read (tests) */                                 \
+    X(diag_ref, 0, 0, 1)          /* 1: the column-by-column 128x128 leaf kernel (reference for tests) */                         \
+    /* K5/K6 column loop */                                                                                                       \
+    X(no_lookahead, 0, 0, 1)      /* 1: trailing update after every block, no chained far update */                               \
+    X(la, 8, 2, 8)                /* blocks per look-ahead super-block (even, 2..8) */                                            \
+    X(near_classic, 0, 0, 1)      /* 1: a near launch after every block instead of the pair form */                               \
+    X(near_quad, 0, 0, 1)         /* 1: near launches after every second pair */                                                  \
+    X(near64_maxn, 768, 0, 1048576)     /* widest near update that takes gemm32_near256_kernel */                                 \
+    X(far_sync, 0, 0, 1)          /* 1: far updates on the caller's stream (no helper stream) */                                  \
+    X(far_async_max_rows, 8192, 0, 1073741824) X(far_async_min_sb, 8, 0, 1048576) /* shape window of the helper-stream form */    \
+    X(far_wgs, 192, 1, 4096)         /* resident workgroups of the helper's persistent far GEMM */                                \
+    X(far_bdma, 1, 0, 1)          /* 0: the far GEMM B operand through registers + ds_write instead of LDS-DMA */                 \
+    X(chain_generic, 0, 0, 1)     /* 1: the generic chained kernel instead of the dedicated far kernel */                         \
+    X(gemm32_64_max, 256, 0, 1073741824)   /* problems with fewer 128-tiles than this take 64x64 tiles (0: never) */              \
+    /* K4 */                                                                                                                      \
+    X(ss_wide, -1, -1, 2)          /* scale-search mapping: -1 by size, 1 eight lanes, 0 one lane, 2 a lane pair per group */     \
+    /* saver */                                                                                                                   \
+    X(stage_host_wgs, 0, 0, 65536)    /* workgroups of gq_stage_to_host (0: default) */
 
 enum Opt {
-#define GQ_X(name, def) OPT_##name,
+#define GQ_X(name, def, lo, hi) OPT_##name,
     GQ_OPTION_LIST(GQ_X)
 #undef GQ_X
     OPT_COUNT
 };
 int64_t opt(Opt o);
+int options_ok();  // GQ_OK, or GQ_E_UNSUPPORTED + gq_last_error when GQ_OPTIONS did not parse (checked by every entry point)
 
 constexpr int GQ_MAX_STACK = 8;  // row-stacked matrices of one gq_gptq_quantize_stacked call
+// The panel block of a scale-search call chain (256 bytes): words [2k], [2k + 1] = "some group valid" / "some group took the
+// candidate" bits per search iteration of stacked matrix k (left at zero by every launch); word GQ_PANEL_RESEARCH counts the
+// panel-wide re-searches of the chain (panel_fixup_kernel; read by gq_gptq_quantize_slice)
+constexpr int GQ_PANEL_RESEARCH = 2 * GQ_MAX_STACK;
 
 struct TypeInfo {
     int bits, qmin, qmax, scale_maxq, group, is_signed, k_search, type_size;

@@ -466,7 +466,7 @@ struct UniformSpec {
 static int column_loop(float* W, const float* U, int64_t R, int64_t C, int q_type, int block_size, int static_groups,
                        const gq_search_t* p, uint8_t* qweight, uint16_t* d, uint8_t* s, uint16_t* dmin, uint8_t* m,
                        void* ws, size_t ws_bytes, hipStream_t st, const int32_t* perm, const UniformSpec* uni,
-                       const int64_t* row_ends = nullptr, int nstack = 1) {
+                       const int64_t* row_ends = nullptr, int nstack = 1, int32_t* researches_out = nullptr) {
     // row_ends / nstack: W is several matrices that share U, one under the other (rows never mix: gptq.py:222-270);
     // only the scale searches need to know where one ends and the next begins (their panel-wide `continue`)
     TypeInfo ti;
@@ -533,7 +533,7 @@ static int column_loop(float* W, const float* U, int64_t R, int64_t C, int q_typ
     // one device word shared by all scale-search launches of this call (each leaves it at zero)
     unsigned* panel = reinterpret_cast<unsigned*>(
         (reinterpret_cast<uintptr_t>(Wblk + ((B > SEG) ? (size_t)R * B : 0)) + 255) & ~(uintptr_t)255);
-    if (ti.k_search && static_groups != 2) GQ_HIP(hipMemsetAsync(panel, 0, 8 * (size_t)(nstack > 1 ? nstack : 1), st));
+    if ((ti.k_search && static_groups != 2) || researches_out) GQ_HIP(hipMemsetAsync(panel, 0, 256, st));
     const int64_t ng = C / ti.group, nsg = C / 256;
     const int gps = uni ? 1 : 256 / ti.group;
     auto uniform_params = [&](int64_t col, int G, int64_t g) {
@@ -713,15 +713,18 @@ static int column_loop(float* W, const float* U, int64_t R, int64_t C, int q_typ
         }
     }
     if (ev_last) GQ_HIP(hipStreamWaitEvent(st, ev_last, 0));  // the caller's stream sees the helper's last write
+    if (researches_out)  // every scale search of this call ran on `st`: the count is final here
+        GQ_HIP(hipMemcpyAsync(researches_out, panel + GQ_PANEL_RESEARCH, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
     return GQ_OK;
 }
 
 int gptq_quantize(float* W, const float* U, int64_t R, int64_t C, int q_type, int block_size, int static_groups,
                   const gq_search_t* p, uint8_t* qweight, uint16_t* d, uint8_t* s, uint16_t* dmin, uint8_t* m,
-                  void* ws, size_t ws_bytes, hipStream_t st, const int32_t* perm, const int64_t* row_ends, int nstack) {
+                  void* ws, size_t ws_bytes, hipStream_t st, const int32_t* perm, const int64_t* row_ends, int nstack,
+                  int32_t* researches_out) {
     if (nstack > 1 && perm) GQ_FAIL(GQ_E_UNSUPPORTED, "gq_gptq_quantize_stacked: act_order matrices are not stacked");
     return column_loop(W, U, R, C, q_type, block_size, static_groups, p, qweight, d, s, dmin, m, ws, ws_bytes, st, perm,
-                       nullptr, row_ends, nstack);
+                       nullptr, row_ends, nstack, researches_out);
 }
 
 // EvoPress FastOBQ.step for one bit width (evopress/src/fast_obq.py:146-200) given U.

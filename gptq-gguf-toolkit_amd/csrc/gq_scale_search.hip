@@ -499,6 +499,10 @@ __global__ __launch_bounds__(256) void panel_fixup_kernel(
     constexpr int NG = 256 / GSZ;
     constexpr int RPB = 256 / NG;  // rows per pass of the workgroup
     __shared__ unsigned sh_valid, sh_acc;
+    // word GQ_PANEL_RESEARCH of the call chain's panel block: how many times a panel was searched AGAIN (sticky: the chain's
+    // owner zeroes and reads it).  A row slice of a row-split matrix decides `valid.any()` over its own rows; as long as no
+    // slice ever searched again, every slice's results equal the whole matrix's -- the host checks this word
+    unsigned* const researches = panel_valid + GQ_PANEL_RESEARCH;
     if (sp.nstack > 1) {  // workgroup k = stacked matrix k: its rows, its panel words
         const int64_t r0 = blockIdx.x ? sp.row_end[blockIdx.x - 1] : 0;
         rows = sp.row_end[blockIdx.x] - r0;
@@ -524,6 +528,7 @@ __global__ __launch_bounds__(256) void panel_fixup_kernel(
         if (tid == 0) {
             sh_valid = 0;
             sh_acc = 0;
+            atomicAdd(researches, 1u);
         }
         __syncthreads();
         for (int64_t r0 = 0; r0 < rows; r0 += RPB) {
@@ -593,7 +598,7 @@ static int launch_ss(const void* x, int64_t rows, int64_t ld, int q_type, const 
     }
     if (ti.k_search && !panel && (!p || p->nstep >= 1)) {
         GQ_HIP(hipMallocAsync(&own, 256, st));
-        GQ_HIP(hipMemsetAsync(own, 0, 8 * (size_t)(nstack > 1 ? nstack : 1), st));
+        GQ_HIP(hipMemsetAsync(own, 0, 256, st));
         panel = reinterpret_cast<unsigned*>(own);
     }
     SearchParams sp;

@@ -48,13 +48,20 @@ def shard_calibration(data: Sequence, rank: int, world_size: int) -> list:
 
 
 def _avg(payload, dst=None):
-    """AVG over the ranks, to every rank or -- `dst` -- to that rank only (half the bytes on every link of a ring)."""
-    if dst is None:
-        dist.all_reduce(payload, op=dist.ReduceOp.AVG)
+    """AVG over the ranks, to every rank or -- `dst` -- to that rank only (half the bytes on every link of a ring).
+    The op is chosen from the BACKEND, once per call and identically on every rank (never by catching an exception around a
+    collective: a rank-local failure would make one rank issue a second collective the others do not): nccl (= RCCL) has
+    AVG; gloo does not -- SUM, divided where the result lives."""
+    if dist.get_backend() != "gloo":
+        if dst is None:
+            dist.all_reduce(payload, op=dist.ReduceOp.AVG)
+        else:
+            dist.reduce(payload, dst=dst, op=dist.ReduceOp.AVG)
         return
-    try:
-        dist.reduce(payload, dst=dst, op=dist.ReduceOp.AVG)
-    except (RuntimeError, ValueError):  # a backend without AVG for reduce: SUM, divided where the result lives
+    if dst is None:
+        dist.all_reduce(payload, op=dist.ReduceOp.SUM)
+        payload.div_(get_world_size())
+    else:
         dist.reduce(payload, dst=dst, op=dist.ReduceOp.SUM)
         if get_rank() == dst:
             payload.div_(get_world_size())

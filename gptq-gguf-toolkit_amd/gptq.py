@@ -386,6 +386,8 @@ class GPTQ:
         h0 = hs[0]
         res = _ops.gptq_quantize(Wf, U, int(q_type), h0.block_size, h0.static_groups, h0.rmin, h0.rdelta, h0.nstep,
                                  quant_scale=h0.quant_scale.value, grid=h0.grid, row_ends=ends)
+        for h in hs:
+            h.W = h.layer.weight  # not a view of Wf: one handle kept alive must not pin the whole stack until reset()
         return [tuple(t[r1 - n:r1] for t in res) for r1, n in zip(ends, rows)]
 
     def _row_split_active(self) -> bool:

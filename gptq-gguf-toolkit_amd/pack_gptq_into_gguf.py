@@ -256,9 +256,21 @@ def add_tokenizer(w: GGUFWriter, dir_model: Path, vocab_size: int):
 def _add_space_prefix(w: GGUFWriter, dir_model: Path, vocab_size: Optional[int] = None) -> None:
     """The tail of LlamaModel.set_vocab (:2138-2158), in its order."""
     if vocab_size == 32016:
-        # CodeLlama only (:2138-2148): a second SpecialVocab carrying the four fill-in-the-middle token ids
-        for typ, tid in (("prefix", 32007), ("suffix", 32008), ("middle", 32009), ("eot", 32010)):
-            w.add_uint32(f"tokenizer.ggml.{typ}_token_id", tid)
+        # CodeLlama only (:2138-2148): a second SpecialVocab(load_merges=False, special_token_types=prefix/suffix/middle/eot)
+        # with the four fill-in-the-middle ids set by hand.  SpecialVocab.add_to_gguf writes a type only when the writer has
+        # an `add_<type>_token_id` method and skips it with a warning otherwise; the GGUFWriter of the pinned gguf-py
+        # (0.17.1, after llama.cpp's fill-in-the-middle rework: fim_pre / fim_suf / fim_mid keys, found by token text at load
+        # time) has add_eot_token_id but no prefix / suffix / middle handlers -> ONE key, three warnings.  (gguf-py is not
+        # installable here: DESIGN.md 0d lists this among the bytes pinned by its published behaviour only.)
+        for typ, tid in (("prefix", 32007), ("suffix", 32008), ("middle", 32009)):
+            print(f"warning: No handler for special token type {typ} with id {tid} - skipping", file=sys.stderr)
+        w.add_uint32("tokenizer.ggml.eot_token_id", 32010)
+        # the same second SpecialVocab reads tokenizer_config.json again and adds its chat template a second time: the
+        # writer refuses the duplicate key (gguf-py: ValueError "Duplicated key name"), as the reference's run would
+        tcj = dir_model / "tokenizer_config.json"
+        tmpl = json.load(open(tcj, encoding="utf-8")).get("chat_template") if tcj.is_file() else None
+        if isinstance(tmpl, str):
+            w.add_string("tokenizer.chat_template", tmpl)
     cfgp = dir_model / "tokenizer_config.json"
     cfg = json.load(open(cfgp, encoding="utf-8")) if cfgp.exists() else {}
     if vocab_size == 49152:

@@ -17,6 +17,7 @@ schema (quantizer.py:268-275).  MI355X-first differences, none of which changes 
 `Quantizer.timing` holds the split of the last `quantize()` call (host seconds per phase and, with
 GQ_TIMING=gpu, HIP-event seconds per phase on the main stream).
 """
+import atexit
 import os
 import queue
 import sys
@@ -163,6 +164,12 @@ class _Saver:
     `_Saver.USE_PROCESS = False` keeps everything in-process; `sync=True` (CPU tensors) writes in line like the reference."""
 
     USE_PROCESS, KERNEL_COPY, INLINE = True, True, True
+    _teardowns: List[threading.Thread] = []  # deferred close() tails still running (see close / _join_teardowns)
+
+    @staticmethod
+    def _join_teardowns(timeout: float = 90.0) -> None:
+        while _Saver._teardowns:
+            _Saver._teardowns.pop().join(timeout=timeout)
 
     def __init__(self, save_dir: str, sync: bool):
         self.save_dir, self.sync = save_dir, sync
@@ -188,6 +195,7 @@ class _Saver:
     def _start_process(self):
         import torch.multiprocessing as tmp
         ctx = tmp.get_context("spawn")
+        _Saver._join_teardowns()  # a previous saver's slots (2.1 GB of /dev/shm) are gone before this one asks for room
         # the slots are files in /dev/shm: ftruncate succeeds on a small tmpfs (Docker's default is 64 MB) and the
         # first write into the slot then kills the process with SIGBUS -- ask before allocating
         need = self.n_slots * self.slot_bytes + (64 << 20)
@@ -475,7 +483,11 @@ class _Saver:
                             pass
                     slots.clear()
             if status == "ok" and not self._writer_dead:
-                threading.Thread(target=_teardown, daemon=True, name="gq-saver-teardown").start()
+                # joined by the next _Saver before it sizes /dev/shm, and at interpreter exit BEFORE the HIP runtime is
+                # finalised (atexit hooks run ahead of module teardown): the thread never calls into a dying runtime
+                th = threading.Thread(target=_teardown, daemon=True, name="gq-saver-teardown")
+                _Saver._teardowns.append(th)
+                th.start()
             else:
                 _teardown()
             self._registered = []
@@ -488,6 +500,9 @@ class _Saver:
                 self.err = self.err or RuntimeError(f"data.pth writer process failed: {info}")
         if self.err is not None:
             raise self.err
+
+
+atexit.register(_Saver._join_teardowns, 30.0)
 
 
 class _Phases:
@@ -658,7 +673,7 @@ class Quantizer:
             block = block.to(device)
             prefix = f"{self.block_modules}.{block_id}."
             layers = select_layers(self.model, prefix, self.quantizable_modules, LINEAR_LAYERS)
-            handles, hooks = self._prepare_hooks_and_handles(layers)
+            handles, hooks = self._prepare_hooks_and_handles(layers, block)
             sched = self._schedule
             for a, kw in zip(input_args, input_kwargs):  # forward #1: Hessians (quantizer.py:150-151)
                 try:
@@ -722,13 +737,19 @@ class Quantizer:
         # (the reference asserts, gptq.py:126, and averages unweighted)
         return GPTQ(layer, allow_no_samples=".experts." in f".{name}.", **self.quantizer_kwargs)
 
-    def _prepare_hooks_and_handles(self, layers: Dict[str, nn.Module]):
-        """reference quantizer.py:221-239; the hook body lives in BlockSchedule.feed."""
+    def _prepare_hooks_and_handles(self, layers: Dict[str, nn.Module], block: Optional[nn.Module] = None):
+        """reference quantizer.py:221-239; the hook body lives in BlockSchedule.feed.  `block`: its Linears outside `layers`
+        get a flag-only pre-hook, so that forward #1 is interrupted only when the last Linear to run is a hooked one."""
         self._schedule = BlockSchedule(layers, self._create_handle, verbose=self.verbose)
         # forward PRE-hooks: same inp[0] as the reference's forward hook (quantizer.py:229), available before the Linear's
         # GEMM, so that forward #1 can stop at the last hooked Linear (BlockSchedule.pre_hook)
         hooks = {name: layer.register_forward_pre_hook(self._schedule.pre_hook(name, self.interrupt_forward1))
                  for name, layer in layers.items()}
+        if block is not None and self.interrupt_forward1:
+            hooked = {id(l) for l in layers.values()}
+            for i, m in enumerate(block.modules()):
+                if isinstance(m, tuple(LINEAR_LAYERS)) and id(m) not in hooked:
+                    hooks[f"<unhooked {i}>"] = m.register_forward_pre_hook(self._schedule.other_pre_hook())
         return self._schedule.handles, hooks
 
     # ------------------------------------------------------------- quantize

@@ -160,3 +160,37 @@ def test_committed_bench_lines_keep_the_driver_contract():
     assert abs(d["value"] - 218.1 / d["ms_per_step"] * 1e3) / d["value"] < 0.01  # 218.1 M params per step
     assert d["roofline"]["traffic"]["GB_per_launch"] > d["roofline"]["traffic"]["algorithmic_GB_per_launch"] > 0
     assert d["whole_model"]["wall_s_quantizer_region"] < d["whole_model_hf_eager"]["wall_s_quantizer_region"]
+
+
+def test_bench_compact_line_and_self_launch_refusal():
+    """VERDICT r04 next #1 / #6 (host side, no GPU): (a) bench.py's LAST stdout line is the compact headline: every key of the
+    driver contract, `roofline` / `cpu_baseline` flat (scalars only: the driver's parser drops nested objects) with the traffic
+    ratio and the trailing-update fractions, <= 2 KB; (b) `python bench.py --gpus 2` with no launcher and fewer than two
+    GPUs refuses loudly instead of measuring one rank."""
+    import importlib.util
+    import json
+    import subprocess
+    import sys
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    full = json.loads(open(os.path.join(ROOT, "profiles", "r04_bench_llama3-8b-block-q4k.json")).read())
+    full.update({"n_gpus": 8, "ranks_seen": 8, "collective_backend": "nccl (RCCL over xGMI)",
+                 "collectives_per_step": {"all_reduce": 3.0, "reduce": 1.0, "all_gather": 1.0, "broadcast": 0.0, "small_all_reduce": 0.0},
+                 "allreduce_probe": {"C": 14336, "payload_MB": 418.0, "ms": 3.21, "backend": "nccl"}})
+    c = bench.compact_line(full)
+    s = json.dumps(c)
+    assert len(s) <= 2048, len(s)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in c, k
+    assert all(not isinstance(v, (dict, list)) for v in c["roofline"].values())
+    assert all(not isinstance(v, (dict, list)) for v in c["cpu_baseline"].values())
+    r = c["roofline"]
+    assert r["traffic"] > r["traffic_algorithmic"] > 0 and r["traffic_ratio"] > 1
+    assert r["trailing_far_alone_frac"] > 0.7 and r["trailing_far_in_region_frac"] > 0 and r["trailing_loop_ms_as_run"] > 0
+    assert c["whole_model_wall_s"] > 0 and c["cpu_baseline"]["stage_update_s"] > 0
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    if not __import__("torch").cuda.is_available():
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True)
+        assert p.returncode != 0 and "RCCL needs one GPU per rank" in p.stderr and "{" not in p.stdout

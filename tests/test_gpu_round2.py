@@ -347,8 +347,10 @@ def _spawn_bench(n, backend, extra=()):
            "--no-cpu-baseline", "--no-whole-model", "--no-side-legs", *extra]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-3000:]
-    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
-    return line, p.stderr
+    lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+    full, compact = lines[-2], lines[-1]  # bench.py: the full dict, then the compact headline LAST
+    assert compact["n_gpus"] == full["n_gpus"] == n and compact["value"] == full["value"]
+    return full, p.stderr
 
 
 def test_bench_two_ranks_hold_identical_results():

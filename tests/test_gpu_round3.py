@@ -227,7 +227,7 @@ def test_bench_eight_ranks_one_allgather_per_block(workload):
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=2400, cwd=ROOT)
     assert p.returncode == 0, "\n".join([ln[:300] for ln in p.stderr.splitlines() if "Error" in ln][:6]) + p.stderr[-1500:]
     assert "verify: all ranks hold identical results" in p.stderr
-    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-2])  # the full dict; the compact line is last
     assert line["n_gpus"] == n and line["ranks_seen"] == n and line["collective_backend"].startswith(backend)
     owners = line["config"]["owners"]
     shapes = bench.WORKLOADS[workload]["shapes"]

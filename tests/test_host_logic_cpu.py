@@ -1164,6 +1164,28 @@ def test_forward1_stops_at_the_last_hooked_linear(tmp_path):
     assert sorted(os.listdir(trees[0])) == sorted(os.listdir(trees[1]))
 
 
+def test_forward1_runs_in_full_when_the_last_linear_is_not_hooked(tmp_path):
+    """with a --quantizable_modules regex that leaves out the block's structurally last Linear (down_proj), the
+    learned "last hooked Linear" (up_proj) is NOT where the forward ends: forward #1 must run in full, every sample."""
+    import fake_ops
+    from make_golden_shim import tiny_calib, tiny_llama
+    from gptq_gguf_toolkit_amd.quant_utils import GGMLQuantizationType as T
+    from gptq_gguf_toolkit_amd.quantizer import Quantizer
+    fake_ops.install()
+    ids = tiny_calib()
+    model = tiny_llama()
+    n_calls = [0]
+    model.model.layers[0].mlp.down_proj.register_forward_hook(lambda *a: n_calls.__setitem__(0, n_calls[0] + 1))
+    drv = Quantizer(model, data_loader=[([], {"input_ids": t}) for t in ids],
+                    quantizable_modules=r".*layers.*((q|k|v|o|gate|up)_proj)$",
+                    quantizer_kwargs=dict(rel_damp=0.01, block_size=128), pre_block_modules=["model.embed_tokens"],
+                    block_modules="model.layers", post_block_modules=["lm_head"], quant_non_block_modules=False,
+                    device="cpu", save_dir=str(tmp_path), interrupt_forward1=True)
+    drv.quantize({k: T.Q4_K for k in ("q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj")})
+    assert n_calls[0] == 2 * len(ids)  # forward #1 and forward #2 of block 0, every sample
+    assert "forward1_interrupts" not in drv.schedule_stats
+
+
 def test_vocab_tail_codellama_granite_and_pair_merges(tmp_path):
     """the rest of LlamaModel.set_vocab (reference pack_gptq_into_gguf.py:2138-2158) -- the CodeLlama
     fill-in-the-middle ids (vocab 32016), granite's add_bos_token = False (vocab 49152, a duplicate key raises like gguf-py) --
@@ -1183,7 +1205,9 @@ def test_vocab_tail_codellama_granite_and_pair_merges(tmp_path):
         return {k: v for k, _, v, _ in w.kv}, [k for k, *_ in w.kv]
     kv, order = kv_of(32016)
     assert kv["tokenizer.ggml.merges"] == ["a b", "aĠb c", "b c"]
-    assert [kv[f"tokenizer.ggml.{t}_token_id"] for t in ("prefix", "suffix", "middle", "eot")] == [32007, 32008, 32009, 32010]
+    # gguf-py 0.17.1's writer has add_eot_token_id only: prefix / suffix / middle are skipped with a warning
+    assert kv["tokenizer.ggml.eot_token_id"] == 32010
+    assert not any(f"tokenizer.ggml.{t}_token_id" in kv for t in ("prefix", "suffix", "middle"))
     assert order.index("tokenizer.ggml.eot_token_id") < order.index("tokenizer.ggml.add_space_prefix")  # :2138 before :2150
     kv, order = kv_of(49152)
     assert kv["tokenizer.ggml.add_bos_token"] is False and order[-1] == "tokenizer.ggml.add_bos_token"
