@@ -11,13 +11,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.environ.get("GQ_SO_PATH") or os.path.join(CSRC, "libgptqgguf_hip.so")  # override: kernel A/B probes
 
-ABI_VERSION = 5  # include/gptq_gguf.h GQ_ABI_VERSION this binding was written against
+ABI_VERSION = 6  # include/gptq_gguf.h GQ_ABI_VERSION this binding was written against
 F32, F16, BF16 = 0, 1, 2
 WS_H_ACCUMULATE, WS_H_PREPARE, WS_GPTQ_QUANTIZE, WS_CHOL_GEMM = 1, 2, 3, 4
 
 EXPORTS = (
     "gq_abi_version", "gq_last_error", "gq_option_count", "gq_option_name", "gq_option_get", "gq_option_default", "gq_option_set", "gq_type_info", "gq_workspace_bytes", "gq_h_accumulate", "gq_h_accumulate_grouped", "gq_h_accumulate_segments", "gq_h_stage", "gq_h_stage_many", "gq_h_prepare", "gq_w_prepare", "gq_h_pack_upper", "gq_h_unpack_upper",
-    "gq_scale_search", "gq_group_search", "gq_gptq_quantize", "gq_gptq_quantize_stacked", "gq_gptq_quantize_perm", "gq_gptq_uses_helper_stream", "gq_far_helper_enable", "gq_obq_h_prepare", "gq_obq_quantize", "gq_rtn_quantize", "gq_dequantize", "gq_pack", "gq_trailing_update", "gq_chol_gemm", "gq_stage_to_host", "gq_fwd_rmsnorm", "gq_fwd_rmsnorm_ordered", "gq_fwd_rope", "gq_fwd_silu_mul",
+    "gq_scale_search", "gq_group_search", "gq_gptq_quantize", "gq_gptq_quantize_stacked", "gq_gptq_quantize_slice", "gq_gptq_quantize_perm", "gq_gptq_uses_helper_stream", "gq_far_helper_enable", "gq_obq_h_prepare", "gq_obq_quantize", "gq_rtn_quantize", "gq_dequantize", "gq_pack", "gq_trailing_update", "gq_chol_gemm", "gq_stage_to_host", "gq_fwd_rmsnorm", "gq_fwd_rmsnorm_ordered", "gq_fwd_rope", "gq_fwd_silu_mul",
     "gq_prof_enable", "gq_prof_ntags", "gq_prof_name", "gq_prof_collect", "gq_prof_collect2",
 )
 
@@ -89,6 +89,7 @@ def lib():
     L.gq_group_search.argtypes = [vp, ci, i64, i64, ci, sp, vp, vp, vp, vp, vp, vp, vp]
     L.gq_gptq_quantize.argtypes = [vp, vp, i64, i64, ci, ci, ci, sp, vp, vp, vp, vp, vp, vp, sz, vp]
     L.gq_gptq_quantize_stacked.argtypes = [vp, vp, i64, i64, ci, ci, ci, sp, vp, vp, vp, vp, vp, vp, ci, vp, sz, vp]
+    L.gq_gptq_quantize_slice.argtypes = [vp, vp, i64, i64, ci, ci, ci, sp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
     L.gq_gptq_quantize_perm.argtypes = [vp, vp, i64, i64, ci, ci, vp, vp, vp, vp, vp, vp, vp, sz, vp]
     L.gq_gptq_uses_helper_stream.argtypes = [i64, i64, ci]
     L.gq_far_helper_enable.argtypes = [ci]

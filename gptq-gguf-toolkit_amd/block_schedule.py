@@ -576,7 +576,12 @@ class BlockSchedule:
         layouts = [[(n, r0, r1) + self._piece_layout(qtypes[n], r1 - r0, handles[n].d_col) for n, r0, r1 in lst]
                    for lst in per_rank]
         sizes = [sum(x[4] for x in lst) for lst in layouts]
-        nbytes = max(max(sizes), 256)
+        # the row-split matrices' re-search counts (GPTQ.compute: quant_utils.py:250-252 evaluated per row slice) ride in the
+        # same buffer: one int32 per split matrix at the end of every rank's chunk -- no collective of their own
+        split = [n for n, h in handles.items() if h._row_split_active()]
+        tail = (4 * len(split) + 255) & ~255 if split else 0
+        body = max(max(sizes), 256)
+        nbytes = body + tail
         dev = next(iter(handles.values())).W_device
         buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         off = 0
@@ -585,8 +590,15 @@ class BlockSchedule:
                 k = shp[0] * shp[1] * t.element_size()
                 buf[off + o:off + o + k].view(dt).view(shp).copy_(t)
             off += tot
+        if split:
+            buf[body:body + 4 * len(split)].view(torch.int32).copy_(torch.cat([handles[n]._researches for n in split]))
         gathered = dist_utils.all_gather_bytes(buf, nbytes)
         self.stats["allgather_bytes"] = self.stats.get("allgather_bytes", 0) + nbytes
+        redo = []
+        if split:
+            # the one host read of the exchange (4 ranks and up only): which split matrices must be quantized whole
+            counts = gathered[:, body:body + 4 * len(split)].view(torch.int32).reshape(world, len(split)).sum(dim=0).tolist()
+            redo = [n for n, c in zip(split, counts) if c != 0]
         parts: Dict[str, List[List[torch.Tensor]]] = {n: [] for n in handles}
         for r in range(world):
             off = 0
@@ -600,6 +612,13 @@ class BlockSchedule:
         out: Dict[str, tuple] = {}
         for n in handles:
             ps = parts[n]
+            if n in redo:
+                # some rank's slice decided the panel-wide `continue` on its own rows: every rank quantizes the whole matrix
+                # (same H, same U on every rank -> identical results, the N = 1 bytes; no second exchange)
+                self.stats["row_split_redone"] = self.stats.get("row_split_redone", 0) + 1
+                handles[n].row_split_redone = True
+                out[n] = handles[n].recompute_whole(qtypes[n])
+                continue
             # a whole matrix: views into the gathered buffer (no copy); row slices: concatenated in rank order
             out[n] = tuple(ps[0]) if len(ps) == 1 else tuple(torch.cat([p[i] for p in ps], dim=0) for i in range(5))
         return out

@@ -21,7 +21,8 @@ int launch_trailing_update(float*, int64_t, const float*, int64_t, const float*,
                            hipStream_t);
 size_t gptq_workspace_bytes(int64_t, int64_t, int);
 int gptq_quantize(float*, const float*, int64_t, int64_t, int, int, int, const gq_search_t*, uint8_t*, uint16_t*,
-                  uint8_t*, uint16_t*, uint8_t*, void*, size_t, hipStream_t, const int32_t*, const int64_t* = nullptr, int = 1);
+                  uint8_t*, uint16_t*, uint8_t*, void*, size_t, hipStream_t, const int32_t*, const int64_t* = nullptr, int = 1,
+                  int32_t* = nullptr);
 size_t h_accumulate_workspace_bytes(int64_t, int64_t);
 int h_accumulate(float*, const void*, int, int64_t, int64_t, float, float, void*, size_t, hipStream_t);
 int h_accumulate_grouped(int, float* const*, const void* const*, const int64_t*, const int64_t*, const float*, const float*,
@@ -310,6 +311,15 @@ int gq_gptq_quantize(float* W, const float* U, int64_t R, int64_t C, int q_type,
     GQ_OPTIONS_OK();
     return gptq_quantize(W, U, R, C, q_type, block_size, static_groups, p, qweight, d, s, dmin, m, ws, ws_bytes,
                          (hipStream_t)stream, nullptr);
+}
+
+int gq_gptq_quantize_slice(float* W, const float* U, int64_t R, int64_t C, int q_type, int block_size, int static_groups,
+                           const gq_search_t* p, uint8_t* qweight, uint16_t* d, uint8_t* s, uint16_t* dmin, uint8_t* m,
+                           int32_t* panel_researches, void* ws, size_t ws_bytes, void* stream) {
+    GQ_OPTIONS_OK();
+    if (!panel_researches) GQ_FAIL(GQ_E_NULL, "gq_gptq_quantize_slice: null panel_researches");
+    return gptq_quantize(W, U, R, C, q_type, block_size, static_groups, p, qweight, d, s, dmin, m, ws, ws_bytes,
+                         (hipStream_t)stream, nullptr, nullptr, 1, panel_researches);
 }
 
 int gq_gptq_quantize_stacked(float* W, const float* U, int64_t R, int64_t C, int q_type, int block_size, int static_groups,

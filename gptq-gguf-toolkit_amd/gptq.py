@@ -45,6 +45,9 @@ class GPTQ:
         # --- beyond the reference ---
         self.owner_rank = 0            # rank that runs step(); the reference hard-codes rank 0 (gptq.py:158)
         self.row_split = False         # every rank runs step() on its own rows (dist_utils.row_split_names)
+        self.row_split_redone = False  # the last row-split quantization fell back to the whole matrix (recompute_whole)
+        self._researches = None        # device int32: panel-wide re-searches of this rank's row slice
+        self._last_cf = None           # column flags of the last _prepare (dead / all-zero columns)
         self.reduce_to = None          # the ONE rank that needs this handle's reduced H (None: every rank -> all-reduce)
         # MoE experts may receive no calibration token at all: with allow_no_samples the handle then uses H = I
         # (round-to-nearest with the lazily computed scales) instead of the reference's assertion (gptq.py:126)
@@ -241,6 +244,8 @@ class GPTQ:
         self.no_samples = False
         self.owner_rank = 0
         self.row_split = False
+        self._researches = None
+        self._last_cf = None
         self.reduce_to = None
 
     # ------------------------------------------------------------------- quantize
@@ -311,6 +316,7 @@ class GPTQ:
         shared = self.shared_H_with is not None or self._has_followers
         if shared and leader._U_cache is not None and not own_U:
             U, flag, cf = leader._U_cache
+            self._last_cf = cf
             mismatch = _ops.w_prepare(cf, self.W)
             if defer_check:
                 self._pending_mismatch, self._flag = mismatch, flag
@@ -320,6 +326,7 @@ class GPTQ:
                 return U
         H = self.H.clone() if shared else self.H  # every reference handle damps its own copy
         U, self._flag, cf = _ops.h_prepare(H, self.W, self.rel_damp, want_flags=True)
+        self._last_cf = cf
         if shared and leader._U_cache is None and not own_U:
             leader._U_cache = (U, self._flag, cf)
         if not shared:
@@ -344,10 +351,28 @@ class GPTQ:
         if self._row_split_active():
             # every rank factorises (same reduced H => the same U, bit for bit) and walks its own rows
             r0, r1, _ = dist_utils.row_slice(self.d_row, dist_utils.get_rank(), dist_utils.get_world_size())
+            # quant_utils.py:250-252 looks across ALL rows of the matrix; a slice looks across its own.  The two agree unless a
+            # slice had to search a panel again (gq_gptq_quantize_slice counts those): the counts of all ranks are summed
+            # after the loop (exchange / BlockSchedule._exchange_block) and a non-zero sum sends the matrix to recompute_whole
+            self._researches = torch.zeros(1, dtype=torch.int32, device=self.W.device)
             if r1 <= r0:
                 return tuple(t[:0] for t in self._empty_result(q_type))
             W = self.W[r0:r1]
+            return _ops.gptq_quantize(W, U, int(q_type), self.block_size, self.static_groups, self.rmin, self.rdelta,
+                                      self.nstep, quant_scale=self.quant_scale.value, grid=self.grid,
+                                      panel_researches=self._researches)
         return _ops.gptq_quantize(W, U, int(q_type), self.block_size, self.static_groups, self.rmin,
+                                  self.rdelta, self.nstep, quant_scale=self.quant_scale.value, grid=self.grid)
+
+    @torch.no_grad()
+    def recompute_whole(self, q_type: GGMLQuantizationType):
+        """Row-split fallback: ALL rows of the matrix on this rank, with the factorisation compute() made -- what the owner of
+        the matrix would have produced (every rank holds the same reduced H, hence the same U: the ranks' results are
+        identical without an exchange).  Called on every rank when the ranks' re-search counts do not sum to zero."""
+        assert self._last_U is not None and self._last_cf is not None, "recompute_whole() follows compute()"
+        self.make_working_copy()
+        _ops.w_prepare(self._last_cf, self.W)  # the dead / all-zero columns gq_h_prepare zeroed in the first working copy
+        return _ops.gptq_quantize(self.W, self._last_U, int(q_type), self.block_size, self.static_groups, self.rmin,
                                   self.rdelta, self.nstep, quant_scale=self.quant_scale.value, grid=self.grid)
 
     def stack_key(self, q_type: GGMLQuantizationType):
@@ -433,6 +458,13 @@ class GPTQ:
         """Broadcast of the 5 result tensors from the owner (reference gptq.py:287-293, src=0 there)."""
         if self._row_split_active():  # all-gather of the ranks' row slices instead of the owner's broadcast
             _, _, chunk = dist_utils.row_slice(self.d_row, dist_utils.get_rank(), dist_utils.get_world_size())
+            n = self._researches.clone()
+            dist_utils.collective_calls["small_all_reduce"] += 1
+            dist_utils.collective_bytes["small_all_reduce"] += 4
+            dist.all_reduce(n, op=dist.ReduceOp.SUM)
+            if int(n.item()) != 0:  # some slice decided :250-252 on its own rows: the whole matrix, on every rank
+                self.row_split_redone = True
+                return self.recompute_whole(q_type)
             return tuple(dist_utils.all_gather_rows(t, self.d_row, chunk) for t in result)
         if result is None:
             result = self._empty_result(q_type)

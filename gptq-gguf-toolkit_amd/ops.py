@@ -226,9 +226,13 @@ def _streams(device, n):
 
 def gptq_quantize(W: torch.Tensor, U: torch.Tensor, q_type: int, block_size=128, static_groups=False, rmin=-1.0,
                   rdelta=0.1, nstep=20, ws: Optional[torch.Tensor] = None, row_chunks: Optional[int] = None,
-                  row_ends: Optional[Sequence[int]] = None, **mq):
+                  row_ends: Optional[Sequence[int]] = None, panel_researches: Optional[torch.Tensor] = None, **mq):
     """GPTQ.step body.  W (fp32, contiguous) is updated IN PLACE to the dequantized matrix.
     Returns (qweight, d, s, dmin, m).
+
+    `panel_researches` (gq_gptq_quantize_slice): W is a ROW SLICE of a matrix several ranks quantize together; the int32
+    device tensor receives the number of panel-wide re-searches of the slice's scale searches (0: the slice's rows equal
+    the whole matrix's rows bit for bit -- quant_utils.py:250-252 is the one place the reference looks across all rows).
 
     `row_ends` (gq_gptq_quantize_stacked): W holds several Linears that share U, one under the other -- matrix k is rows
     [row_ends[k-1], row_ends[k]), multiples of 64, the last one == R.  One walk over the columns instead of one per
@@ -259,6 +263,17 @@ def gptq_quantize(W: torch.Tensor, U: torch.Tensor, q_type: int, block_size=128,
                                              _search(rmin, rdelta, nstep, **mq), _ptr(q), _ptr(d), _ptr(s), _ptr(dmin),
                                              _ptr(m), ends, len(row_ends), _ptr(ws), ws.numel(), _stream(W)),
               "gq_gptq_quantize_stacked")
+        t = _idt(q_type)
+        return q.view(t), d, s.view(t), dmin, m.view(t)
+
+    if panel_researches is not None:
+        assert panel_researches.dtype == torch.int32 and panel_researches.is_cuda and panel_researches.numel() >= 1
+        need = workspace_bytes(_cabi.WS_GPTQ_QUANTIZE, R, C, 0, bs)
+        if ws is None or ws.numel() < need:
+            ws = _ws(need, W.device)
+        check(lib().gq_gptq_quantize_slice(_ptr(W), _ptr(U), R, C, int(q_type), bs, int(bool(static_groups)),
+                                           _search(rmin, rdelta, nstep, **mq), _ptr(q), _ptr(d), _ptr(s), _ptr(dmin), _ptr(m),
+                                           _ptr(panel_researches), _ptr(ws), ws.numel(), _stream(W)), "gq_gptq_quantize_slice")
         t = _idt(q_type)
         return q.view(t), d, s.view(t), dmin, m.view(t)
 

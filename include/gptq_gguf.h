@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define GQ_ABI_VERSION 5
+#define GQ_ABI_VERSION 6
 
 /* ggml type ids (quant_utils.py:11-16) */
 enum { GQ_Q2_K = 10, GQ_Q3_K = 11, GQ_Q4_K = 12, GQ_Q5_K = 13, GQ_Q6_K = 14 };
@@ -82,7 +82,8 @@ const char* gq_last_error(void);
 /* ---- environment and options -------------------------------------------------------------------------------------
    The LIBRARY reads two environment variables:
      GQ_OPTIONS    "name=value,name=value" (a bare name means 1): initial values of the options below, read once at the
-                   first call; an unknown name aborts (a typo must not silently measure the default)
+                   first call; an unknown name, a value that is not an integer or one outside the option's range makes
+                   EVERY entry point fail with GQ_E_UNSUPPORTED + gq_last_error (a typo must not silently measure the default)
      GQ_PROF_DUMP  file that gq_prof_collect2 appends every timed launch interval to (timeline studies)
    The PYTHON package (host code) reads:
      GQ_SO_PATH         another build of this library (kernel A/B probes)
@@ -221,6 +222,20 @@ int gq_gptq_quantize_stacked(float* W, const float* U, int64_t R, int64_t C, int
                              uint8_t* qweight, uint16_t* d, uint8_t* s, uint16_t* dmin, uint8_t* m,
                              const int64_t* row_ends_host, int n_stacked,
                              void* ws, size_t ws_bytes, void* stream);
+
+/* gq_gptq_quantize on a ROW SLICE of a matrix that several ranks quantize together (rows are independent in
+   gptq.py:222-270 given U; SURVEY section 8(e): from 4 ranks up the widest Linear of a block is cut R/k rows per GPU).
+   The one place where the reference looks across ALL rows of a matrix is make_k_quants' `if not valid.any(): continue`
+   (quant_utils.py:250-252): a slice evaluates it over its own rows.  The slice's results equal the whole matrix's rows
+   bit for bit unless some slice had to search a panel AGAIN because of that test (the slow path of the scale search:
+   a panel with an iteration in which NO group is valid and whose candidate some group had taken).
+   *panel_researches (device int32, written on `stream`) = the number of such re-searches in this call.  The caller sums
+   the ranks' counts (they travel with the block's all-gather) and, when the sum is not 0, quantizes that matrix whole
+   instead (gq_gptq_quantize on all rows, same U): always the N = 1 bytes.  0 for Q3_K / Q6_K (no search). */
+int gq_gptq_quantize_slice(float* W, const float* U, int64_t R, int64_t C, int q_type,
+                           int block_size, int static_groups, const gq_search_t* p_host,
+                           uint8_t* qweight, uint16_t* d, uint8_t* s, uint16_t* dmin, uint8_t* m,
+                           int32_t* panel_researches, void* ws, size_t ws_bytes, void* stream);
 
 /* 1 if gq_gptq_quantize / gq_gptq_quantize_perm / gq_obq_quantize on an R x C matrix MAY put the bulk of its far
    trailing updates (gptq.py:270 beyond the current 1024-column super-block) on the library's own helper HIP stream,

@@ -147,6 +147,16 @@ typedef struct {
     int valid;
 } kq_state_t;
 
+/* Checker-side instrumentation (not part of the reference): how often the panel-wide `continue` of :251-252 skipped an
+   iteration whose candidate SOME group would have taken -- the event that makes a row slice of a matrix decide differently
+   from the whole matrix (the HIP library reports the same count through gq_gptq_quantize_slice). */
+static int64_t g_panel_researches = 0;
+int64_t gqo_panel_researches(int reset) {
+    int64_t v = g_panel_researches;
+    if (reset) g_panel_researches = 0;
+    return v;
+}
+
 static void make_k_quants_r(const float* x, int64_t n_groups, int G, int bits, double rmin, double rdelta, int nstep,
                             int rmode, float* scale_out, float* zero_out) {
     const float maxq = (float)((1 << bits) - 1);
@@ -244,7 +254,14 @@ static void make_k_quants_r(const float* x, int64_t n_groups, int G, int bits, d
                 s->this_scale = this_scale;
                 s->this_min = this_min;
             }
-            if (!any_valid) continue; /* :251-252: panel-wide early continue */
+            if (!any_valid) { /* :251-252: panel-wide early continue */
+                for (int64_t g = 0; g < n_groups; ++g)
+                    if (st[g].cand_err < st[g].best_err) {
+                        g_panel_researches += 1;
+                        break;
+                    }
+                continue;
+            }
 #pragma omp parallel for schedule(static)
             for (int64_t g = 0; g < n_groups; ++g) {
                 kq_state_t* s = &st[g];

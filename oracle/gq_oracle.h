@@ -52,6 +52,9 @@ float gqo_bf16_to_f32(uint16_t h);
    (8 lanes, chunks added in order, lanes summed 0->7).  Exposed for tests. */
 float gqo_aten_sum(const float* v, int n);
 
+/* checker-side counter (see gq_oracle.c): skipped iterations (quant_utils.py:251-252) whose candidate a group would have taken */
+int64_t gqo_panel_researches(int reset);
+
 /* reference quant_utils.py:199-274 make_k_quants.  x: [n_groups, G] contiguous.
    scale/zero: [n_groups].  zero = -best_min. */
 void gqo_make_k_quants(const float* x, int64_t n_groups, int G, int bits,

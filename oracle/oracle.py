@@ -152,6 +152,14 @@ def _alloc_outs(R, C, q_type):
             np.empty((R, C // G), np.uint8))
 
 
+def panel_researches(reset=True) -> int:
+    """Skipped search iterations (quant_utils.py:251-252) whose candidate some group would have taken, since the last
+    reset -- what gq_gptq_quantize_slice reports for a row slice."""
+    L = lib()
+    L.gqo_panel_researches.restype = ctypes.c_int64
+    return int(L.gqo_panel_researches(int(bool(reset))))
+
+
 def gptq_step(W, U, q_type, block_size=128, static_groups=False, rmin=-1.0, rdelta=0.1, nstep=20):
     """GPTQ.step.  Returns (W_dequantized, qweight, d, s, dmin, m) -- d/dmin as uint16 bits."""
     W = np.array(W, np.float32, order="C", copy=True)

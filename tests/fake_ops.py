@@ -6,7 +6,8 @@ import torch
 
 from oracle import oracle as O
 
-calls = {"h_accumulate": 0, "h_prepare": 0, "w_prepare": 0, "gptq_quantize": 0, "gptq_quantize_stacked": 0}
+calls = {"h_accumulate": 0, "h_prepare": 0, "w_prepare": 0, "gptq_quantize": 0, "gptq_quantize_stacked": 0,
+         "gptq_quantize_slice": 0}
 
 
 def _f16(bits):
@@ -70,7 +71,7 @@ def _mode(mq):
 
 
 def gptq_quantize(W, U, q_type, block_size=128, static_groups=False, rmin=-1.0, rdelta=0.1, nstep=20, ws=None,
-                  row_ends=None, **mq):
+                  row_ends=None, panel_researches=None, **mq):
     calls["gptq_quantize"] += 1
     if row_ends is not None and len(row_ends) > 1:
         # row-stacked Linears that share U (gq_gptq_quantize_stacked): the oracle, matrix by matrix
@@ -83,7 +84,11 @@ def gptq_quantize(W, U, q_type, block_size=128, static_groups=False, rmin=-1.0, 
             r0 = r1
         return tuple(torch.cat([p[i] for p in parts]) for i in range(5))
     _mode(mq)
+    O.panel_researches(reset=True)
     Wd, q, d, s, dmin, m = O.gptq_step(W.numpy(), U.numpy(), q_type, block_size, static_groups, rmin, rdelta, nstep)
+    if panel_researches is not None:  # gq_gptq_quantize_slice
+        calls["gptq_quantize_slice"] += 1
+        panel_researches.fill_(O.panel_researches(reset=True))
     _mode({})
     W.copy_(torch.from_numpy(Wd))
     return torch.from_numpy(q), _f16(d), torch.from_numpy(s), _f16(dmin), torch.from_numpy(m)

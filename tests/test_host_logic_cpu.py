@@ -1306,3 +1306,92 @@ def test_stack_groups():
         sch.handles[f"x{i}"].shared_H_with = sch.handles["x0"]
     g = sch._stack_groups(list(many), {n: T.Q4_K for n in many}, {f"x{i}": False for i in range(1, 11)})
     assert [len(x) for x in g] == [8, 3] and g[0][0] == "x0"
+
+
+# --------------------------------------------------------------------------- row split: the panel-wide `continue`
+def _worker_rowsplit_corner(rank, world, port, ret, mode, tiny_slice, via_schedule, device="cpu"):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), GQ_ROW_SPLIT=mode)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import fake_ops
+    if device == "cpu":
+        fake_ops.install()  # the GPU test runs the same worker on the HIP library (tests/test_gpu_round5.py)
+    from gptq_gguf_toolkit_amd import dist_utils
+    from gptq_gguf_toolkit_amd.block_schedule import BlockSchedule
+    from gptq_gguf_toolkit_amd.gptq import GPTQ
+    from gptq_gguf_toolkit_amd.quant_utils import GGMLQuantizationType as T
+    torch.manual_seed(0)
+    R, C = 512, 512
+    lin = torch.nn.Linear(C, R, bias=False)
+    W = torch.randn(R, C) * 0.02
+    if tiny_slice:
+        W[128:256] *= 1e-6  # rank 1's rows: ~2e-8, no group of that slice is ever `valid` (quant_utils.py:250)
+    lin.weight.data = W
+    X = torch.randn(1, 96, C)
+    if device != "cpu":
+        lin, X = lin.to(device), X.to(device)
+    before = dict(dist_utils.collective_calls)
+    if via_schedule:
+        sched = BlockSchedule({"down": lin}, lambda l, n: GPTQ(l, rel_damp=0.01, block_size=128))
+        sched.feed("down", X)
+        sched.sample_done()
+        res = sched.quantize({"down": T.Q4_K}, writeback=False)["down"]
+        redone = sched.stats.get("row_split_redone", 0)
+        owners = dict(sched.owners)
+    else:
+        h = GPTQ(lin, rel_damp=0.01, block_size=128)
+        h.row_split = mode != "0"
+        h.update(X)
+        res = h.quantize(T.Q4_K)
+        redone = int(h.row_split_redone)
+        owners = {}
+    coll = {k: v - before.get(k, 0) for k, v in dist_utils.collective_calls.items()}
+    ret[rank] = (tuple(t.cpu().clone() for t in res), redone, coll, dict(fake_ops.calls), owners)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("via_schedule", [True, False])
+def test_four_rank_row_split_equals_owner_mode_even_when_a_slice_has_no_valid_group(via_schedule):
+    """VERDICT r04 next #2.  make_k_quants' `if not valid.any(): continue` (quant_utils.py:250-252) looks across ALL rows of the
+    matrix; a row slice looks across its own.  4 gloo ranks, one Linear split 128 rows per rank, rank 1's rows ~2e-8 (no
+    group of that slice is ever valid, groups of the other slices are): the slice's own verdict differs from the matrix's, the
+    re-search counts (gq_gptq_quantize_slice) that ride in the block's all-gather say so, and every rank quantizes the whole
+    matrix instead -- bytes identical to GQ_ROW_SPLIT=0 (owner mode = the N = 1 result).  With ordinary weights nothing is
+    redone and no collective is added (BlockSchedule; the handle-level path pays one 4-byte all-reduce)."""
+    world = 4
+    mgr = mp.Manager()
+    got = {}
+    for k, (mode, tiny) in enumerate((("0", True), ("all", True), ("all", False), ("0", False))):
+        ret = mgr.dict()
+        mp.spawn(_worker_rowsplit_corner, args=(world, 34000 + 11 * k + os.getpid() % 2000, ret, mode, tiny, via_schedule),
+                 nprocs=world, join=True)
+        got[(mode, tiny)] = [ret[r] for r in range(world)]
+    for tiny in (True, False):
+        ref = got[("0", tiny)][0][0]
+        for r in range(world):
+            for mode in ("0", "all"):
+                res = got[(mode, tiny)][r][0]
+                assert all(torch.equal(a, b) for a, b in zip(ref, res)), f"rank {r} mode {mode} tiny {tiny}"
+    for r in range(world):
+        res, redone, coll, calls, owners = got[("all", True)][r]
+        assert redone == 1 and calls["gptq_quantize_slice"] == 1 and calls["gptq_quantize"] == 2  # the slice, then the whole matrix
+        res, redone, coll, calls, owners = got[("all", False)][r]
+        assert redone == 0 and calls["gptq_quantize_slice"] == 1 and calls["gptq_quantize"] == 1
+        if via_schedule:
+            assert owners == {"down": "rows/4"}
+            assert (coll["all_gather"], coll["broadcast"], coll.get("small_all_reduce", 0)) == (1, 0, 0), coll
+        else:
+            assert coll["small_all_reduce"] == 1 and coll["all_gather"] == 5, coll
+    # the corner is real: without the fallback rank 1's slice result differs from the whole matrix's rows
+    import fake_ops
+    from oracle import oracle as O
+    torch.manual_seed(0)
+    torch.nn.Linear(512, 512, bias=False)
+    W = torch.randn(512, 512) * 0.02
+    W[128:256] *= 1e-6
+    x = W[:, :256].contiguous().numpy()
+    whole = O.scale_search(x, 12)
+    part = O.scale_search(x[128:256].copy(), 12)
+    assert any(not np.array_equal(np.asarray(a)[128:256], np.asarray(b)) for a, b in zip(whole, part))
