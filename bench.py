@@ -505,7 +505,7 @@ def cpu_baseline(wl, W16, keep):
             dt_codec += time.perf_counter() - t1
             dt += t1 - t0
             tot += R * C
-            same += float((oq == keep[n][0][0].cpu().numpy()).sum())
+            same += float((oq == keep["__out__"][n][0].cpu().numpy()).sum())
             cnt += oq.size
             del W, U, oq
         # the reference's own CPU calls for the two tolerance-class stages, on a sample
@@ -720,7 +720,7 @@ def compact_line(line):
         c["sample"] = str(c.get("sample", ""))[:90]
         c.update({f"stage_{k}": v for k, v in st.items()})
         c["step_only_value"] = so.get("value")
-        out["cpu_baseline"] = c
+    out["cpu_baseline"] = c or None  # (None at N > 1: the baseline is part of the N = 1 line)
     for key in ("whole_model", "whole_model_hf_eager", "whole_model_batch4"):
         out[f"{key}_wall_s"] = _get(line, key, "wall_s_quantizer_region")
     out["collectives_per_step"] = line.get("collectives_per_step")
@@ -961,7 +961,9 @@ def main():
             "tolerance_parity": tolerance_parity(wl, W16, X) if side else None,
             "tolerance_parity_widest": tolerance_parity(wl, W16, X, widest=True, n_rows=128) if side else None,
             "fast_obq": fast_obq_leg(wl, W16, X) if side else None,
-            "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline(wl, W16, keep),
+            # the host-core baseline belongs to the N = 1 line (rank 0 holds every U there; at N > 1 the ranks' host cores are
+            # busy feeding their GPUs and rank 0 factorised only the matrices it owns)
+            "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(wl, W16, keep),
         }
     del keep, sched
     if args.workload.startswith("llama3-8b-block") and not args.no_whole_model:

@@ -10,6 +10,26 @@ Layout (little endian):
   n_tensors x { string name | u32 n_dims | u64 dims[n_dims] (ggml order: innermost first)
                 | u32 ggml_type | u64 offset (from the start of the data section) }
   padding to `general.alignment` (32) | tensor data, each tensor padded to the alignment
+
+Where the GGUF v3 specification leaves a choice, this writer makes the choice gguf-py's `GGUFWriter` makes (its published
+behaviour, cited per rule as class.method; DESIGN.md section 0d lists them with the test that asserts each):
+  R1  key/value pairs are written in INSERTION order and `general.architecture` is the first one (`GGUFWriter.__init__`
+      calls `add_architecture()`; `write_kv_data_to_file` walks the dict);
+  R2  a key added twice raises ValueError("Duplicated key name ...") (`add_key_value`); a tensor name added twice raises
+      ValueError("Duplicated tensor name ...") (`add_tensor_info`);
+  R3  the element type of an ARRAY is the type of its FIRST element by the Python type -- str -> STRING, bool -> BOOL,
+      int -> INT32, float -> FLOAT32 (`GGUFValueType.get_type`) -- and every element must map to the same type
+      (ValueError "All items in a GGUF array should be of the same type", `_pack_val`); an EMPTY array is not written at all
+      (`add_array` returns early);
+  R4  strings are UTF-8 with a u64 byte length and no terminator; BOOL is one byte 0 / 1 (`_pack_val`);
+  R5  tensor infos AND tensor data are both in the order of the `add_tensor` calls (`write_ti_data_to_file` /
+      `write_tensors_to_file` walk the same dict); a tensor's offset is relative to the start of the data section and
+      advances by `ggml_pad(nbytes, alignment)`; dimensions are stored innermost first;
+  R6  every pad byte is 0x00: between the tensor infos and the data section and after EVERY tensor including the last one
+      (`write_padding` writes `bytes([0] * pad)`), so the file length is a multiple of the alignment;
+  R7  the alignment is 32 and `general.alignment` is NOT written unless a custom alignment was asked for;
+  R8  a uint8 array handed over with a `raw_dtype` is block bytes: its logical shape is `quant_shape_from_byte_shape`
+      (`add_tensor`); fp16 / fp32 numpy arrays name their own type.
 """
 import struct
 from typing import Any, List, Sequence, Tuple
@@ -48,6 +68,21 @@ _SCALAR_FMT = {GGUFValueType.UINT8: "<B", GGUFValueType.INT8: "<b", GGUFValueTyp
                GGUFValueType.INT16: "<h", GGUFValueType.UINT32: "<I", GGUFValueType.INT32: "<i",
                GGUFValueType.FLOAT32: "<f", GGUFValueType.BOOL: "<?", GGUFValueType.UINT64: "<Q",
                GGUFValueType.INT64: "<q", GGUFValueType.FLOAT64: "<d"}
+
+
+def value_type_of(v: Any) -> int:
+    """gguf-py `GGUFValueType.get_type` (rule R3): the GGUF type a Python value is written as when none is given."""
+    if isinstance(v, (str, bytes, bytearray)):
+        return GGUFValueType.STRING
+    if isinstance(v, (list, tuple)):
+        return GGUFValueType.ARRAY
+    if isinstance(v, float):
+        return GGUFValueType.FLOAT32
+    if isinstance(v, bool):  # before int: bool is an int in Python
+        return GGUFValueType.BOOL
+    if isinstance(v, int):
+        return GGUFValueType.INT32
+    raise ValueError(f"Unknown type: {type(v)}")
 
 
 def _pack_value(vtype: int, v: Any, sub: int = None) -> bytes:
@@ -109,7 +144,19 @@ class GGUFWriter:
     def add_uint32(self, k, v): self.add(k, GGUFValueType.UINT32, int(v))
     def add_float32(self, k, v): self.add(k, GGUFValueType.FLOAT32, float(v))
     def add_bool(self, k, v): self.add(k, GGUFValueType.BOOL, bool(v))
-    def add_array(self, k, v, sub): self.add(k, GGUFValueType.ARRAY, list(v), sub)
+
+    def add_array(self, k, v, sub=None):
+        """Rule R3.  `sub` given (this package always names it): it must be what gguf-py would infer from the elements --
+        the reference calls `add_array(key, values)` / `add_token_types` / `add_token_scores` without a type."""
+        v = list(v)
+        if len(v) == 0:
+            return  # gguf-py: `if len(val) == 0: return`
+        inferred = value_type_of(v[0])
+        if not all(value_type_of(x) == inferred for x in v[1:]):
+            raise ValueError("All items in a GGUF array should be of the same type")
+        if sub is not None and sub != inferred:
+            raise ValueError(f"array {k!r}: element type {sub} asked for, gguf-py would write {inferred} for these values")
+        self.add(k, GGUFValueType.ARRAY, v, inferred)
 
     # ---- tensors
     def add_tensor(self, name: str, data: np.ndarray, raw_dtype: int = None):
@@ -120,6 +167,8 @@ class GGUFWriter:
             shape = data.shape
         else:
             shape = quant_shape_from_byte_shape(data.shape, raw_dtype) if data.dtype == np.uint8 else data.shape
+        if any(n == name for n, *_ in self.tensors):  # rule R2
+            raise ValueError(f"Duplicated tensor name {name!r}")
         self.tensors.append((name, tuple(int(x) for x in shape), int(raw_dtype), data))
 
     def write(self):

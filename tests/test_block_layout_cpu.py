@@ -43,7 +43,7 @@ def test_cabi_exports_every_declared_symbol():
         assert hasattr(L, sym), f"{sym} declared in gptq_gguf.h but not exported"
     assert set(_cabi.EXPORTS) == declared
     lib = _cabi.lib()
-    assert lib.gq_abi_version() == _cabi.ABI_VERSION == 5
+    assert lib.gq_abi_version() == _cabi.ABI_VERSION == 6
     for t, ts in ((10, 84), (11, 110), (12, 144), (13, 176), (14, 210)):
         assert _cabi.type_info(t)["type_size"] == ts
     with pytest.raises(_cabi.GQError):

@@ -1395,3 +1395,68 @@ def test_four_rank_row_split_equals_owner_mode_even_when_a_slice_has_no_valid_gr
     whole = O.scale_search(x, 12)
     part = O.scale_search(x[128:256].copy(), 12)
     assert any(not np.array_equal(np.asarray(a)[128:256], np.asarray(b)) for a, b in zip(whole, part))
+
+
+# --------------------------------------------------------------------------- f1: the spec's open choices
+def test_gguf_writer_makes_gguf_pys_choices_where_the_spec_is_open(tmp_path):
+    """The GGUF v3 specification leaves open (or only implies) what this writer must do the way gguf-py 0.17.1's GGUFWriter does
+    for a file to be byte-identical to the reference's (pack_gptq_into_gguf.py:155,348,437-475).  gguf-py is not installable
+    here, so each rule is asserted against its PUBLISHED behaviour, by name (gguf_writer.py module docstring R1-R8; DESIGN.md
+    section 0d): what stays unpinned is then a list of named keys, not the container."""
+    import struct
+    from gptq_gguf_toolkit_amd.gguf_writer import GGMLType, GGUFValueType as VT, GGUFWriter, parse_gguf, value_type_of
+    p = str(tmp_path / "r.gguf")
+    w = GGUFWriter(p, "llama")
+    # R1: insertion order, general.architecture first
+    w.add_uint32("llama.block_count", 2)
+    w.add_string("general.name", "x")
+    w.add_bool("tokenizer.ggml.add_bos_token", True)
+    # R3: element type = Python type of the first element; homogeneous; empty arrays are not written
+    w.add_array("tokenizer.ggml.tokens", ["a", "bc"])
+    w.add_array("tokenizer.ggml.token_type", [1, 3])
+    w.add_array("tokenizer.ggml.scores", [0.0, -1000.0])
+    w.add_array("tokenizer.ggml.merges", [])
+    with pytest.raises(ValueError, match="same type"):
+        w.add_array("bad.mixed", [1, 2.0])
+    with pytest.raises(ValueError, match="gguf-py would write"):
+        w.add_array("bad.sub", [1, 2], VT.UINT32)  # python ints are INT32 in gguf-py unless the caller packs them itself
+    assert (value_type_of("s"), value_type_of(1), value_type_of(1.0), value_type_of(True)) == (VT.STRING, VT.INT32, VT.FLOAT32, VT.BOOL)
+    # R2: duplicates raise
+    with pytest.raises(ValueError, match="Duplicated key name"):
+        w.add_uint32("llama.block_count", 3)
+    rng = np.random.default_rng(0)
+    t0 = rng.standard_normal((3, 5)).astype(np.float32)             # 60 bytes: needs 4 pad bytes
+    t1 = rng.integers(0, 256, (2, 144), dtype=np.uint8)             # one Q4_K block per row: logical [2, 256]
+    t2 = rng.standard_normal(7).astype(np.float16)                  # 14 bytes: the LAST tensor is padded too
+    w.add_tensor("z_last_in_name_order.weight", t0)
+    w.add_tensor("a_first_in_name_order.weight", t1, raw_dtype=GGMLType.Q4_K)
+    w.add_tensor("m.weight", t2)
+    with pytest.raises(ValueError, match="Duplicated tensor name"):
+        w.add_tensor("m.weight", t2)
+    w.write()
+    kv, tensors, buf = parse_gguf(p)
+    assert list(kv) == ["general.architecture", "llama.block_count", "general.name", "tokenizer.ggml.add_bos_token",
+                        "tokenizer.ggml.tokens", "tokenizer.ggml.token_type", "tokenizer.ggml.scores"]      # R1, R3 (no merges)
+    assert "general.alignment" not in kv                                                                       # R7
+    assert kv["tokenizer.ggml.tokens"][1] == [VT.ARRAY, VT.STRING] and kv["tokenizer.ggml.token_type"][1] == [VT.ARRAY, VT.INT32]
+    assert kv["tokenizer.ggml.scores"][1] == [VT.ARRAY, VT.FLOAT32]
+    # R4: u64 length + UTF-8, no terminator; BOOL one byte
+    key = b"general.architecture"
+    assert buf[24:24 + 8 + len(key) + 4 + 8 + 5] == struct.pack("<Q", len(key)) + key + struct.pack("<IQ", VT.STRING, 5) + b"llama"
+    i = buf.index(b"tokenizer.ggml.add_bos_token") + len(b"tokenizer.ggml.add_bos_token")
+    assert buf[i:i + 5] == struct.pack("<I", VT.BOOL) + b"\x01" and buf[i + 5:i + 13] == struct.pack("<Q", len("tokenizer.ggml.tokens"))
+    # R5: infos and data in add_tensor order (NOT sorted by name), offsets relative to the data section, ggml_pad steps; R8
+    assert [t[0] for t in tensors] == ["z_last_in_name_order.weight", "a_first_in_name_order.weight", "m.weight"]
+    assert [t[1] for t in tensors] == [(3, 5), (2, 256), (7,)] and [t[2] for t in tensors] == [GGMLType.F32, GGMLType.Q4_K, GGMLType.F16]
+    data0 = tensors[0][3]
+    assert data0 % 32 == 0 and [t[3] - data0 for t in tensors] == [0, 64, 64 + 288]
+    assert buf[tensors[0][3]:tensors[0][3] + 60] == t0.tobytes() and buf[tensors[1][3]:tensors[1][3] + 288] == t1.tobytes()
+    # R6: every pad byte is zero -- before the data section, between tensors, after the last one; length a multiple of 32
+    assert buf[data0 + 60:data0 + 64] == b"\x00" * 4
+    end2 = tensors[2][3] + 14
+    assert len(buf) == end2 + 18 and buf[end2:] == b"\x00" * 18 and len(buf) % 32 == 0
+    info_end = buf.index(b"m.weight") + len(b"m.weight") + 4 + 8 + 4 + 8   # n_dims, one dim, type, offset
+    assert set(buf[info_end:data0]) <= {0} and data0 - info_end < 32
+    # dims innermost first (R5): the Q4_K tensor's info holds ne = [256, 2]
+    j = buf.index(b"a_first_in_name_order.weight") + len(b"a_first_in_name_order.weight")
+    assert struct.unpack_from("<IQQIQ", buf, j) == (2, 256, 2, GGMLType.Q4_K, 64)
