@@ -1,0 +1,16 @@
+#!/bin/bash
+# the four-wave SYRK with one of its three streams removed (profiles/micro/build_syrk_r05_probes.sh), on
+# all-zero and on random operands, alone on the GPU, C = 14336, 65 536 tokens.  TFLOP/s are "algorithmic flops / time" of the
+# launch whatever the variant computes: for the variants without MFMAs the number says how fast the REST of the loop would let
+# the matrix pipe run.  usage (GPU box): bash profiles/r05_syrk_decompose.sh > gpurun_out/r05_syrk_decompose.txt
+cd "$(dirname "$0")/.."
+B=profiles/micro/_build
+for rep in 1 2; do
+  for data in zeros random; do
+    for v in shipped nomfma_nord nomfma nord nodma; do
+      so=""; [ $v != shipped ] && so=$PWD/$B/libgq_$v.so
+      a=$(GQ_SO_PATH=$so DATA=$data CS=14336 ITERS=8 python profiles/syrk_probe.py 2>/dev/null | tail -3 | awk '{printf "%s ", $5}')
+      echo "[$data] [$v] C=14336: $a TFLOP/s"
+    done
+  done
+done

@@ -8,7 +8,9 @@ from gptq_gguf_toolkit_amd import ops
 nseq, L = int(os.environ.get("NSEQ", 32)), 2048
 dev = torch.device("cuda")
 Cs = [int(c) for c in os.environ.get("CS", "4096,4096,4096,14336").split(",")]
-X = [torch.randn(nseq * L, C, device=dev, dtype=torch.float16) for C in Cs]
+zeros = os.environ.get("DATA", "random") == "zeros"  # all-zero operands: no power cap (the structural ceiling of the kernel)
+X = [torch.zeros(nseq * L, C, device=dev, dtype=torch.float16) if zeros else
+     torch.randn(nseq * L, C, device=dev, dtype=torch.float16) for C in Cs]
 H = [torch.zeros(C, C, device=dev) for C in Cs]
 for it in range(int(os.environ.get("ITERS", 2))):
     torch.cuda.synchronize(); t0 = time.perf_counter()

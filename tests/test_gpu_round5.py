@@ -88,8 +88,8 @@ def test_slice_entry_counts_panel_researches_like_the_oracle():
     from oracle import oracle as O
     torch.manual_seed(3)
     R, C = 128, 512
-    U = torch.linalg.cholesky(torch.linalg.inv(torch.randn(C, 2 * C).double() @ torch.randn(2 * C, C).double() / C
-                                               + torch.eye(C).double()), upper=True).float().cuda().contiguous()
+    Z = torch.randn(C, 2 * C).double()
+    U = torch.linalg.cholesky(torch.linalg.inv(Z @ Z.T / C + torch.eye(C).double()), upper=True).float().cuda().contiguous()
     for scale, want_positive in ((0.02, False), (2e-8, True)):
         W = (torch.randn(R, C) * scale).cuda()
         n = torch.full((1,), -7, dtype=torch.int32, device="cuda")
