@@ -935,7 +935,9 @@ def main():
                 "avg_launch_ms": round(syrk_sum_ms / max(syrk_n, 1), 4),
                 "share_of_step": round(syrk_ms / 1e3 / dt, 3)}
         far = prof.get("trailing_far_gemm32", (0.0, 0, 0.0))
-        side = not args.no_side_legs
+        # the side legs are single-GPU measurements of the N = 1 line; some of them drive handles whose quantize() issues
+        # collectives, which only rank 0 would enter here (a hang under RCCL): never at N > 1
+        side = not args.no_side_legs and world == 1
         line = {
             "metric": "Mparams/s GPTQ-quantized", "value": round(params * args.steps / dt / 1e6, 2),
             "unit": "Mparams/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

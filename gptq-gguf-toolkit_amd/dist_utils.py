@@ -184,10 +184,9 @@ def _all_gather_into(out, inp) -> None:
     """out[r * n : (r + 1) * n] = rank r's inp (n = inp.numel()), ONE collective, no list of temporaries."""
     collective_calls["all_gather"] += 1
     collective_bytes["all_gather"] += inp.numel() * inp.element_size()
-    try:
-        dist.all_gather_into_tensor(out.view(-1), inp.view(-1))
-    except (RuntimeError, NotImplementedError):  # a backend without the tensor form: views of `out` as the list
-        dist.all_gather(list(out.view(-1).chunk(get_world_size())), inp.view(-1))
+    # (nccl = RCCL and gloo both have the tensor form; no fallback around a collective: a rank-local failure must not make one
+    # rank issue a collective the others do not)
+    dist.all_gather_into_tensor(out.view(-1), inp.view(-1))
 
 
 def all_gather_bytes(mine, nbytes: int):

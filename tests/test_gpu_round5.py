@@ -33,6 +33,9 @@ def test_bench_launches_its_own_ranks(n):
     assert full["collectives_per_step"]["all_gather"] == 1 and full["allreduce_probe"]["ms"] > 0
     assert compact["roofline"]["frac"] > 0 and compact["cpu_baseline"] is None  # the host-core baseline is an N = 1 leg
     assert full["config"]["calib_seqs_per_rank"] == 32 // n
+    # nothing on rank 0 may enter a collective the other ranks do not (it would hang under RCCL): the single-GPU side legs are off
+    assert all(full[k] is None for k in ("trailing_update", "encoders", "column_loop", "tolerance_parity", "fast_obq"))
+    assert "Connection closed" not in json.dumps(full)
 
 
 def test_bench_refuses_more_ranks_than_gpus_without_gloo():
