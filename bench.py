@@ -611,7 +611,9 @@ def whole_model_run(wl, dev, world, rank, save_root=None, nseq=None, L=None, lay
             with torch.no_grad():
                 model(input_ids=ids[0].to(dev), use_cache=False)
             torch.cuda.synchronize()
-        wm_prof = os.environ.get("GQ_BENCH_WM_PROF")  # e.g. "syrk,transpose16": HIP-event time of those kernels in the run
+        # HIP-event time of the named kernels inside the run (default: the SYRK -- its roofline fraction on the activations of a
+        # real forward, next to the synthetic step's; ~4 us per launch, 4 launches per block); e.g. "syrk,transpose16"
+        wm_prof = os.environ.get("GQ_BENCH_WM_PROF", "syrk")
         if wm_prof:
             _cabi.prof_enable(wm_prof.split(","))
         t1 = time.perf_counter()
@@ -630,6 +632,17 @@ def whole_model_run(wl, dev, world, rank, save_root=None, nseq=None, L=None, lay
     finally:
         if rank == 0:
             shutil.rmtree(save_dir, ignore_errors=True)
+    syrk_wm = None
+    if wm_prof and "syrk" in prof_got and prof_got["syrk"][0] > 0:
+        # algorithmic flops of the run's Hessian folds: per block the four distinct inputs (q/k/v, o, gate/up: hidden wide; down:
+        # intermediate wide), T C (C + 128) each, T = this rank's calibration tokens
+        hdim, idim, nblk = cfg_kw["hidden_size"], cfg_kw["intermediate_size"], cfg_kw["num_hidden_layers"]
+        T_ = float(len(ids) * L)
+        fl = nblk * T_ * (3.0 * hdim * (hdim + 128) + idim * (idim + 128.0))
+        a_ = fl / (prof_got["syrk"][0] * 1e-3) / 1e12
+        syrk_wm = {"achieved": round(a_, 1), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(a_ / PEAK_F16_MFMA_TFLOPS, 4),
+                   "launches": prof_got["syrk"][1], "ms": prof_got["syrk"][0],
+                   "operands": "bf16 activations of the model's own forward (random-init weights): sum of launch durations"}
     out = {"model": f"random-init LlamaForCausalLM {cfg_kw['num_hidden_layers']} layers, hidden {cfg_kw['hidden_size']}, "
                     f"bf16, attn {os.environ.get('GQ_ATTN', 'sdpa')}; embed + lm_head RTN ({q}), all block Linears GPTQ ({q})",
            "forward": {"off": "HF eager modules (the reference's forward)",
@@ -642,6 +655,7 @@ def whole_model_run(wl, dev, world, rank, save_root=None, nseq=None, L=None, lay
                     + (" (the reference's cadence)" if calib_batch == 1 else " (--calibration_batch: same Hessian sums, fewer and larger GEMMs)"),
            "params_quantized_M": round(params / 1e6, 1),
            "wall_s_quantizer_region": round(wall, 2), "Mparams_per_s": round(params / wall / 1e6, 1),
+           "syrk_roofline_on_model_activations": syrk_wm,
            "split": dict(drv.timing, **({"kernel_ms_launches": prof_got} if wm_prof else {})), "schedule": getattr(drv, "schedule_stats", None), "model_build_s": round(t_build, 1),
            "data_pth": {"files": files, "GB": round(nbytes / 1e9, 2), "dir": root},
            "region": "Quantizer.quantize (reference quant.py:251-254), model and ids resident on the GPU/host before it, "
@@ -710,6 +724,7 @@ def compact_line(line):
                         ("trailing_loop_ms_as_run", ("loop_ms", "as_run"))):
         r[k_out] = _get(tu, *path)
     r["trailing_peak_TFLOPs_f32"] = PEAK_F32_MFMA_TFLOPS
+    r["frac_on_model_forward_activations"] = _get(line, "whole_model", "syrk_roofline_on_model_activations", "frac")
     r["column_loop_ns_per_step"] = _get(line, "column_loop", "ns_per_step")
     r["encoders_frac_of_hbm"] = _get(line, "encoders", "frac")
     out["roofline"] = r
@@ -907,13 +922,14 @@ def main():
         # driver's run cannot carry counters: a --pmc run serialises the kernels).  The file names the kernel sources it
         # was measured on; for any other build the field is null -- a stale constant is not a measurement.
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r04_syrk_traffic.json")
-        if os.path.exists(tpath) and args.workload == "llama3-8b-block-q4k" and world == 1 and not args.calib_seqs \
-                and not args.seq_len:
+        # (the newest profiles/r*_syrk_traffic.json; it names the kernel sources it was measured on)
+        import glob
+        import hashlib
+        tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_syrk_traffic.json")))
+        if tfiles and args.workload == "llama3-8b-block-q4k" and world == 1 and not args.calib_seqs and not args.seq_len:
+            tpath = tfiles[-1]
             try:
-                import glob
-                import hashlib
-                tj = json.load(open(tpath))  # written by profiles/collect_r04.sh
+                tj = json.load(open(tpath))  # written by profiles/collect_r05.sh
                 hsh = hashlib.sha256()
                 for fn in sorted(glob.glob(os.path.join(ROOT, "gptq-gguf-toolkit_amd", "csrc", "*.h*"))):
                     hsh.update(open(fn, "rb").read())
@@ -921,7 +937,7 @@ def main():
                     traffic = {"GB_per_launch": tj["GB_per_launch"], "algorithmic_GB_per_launch": tj.get("algorithmic_GB_per_launch"),
                                "measured_on": tj.get("measured_on"), "launches": tj.get("launches")}
                 else:
-                    traffic = {"GB_per_launch": None, "note": "profiles/r04_syrk_traffic.json was measured on other kernel "
+                    traffic = {"GB_per_launch": None, "note": f"profiles/{os.path.basename(tpath)} was measured on other kernel "
                                                               "sources than this build's: not reported"}
             except Exception:
                 traffic = None

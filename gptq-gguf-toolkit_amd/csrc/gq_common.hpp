@@ -60,6 +60,7 @@ extern thread_local char g_err[512];
     /* K5/K6 column loop */                                                                                                       \
     X(no_lookahead, 0, 0, 1)      /* 1: trailing update after every block, no chained far update */                               \
     X(la, 8, 2, 8)                /* blocks per look-ahead super-block (even, 2..8) */                                            \
+    X(seg_pair, 1, 0, 1)          /* 0: one column-loop launch per 128-column block instead of one per 256-column pair */          \
     X(near_classic, 0, 0, 1)      /* 1: a near launch after every block instead of the pair form */                               \
     X(near_quad, 0, 0, 1)         /* 1: near launches after every second pair */                                                  \
     X(near64_maxn, 768, 0, 1048576)     /* widest near update that takes gemm32_near256_kernel */                                 \

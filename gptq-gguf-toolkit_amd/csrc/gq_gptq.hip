@@ -56,7 +56,10 @@ __global__ __launch_bounds__(SEG_WAVES * 64) void gptq_segment_kernel(
     const int32_t* __restrict__ perm, const float* __restrict__ uscale = nullptr,
     const float* __restrict__ uzero = nullptr,  // PERM (act_order, gptq.py:211-216): column j takes the parameters of
                                                 // the group of its ORIGINAL column perm[j]
-    const float* __restrict__ Unext = nullptr) {  // != nullptr: U[a .. a+127][a+128 .. a+255]; epilogue below
+    const float* __restrict__ Unext = nullptr,  // != nullptr: U[a .. a+127][a+128 .. a+255]; epilogue below
+    int npair = 1) {  // 2 (r05; needs Unext, src == W + a): this launch ALSO walks the partner block a+128 .. a+255 once its
+                      // epilogue has brought this block's errors there -- every workgroup owns its 64 rows in both blocks, so
+                      // nothing but the workgroup's own stores has to be visible: one launch per 256-column group instead of two
     // One workgroup = 64 rows (lane = row) x SEG_WAVES waves.  Wave 0 walks the columns (the dependent chain) one
     // 16-column sub-block ("tile") at a time; the rank-1 updates of the later tiles run UNDER the next chain:
     //   iteration t:  wave 0: chain(t) -> -err of tile t into ne[t & 1]
@@ -76,6 +79,14 @@ __global__ __launch_bounds__(SEG_WAVES * 64) void gptq_segment_kernel(
     const int64_t row = (int64_t)blockIdx.x * 64 + lane;
     const bool live = row < R;
     const int64_t r = live ? row : 0;
+    for (int half = 0; half < npair; ++half) {
+    if (half) {  // the partner block: same rows, next 128 columns; the epilogue's stores of this workgroup are complete
+        __syncthreads();
+        a += SEG;
+        src += SEG;
+        err_col0 += SEG;
+        Unext = nullptr;
+    }
     // Two-step prologue: everything the FIRST tile's chain needs (U rows 0..15, the tile's 16 columns of W, its
     // reciprocal diagonal) is brought in by all waves, then the chain starts while waves 1..7 -- idle in
     // iteration 0 -- bring in the other 7/8 (gptq.py:225 w_blk = w[:, c1:c2].clone()).
@@ -283,6 +294,7 @@ __global__ __launch_bounds__(SEG_WAVES * 64) void gptq_segment_kernel(
             if (r0 + ro < R) wp[(int64_t)ro * C] = wv[e] + acc[e];
         }
     }
+    }  // half
 }
 
 // evopress/src/quant_utils.py:57-106 Quantizer.find_params(x, weight=True), perchannel: one wave per row of the
@@ -562,6 +574,8 @@ static int column_loop(float* W, const float* U, int64_t R, int64_t C, int q_typ
                                    hipFuncAttributeMaxDynamicSharedMemorySize, SEG_LDS_BYTES));
         seg_attr = true;
     }
+    const bool seg_pair = opt(OPT_seg_pair) != 0;
+    bool walked_by_partner = false;  // this block's columns were walked by the previous (even) block's launch
     for (int64_t c1 = 0; c1 < C; c1 += B) {  // gptq.py:222
         const int64_t c2 = c1 + B < C ? c1 + B : C;
         // one segment iff the block fits in LDS and stays inside one 256-column super-group
@@ -583,7 +597,8 @@ static int column_loop(float* W, const float* U, int64_t R, int64_t C, int q_typ
             hipLaunchKernelGGL(copy2d_kernel, dim3(2048), dim3(256), 0, st, Wblk, B, W + c1, C, R, ncols);
             GQ_LAUNCH_CHECK();
         }
-        int64_t a = c1;
+        int64_t a = walked_by_partner ? c2 : c1;
+        walked_by_partner = false;
         while (a < c2) {
             // a segment never crosses a 256-column super-group boundary: the lazy
             // scale search (gptq.py:240-245) must see W as it is at that column.
@@ -603,6 +618,9 @@ static int column_loop(float* W, const float* U, int64_t R, int64_t C, int q_typ
             const float* unext = (pair_look && single && len == SEG && !(pos & 1) && c2 + B <= C) ? U + a * C + a + SEG : nullptr;
             const float* srcp = single ? (W + a) : (Wblk + (a - c1));
             const int64_t ld_src = single ? C : B;
+            // the partner block in the same launch (it is a whole single segment too: B == SEG, c2 + B <= C)
+            const int npair = (unext && seg_pair && !uni && B == SEG) ? 2 : 1;
+            walked_by_partner = npair == 2;
             {
                 ProfScope ps(PT_GPTQ_SEGMENT, st);
                 if (uni)
@@ -612,11 +630,11 @@ static int column_loop(float* W, const float* U, int64_t R, int64_t C, int q_typ
                 else if (perm)
                     hipLaunchKernelGGL(gptq_segment_kernel<true>, seg_grid, seg_block, SEG_LDS_BYTES, st, W, C, srcp, ld_src, U, a,
                                        len, R, d, s, dmin, m, ti.group, ti.is_signed, (float)ti.qmin, (float)ti.qmax, qweight, Err,
-                                       ldE, pos * B + (a - c1), perm, nullptr, nullptr, unext);
+                                       ldE, pos * B + (a - c1), perm, nullptr, nullptr, unext, npair);
                 else
                     hipLaunchKernelGGL(gptq_segment_kernel<false>, seg_grid, seg_block, SEG_LDS_BYTES, st, W, C, srcp, ld_src, U, a,
                                        len, R, d, s, dmin, m, ti.group, ti.is_signed, (float)ti.qmin, (float)ti.qmax, qweight, Err,
-                                       ldE, pos * B + (a - c1), perm, nullptr, nullptr, unext);
+                                       ldE, pos * B + (a - c1), perm, nullptr, nullptr, unext, npair);
                 GQ_LAUNCH_CHECK();
             }
             if (e < c2) {  // push this segment's rank-1 updates into the rest of the block

@@ -109,7 +109,8 @@ const char* gq_last_error(void);
      chol_planes [2] 2 = row-scaled fp16 x 2, 3 = bf16 x 3 (tolerance class) | chol_3b_min [1024] | chol_fp32 [0] fp32 MFMA only
      (tolerance class) | chol_no_pair [0] | chol_no_equil [0] | chol_poison [0] NaN-fill scratch that must not be read |
      diag_ref [0] column-by-column leaf kernel (tolerance class)
-     no_lookahead [0] | la [8] blocks per super-block | near_classic [0] | near_quad [0] | near64_maxn [768] | far_sync [0] |
+     no_lookahead [0] | la [8] blocks per super-block | seg_pair [1] one column-loop launch per 256-column pair of blocks (0: per
+     block) | near_classic [0] | near_quad [0] | near64_maxn [768] | far_sync [0] |
      far_async_max_rows [8192] | far_async_min_sb [8] | far_wgs [192] | far_bdma [1] far GEMM B operand by LDS-DMA (0: registers + ds_write) |
      chain_generic [0] | gemm32_64_max [256]
      ss_wide [-1] scale-search mapping: -1 by size, 1 eight lanes, 0 one lane, 2 a lane pair per group

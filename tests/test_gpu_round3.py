@@ -291,7 +291,8 @@ def test_trailing_update_kernel_choices_are_bit_identical():
     from conftest import ROOT
     hashes = {}
     for tag, opts in (("default", ""), ("near128", "near64_maxn=0"), ("classic", "near_classic"), ("generic_far", "chain_generic=1"),
-                      ("quad", "near_quad=1"), ("far_b_by_dma", "far_bdma=1"), ("far_b_by_registers", "far_bdma=0")):
+                      ("quad", "near_quad=1"), ("far_b_by_dma", "far_bdma=1"), ("far_b_by_registers", "far_bdma=0"),
+                      ("one_launch_per_block", "seg_pair=0")):  # r05: default = one column-loop launch per 256-column pair
         env = dict(os.environ, GQ_OPTIONS=opts)
         p = subprocess.run([sys.executable, "-c", _LOOP_HASH.format(root=ROOT)], env=env, capture_output=True, text=True,
                            timeout=600)

@@ -1363,12 +1363,14 @@ def test_four_rank_row_split_equals_owner_mode_even_when_a_slice_has_no_valid_gr
     world = 4
     mgr = mp.Manager()
     got = {}
-    for k, (mode, tiny) in enumerate((("0", True), ("all", True), ("all", False), ("0", False))):
+    # (the handle-level path runs the corner case only: the CPU suite's budget)
+    configs = (("0", True), ("all", True), ("all", False), ("0", False)) if via_schedule else (("0", True), ("all", True))
+    for k, (mode, tiny) in enumerate(configs):
         ret = mgr.dict()
         mp.spawn(_worker_rowsplit_corner, args=(world, 34000 + 11 * k + os.getpid() % 2000, ret, mode, tiny, via_schedule),
                  nprocs=world, join=True)
         got[(mode, tiny)] = [ret[r] for r in range(world)]
-    for tiny in (True, False):
+    for tiny in (True, False) if via_schedule else (True,):
         ref = got[("0", tiny)][0][0]
         for r in range(world):
             for mode in ("0", "all"):
@@ -1377,13 +1379,13 @@ def test_four_rank_row_split_equals_owner_mode_even_when_a_slice_has_no_valid_gr
     for r in range(world):
         res, redone, coll, calls, owners = got[("all", True)][r]
         assert redone == 1 and calls["gptq_quantize_slice"] == 1 and calls["gptq_quantize"] == 2  # the slice, then the whole matrix
-        res, redone, coll, calls, owners = got[("all", False)][r]
-        assert redone == 0 and calls["gptq_quantize_slice"] == 1 and calls["gptq_quantize"] == 1
         if via_schedule:
+            res, redone, coll, calls, owners = got[("all", False)][r]
+            assert redone == 0 and calls["gptq_quantize_slice"] == 1 and calls["gptq_quantize"] == 1
             assert owners == {"down": "rows/4"}
             assert (coll["all_gather"], coll["broadcast"], coll.get("small_all_reduce", 0)) == (1, 0, 0), coll
         else:
-            assert coll["small_all_reduce"] == 1 and coll["all_gather"] == 5, coll
+            assert coll["small_all_reduce"] == 1 and coll["all_gather"] == 0, coll  # redone: no slices to gather
     # the corner is real: without the fallback rank 1's slice result differs from the whole matrix's rows
     import fake_ops
     from oracle import oracle as O
