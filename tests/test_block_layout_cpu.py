@@ -132,8 +132,42 @@ def test_environment_variables_are_few_and_documented():
         assert not re.findall(r"^\s*#\s*(?:ifdef|ifndef|if)\b", src, re.M), f"{os.path.basename(f)}: preprocessor conditionals in a shipped kernel source"
 
 
+def test_committed_r05_bench_lines():
+    """The round's five collections (profiles/collect_r05.sh): the full dict and the compact headline of each BASELINE config that
+    fits one GPU; the compact line carries the driver contract and stays under 2 KB; the traffic figure belongs to the kernel
+    sources it names."""
+    import glob
+    import hashlib
+    import json
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r05_bench_*_compact.json")))
+    assert len(files) == 5
+    for f in files:
+        raw = open(f).read().strip()
+        assert len(raw) <= 2048, (f, len(raw))
+        c = json.loads(raw)
+        full = json.loads(open(f.replace("_compact.json", ".json")).read())
+        for k, t in (("metric", str), ("value", (int, float)), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                     ("ms_per_step", (int, float)), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str)):
+            assert isinstance(c[k], t) and c[k] == full[k], (f, k)
+        assert c["vs_baseline"] is None and "workload" in c["config"] and "model" not in c["config"]
+        r = c["roofline"]
+        assert r["bound"] == "mfma" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["trailing_far_alone_frac"] > 0.5
+        assert all(not isinstance(v, (dict, list)) for v in r.values())
+        assert c["cpu_baseline"]["kind"] == "port" and c["cpu_baseline"]["cores"] >= 1 and c["cpu_baseline"]["value"] > 0
+        assert full["encoders"]["launches"]["gptq_segment"] <= full["encoders"]["launches"]["scale_search"]  # one launch per pair
+    d = json.loads(open(os.path.join(ROOT, "profiles", "r05_bench_llama3-8b-block-q4k_compact.json")).read())
+    assert d["roofline"]["traffic"] > d["roofline"]["traffic_algorithmic"] > 0 and d["roofline"]["frac_on_model_forward_activations"] > 0.4
+    assert d["whole_model_wall_s"] < d["whole_model_hf_eager_wall_s"]
+    tj = json.load(open(os.path.join(ROOT, "profiles", "r05_syrk_traffic.json")))
+    h = hashlib.sha256()
+    for fn in sorted(glob.glob(os.path.join(ROOT, "gptq-gguf-toolkit_amd", "csrc", "*.h*"))):
+        h.update(open(fn, "rb").read())
+    # (a later edit of a kernel source makes bench.py report traffic = null until collect_r05.sh is run again: say so here)
+    assert tj["kernel_sources_sha256"] == h.hexdigest()[:16], "csrc changed after the traffic pass: re-run profiles/collect_r05.sh"
+
+
 def test_committed_bench_lines_keep_the_driver_contract():
-    """The five committed lines of the round (profiles/r04_bench_<workload>.json, written by bench.py on the GPU box) carry every
+    """The five committed lines of round 4 (profiles/r04_bench_<workload>.json, written by bench.py on the GPU box) carry every
     key of the driver's contract with the right types, the two objects of the hot-path tier (roofline, cpu_baseline) and the
     section-8(d) figures added in r04 -- a guard against a bench.py edit that silently drops one."""
     import glob
