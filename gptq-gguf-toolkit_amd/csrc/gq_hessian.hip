@@ -124,6 +124,14 @@ struct SyrkGroup {
     // of XCD x that finished a round; a round starts when all of them have, so the 32 tiles an XCD works on at a
     // time stay in step and share their 12 operand panels through the XCD's L2.  nullptr: one tile per workgroup.
     unsigned* bar;
+    // syrk16_256w_kernel (r05): soft XCD rendezvous INSIDE a tile, every `ck` half-stages (a power of two; 0: none).  Between
+    // the round-start rendezvous the 32 workgroups of an XCD drift apart by more than the ~20 half-stages of panels their 4 MB
+    // L2 holds, and a panel byte that should be fetched once per XCD is fetched again from the fabric: the kernel is bound by
+    // exactly that delivery (profiles/r05_syrk_decompose.txt; zeros, C = 14336: 1.34 -> 1.76 PFLOP/s with ck = 256).  bar[8 + x]
+    // counts checkpoint arrivals of XCD x; every workgroup contributes exactly `nck` per round (the checkpoints it passes, the
+    // rest when its unit ends, all of them when it has no unit), so checkpoint k of round r waits for (r nck + k) x workgroups
+    // -- at most ~4 us: peers that are not resident can never hang it, and results do not depend on it.
+    int ck, nck;
 };
 
 template <bool BF16>
@@ -1055,7 +1063,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     const uint32_t ent = (uint32_t)__builtin_amdgcn_readfirstlane((int)grp.table[(blockIdx.x & 7) * grp.per_xcd + slot]);
     if (ent == 0xffffffffu) {
-        if (grp.bar) continue;
+        if (grp.bar) {
+            if (grp.ck && tid == 0)
+                __hip_atomic_fetch_add(grp.bar + 8 + (blockIdx.x & 7), (unsigned)grp.nck, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            continue;
+        }
         break;
     }
     const uint32_t aux = grp.aux ? (uint32_t)__builtin_amdgcn_readfirstlane((int)grp.aux[(blockIdx.x & 7) * grp.per_xcd + slot])
@@ -1146,13 +1158,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
     w.first_fragments();
+    const int ck = grp.bar ? grp.ck : 0;
     for (int n = 0; n < nhs; n += 4) {  // nhs % 4 == 0
+        if (ck && n && (n & (ck - 1)) == 0 && tid == 0) {  // checkpoint n / ck of this round (SyrkGroup::ck)
+            unsigned* b2 = grp.bar + 8 + (blockIdx.x & 7);
+            __hip_atomic_fetch_add(b2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned want = ((unsigned)round * (unsigned)grp.nck + (unsigned)(n / ck)) * (gridDim.x >> 3);
+            for (int spin = 0; spin < 32 && __hip_atomic_load(b2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want; ++spin)
+                __builtin_amdgcn_s_sleep(4);
+        }
         w.template step<0>(); GQ_WADV();
         w.template step<1>(); GQ_WADV();
         w.template step<2>(); GQ_WADV();
         w.template step<3>(); GQ_WADV();
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+    if (ck && tid == 0) {  // what this unit did not pass of the round's nck checkpoints (K-split units are shorter)
+        const int passed = (nhs - 1) / ck;
+        if (grp.nck > passed)
+            __hip_atomic_fetch_add(grp.bar + 8 + (blockIdx.x & 7), (unsigned)(grp.nck - passed), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 #undef GQ_WADV
     float* __restrict__ H = P.H;
     const float beta = P.beta, alpha = P.alpha;
@@ -1349,6 +1374,8 @@ static int syrk16_launch(int kind, const int* idx, int m, float* const* H, const
     grp.aux = nullptr;
     grp.partial = nullptr;
     grp.bar = nullptr;
+    grp.ck = 0;
+    grp.nck = 0;
     int n_reduce = 0;
     const uint32_t* reduce_list = nullptr;
     std::vector<uint32_t> table;
@@ -1424,7 +1451,16 @@ static int syrk16_launch(int kind, const int* idx, int m, float* const* H, const
         size_t bar_at = 0;
         if (kind == 2 && persist && per_xcd > 32) {
             bar_at = table.size();
-            for (int x = 0; x < 8; ++x) table.push_back(0u);
+            for (int x = 0; x < 16; ++x) table.push_back(0u);  // [0..7] rounds, [8..15] checkpoints inside a tile
+            // checkpoints: only when every problem of the launch walks the same number of half-stages (a dense block's inputs do;
+            // MoE experts with their own token counts do not)
+            int64_t ck = opt(OPT_syrk_ck);
+            bool same = (ck & (ck - 1)) == 0 && ck >= 16 && opt(OPT_syrk_w4) != 0;
+            for (int k = 1; k < m && same; ++k) same = grp.p[k].Tp == grp.p[0].Tp;
+            if (same && grp.p[0].Tp / 32 > ck) {
+                grp.ck = (int)ck;
+                grp.nck = (int)((grp.p[0].Tp / 32 - 1) / ck);
+            }
         }
         if (table.size() & 1) table.push_back(0xffffffffu);
         for (int k = 0; k < m && segs; ++k) {

@@ -41,6 +41,17 @@ if rows:
     print(f"{len(rows)} SYRK launches, {per:.2f} GB per launch (algorithmic {alg:.2f})")
 PY
 rm -rf $OUT/pmc_fetch
+# the same pass without the rendezvous inside a tile (option syrk_ck = 0): what the checkpoints save in fabric reads
+timeout 600 env GQ_OPTIONS=syrk_ck=0 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch0 -o p -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-whole-model --no-side-legs > $OUT/pmc_fetch0.log 2>&1 || echo "pmc pass (syrk_ck=0) failed"
+python3 - <<PY
+import csv, glob
+v = [float(r["Counter_Value"]) for f in glob.glob("$OUT/pmc_fetch0/**/*counter_collection.csv", recursive=True)
+     for r in csv.DictReader(open(f)) if "syrk16" in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE"]
+if v:
+    open("$OUT/r05_syrk_traffic_ck0.txt", "w").write(f"GQ_OPTIONS=syrk_ck=0: {len(v)} SYRK launches, {sum(v) * 2048 / 1e9 / len(v):.2f} GB of L2-miss reads per launch\n")
+    print(open("$OUT/r05_syrk_traffic_ck0.txt").read().strip())
+PY
+rm -rf $OUT/pmc_fetch0
 cp $OUT/r05_syrk_traffic.json $R/profiles/r05_syrk_traffic.json  # bench.py reads it (and checks the source hash)
 for W in $WLS; do
   EXTRA=""
