@@ -1187,20 +1187,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int rl0 = wm * 128 + 4 * lk, cl0 = wn * 128 + lr;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
+        if (Pp) {  // K-split unit: raw sums, combined in fixed order by syrk_reduce_kernel
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const f32x4 v = w.c[i][j];
+                float* q_ = Pp + (rl0 + i * 16) * BT + cl0 + j * 16;
+                q_[0] = v[0]; q_[BT] = v[1]; q_[2 * BT] = v[2]; q_[3 * BT] = v[3];
+            }
+            continue;
+        }
+        // r05: the 32 loads of a row of accumulator tiles are in flight together (one exposed HBM round trip per row instead of one
+        // per tile: the epilogue was 3-6 % of a launch on un-capped operands); same values, same operations per element
+        const int64_t row = i0 + i * 16;
+        float hv[8][4];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t col = j0 + j * 16;
+            hv[j][0] = H[(row + 0) * C + col]; hv[j][1] = H[(row + 1) * C + col];
+            hv[j][2] = H[(row + 2) * C + col]; hv[j][3] = H[(row + 3) * C + col];
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const f32x4 v = w.c[i][j];
-            if (Pp) {  // K-split unit: raw sums, combined in fixed order by syrk_reduce_kernel
-                float* q_ = Pp + (rl0 + i * 16) * BT + cl0 + j * 16;
-                q_[0] = v[0]; q_[BT] = v[1]; q_[2 * BT] = v[2]; q_[3 * BT] = v[3];
-                continue;
-            }
-            const int64_t col = j0 + j * 16, row = i0 + i * 16;
+            const int64_t col = j0 + j * 16;
             float4 h;
-            h.x = beta * H[(row + 0) * C + col] + alpha * v[0];
-            h.y = beta * H[(row + 1) * C + col] + alpha * v[1];
-            h.z = beta * H[(row + 2) * C + col] + alpha * v[2];
-            h.w = beta * H[(row + 3) * C + col] + alpha * v[3];
+            h.x = beta * hv[j][0] + alpha * v[0];
+            h.y = beta * hv[j][1] + alpha * v[1];
+            h.z = beta * hv[j][2] + alpha * v[2];
+            h.w = beta * hv[j][3] + alpha * v[3];
             H[(row + 0) * C + col] = h.x; H[(row + 1) * C + col] = h.y;
             H[(row + 2) * C + col] = h.z; H[(row + 3) * C + col] = h.w;
             if (ti != tj) *reinterpret_cast<float4*>(H + col * C + row) = h;

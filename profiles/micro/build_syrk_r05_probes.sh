@@ -7,6 +7,9 @@
 #   nomfma_nord  no v_mfma, no ds_read: the LDS-DMA ring and its barrier alone = what the L2 -> LDS path delivers
 #   nodma        MFMAs + fragment reads on a ring that is never refilled (prologue only): the compute side alone
 #   nord         MFMAs + DMA, no fragment reads (stale registers): without the LDS read traffic
+#   hotdma       the shipped loop whose DMA base never advances: every half-stage re-reads the first 32 token rows (L2-resident):
+#                the DMA instructions, their LDS writes and everything else stay, the memory side behind the L2 is taken out
+#   noepi        no epilogue (H neither read nor written)        norv   persistent rounds without the round-start XCD rendezvous
 R=$(cd "$(dirname "$0")/../.." && pwd)
 B=$R/profiles/micro/_build
 mkdir -p $B/src/csrc $B/include
@@ -17,7 +20,7 @@ for f in gq_api gq_codec gq_scale_search gq_gptq gq_cholesky gq_forward; do
   /opt/rocm/bin/hipcc $FLAGS -c $B/src/csrc/$f.hip -o $B/$f.o &
 done
 wait
-VARS="nomfma nomfma_nord nodma nord"
+VARS="nomfma nomfma_nord nodma nord hotdma noepi norv"
 for V in $VARS; do
   S=$B/src/csrc/gq_hessian_$V.hip
   cp $R/gptq-gguf-toolkit_amd/csrc/gq_hessian.hip $S
@@ -40,6 +43,22 @@ if v in ("nomfma_nord", "nord"):
 if v == "nodma":
     body = body.replace("if constexpr (S.dma[M] >= 0) {  // a DMA piece of half-stage n+3", "if constexpr (false && S.dma[M] >= 0) {", 1)
 s = s[:a] + body + s[b:]
+ka = s.index("void syrk16_256w_kernel(const SyrkGroup grp) {")
+kb = s.index("// K-split tiles: H tile = beta", ka)
+kern = s[ka:kb]
+if v == "hotdma":
+    old = "        if (hnext + 1 < nhs) {                                                                        \\"
+    assert kern.count(old) == 1
+    kern = kern.replace(old, "        if (false && hnext + 1 < nhs) {                                                               \\")
+if v == "noepi":
+    old = "    for (int i = 0; i < 8; ++i) {\n#pragma unroll\n        for (int j = 0; j < 8; ++j) {\n            const f32x4 v = w.c[i][j];"
+    assert kern.count(old) == 1
+    kern = kern.replace(old, old + "\n            if (v[0] != 12345.678f) continue;")
+if v == "norv":
+    old = "if (grp.bar && round > 0) {"
+    assert kern.count(old) == 1
+    kern = kern.replace(old, "if (false && grp.bar && round > 0) {")
+s = s[:ka] + kern + s[kb:]
 open(p, "w").write(s)
 PY
   /opt/rocm/bin/hipcc $FLAGS -c $S -o $B/gq_hessian_$V.o &

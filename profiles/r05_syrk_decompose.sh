@@ -5,12 +5,13 @@
 # the matrix pipe run.  usage (GPU box): bash profiles/r05_syrk_decompose.sh > gpurun_out/r05_syrk_decompose.txt
 cd "$(dirname "$0")/.."
 B=profiles/micro/_build
-for rep in 1 2; do
+# Both with the rendezvous inside a tile the round added (default, syrk_ck = 256) and without it (syrk_ck = 0: the r04 kernel).
+for ck in 0 256; do
   for data in zeros random; do
-    for v in shipped nomfma_nord nomfma nord nodma; do
+    for v in shipped nomfma_nord nomfma nord nodma hotdma noepi norv; do
       so=""; [ $v != shipped ] && so=$PWD/$B/libgq_$v.so
-      a=$(GQ_SO_PATH=$so DATA=$data CS=14336 ITERS=8 python profiles/syrk_probe.py 2>/dev/null | tail -3 | awk '{printf "%s ", $5}')
-      echo "[$data] [$v] C=14336: $a TFLOP/s"
+      a=$(GQ_OPTIONS=syrk_ck=$ck GQ_SO_PATH=$so DATA=$data CS=14336 ITERS=8 python profiles/syrk_probe.py 2>/dev/null | tail -3 | awk '{printf "%s ", $5}')
+      echo "[syrk_ck=$ck] [$data] [$v] C=14336: $a TFLOP/s"
     done
   done
 done
