@@ -87,6 +87,8 @@ if os.environ.get("TIME", "1") == "1":
         for n in (7168, 3584, 1792):
             A = torch.randn(n, n, device=dev)
             X = torch.tril(torch.randn(n, n, device=dev))
+            if os.environ.get("DATA") == "zeros":  # no power cap: the kernel's structural rate
+                A.zero_(); X.zero_()
             Cm = torch.zeros(n, n, device=dev)
             for name, args, flops in [("G1 A X^T kr1", (Cm, A, X, True, 1, 1, False), n ** 3),
                                       ("G2 syrk lower", (Cm, A, A, True, 0, 0, True), n ** 3),

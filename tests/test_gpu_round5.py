@@ -103,3 +103,49 @@ def test_slice_entry_counts_panel_researches_like_the_oracle():
         cnt = O.panel_researches(reset=True)
         assert int(n.item()) == cnt and (cnt > 0) == want_positive, (int(n.item()), cnt)
         assert (q.cpu().numpy() == oq).all() and (s.cpu().numpy() == os_).all() and (m.cpu().numpy() == om).all()
+
+
+# ----------------------------------------------------------------- RCCL API surface (what one GPU can show)
+_RCCL_ONE = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, {root!r})
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT={port!r}, RANK="0", WORLD_SIZE="1")
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", device_id=dev)            # bench.py / quant.py: exactly this call
+from gptq_gguf_toolkit_amd import dist_utils
+assert dist.get_backend() == "nccl"
+C = 1024
+H = torch.randn(C, C, device=dev); H = H + H.T
+ref = H.clone()
+# the calls the N > 1 path issues, forced past the world-size-1 shortcuts: payload dtypes, ops and tensor forms RCCL must take
+from gptq_gguf_toolkit_amd import ops
+p = ops.h_pack_upper(H)
+dist.all_reduce(p, op=dist.ReduceOp.AVG)                   # gptq.py:131-132
+dist.reduce(p, dst=0, op=dist.ReduceOp.AVG)                # reduce to owner
+dist.reduce(p, dst=0, op=dist.ReduceOp.SUM)
+ops.h_unpack_upper(p, H)
+assert torch.equal(H, ref)
+cnt = torch.zeros(1, dtype=torch.float64, device=dev); dist.all_reduce(cnt, op=dist.ReduceOp.SUM)      # MoE sample counts
+n32 = torch.zeros(1, dtype=torch.int32, device=dev); dist.all_reduce(n32, op=dist.ReduceOp.SUM)        # row-split re-search counts
+buf = (torch.arange(4096, device=dev) % 251).to(torch.uint8)
+out = dist_utils.all_gather_bytes(buf, 4096)               # ONE all-gather per block: uint8 all_gather_into_tensor
+assert out.shape == (1, 4096) and torch.equal(out[0], buf)
+lo = torch.ones(1, device=dev, dtype=torch.float64); dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(lo, op=dist.ReduceOp.MAX)
+box = ["x"]; dist.broadcast_object_list(box, src=0)        # bench.py whole-model leg: the save directory
+dist.barrier(); torch.cuda.synchronize()
+dist.destroy_process_group()
+print("RCCL-ONE-OK")
+"""
+
+
+def test_rccl_collectives_the_path_issues_are_accepted_on_one_rank():
+    """N > 1 over RCCL has never been observed (one GPU per box).  What one GPU can show: every collective CALL the N > 1 path
+    issues -- backend init with device_id, all_reduce / reduce with AVG on the packed fp32 Hessian tiles, fp64 and int32 SUM,
+    uint8 all_gather_into_tensor, MIN / MAX, broadcast_object_list, barrier -- is accepted by RCCL with these dtypes and ops
+    (a one-rank communicator), so that the first multi-GPU lease cannot die on an unsupported call."""
+    code = _RCCL_ONE.format(root=ROOT, port=str(38000 + os.getpid() % 2000))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "RCCL-ONE-OK" in p.stdout, p.stderr[-3000:]
