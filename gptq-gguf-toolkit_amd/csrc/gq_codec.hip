@@ -345,17 +345,53 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t* __restrict__ q
         }
         __syncthreads();
         constexpr int NDW = TS / 4;  // whole dwords of a block; TS % 4 == 2 (Q3_K, Q6_K): the fp16 d follows
-        for (int i = tid; i < nb * NDW; i += 256) {
-            const int b = i / NDW, w = i % NDW;
-            const uint32_t v = pack_dword<QT>(sq + b * 256, ss + b * NG, sm + b * NG, sd[b], sdm[b], w);
-            uint8_t* dst = so + b * TS + 4 * w;
-            if ((TS % 4 == 0) || !(b & 1)) {
-                *reinterpret_cast<uint32_t*>(dst) = v;
-            } else {  // odd block of a 110- / 210-byte layout: 2-byte aligned
-                reinterpret_cast<uint16_t*>(dst)[0] = (uint16_t)v;
-                reinterpret_cast<uint16_t*>(dst)[1] = (uint16_t)(v >> 16);
+        if constexpr (TS % 4 == 0) {
+            // r05: 84- / 144- / 176-byte blocks are whole dwords and the workgroup's output region is contiguous: thread i's
+            // dword IS output dword i -- stored straight to global memory (coalesced 4-byte stores), no LDS image of the
+            // output, one barrier and one pass fewer
+            uint32_t* op32 = reinterpret_cast<uint32_t*>(out + b0 * TS);
+            if constexpr (QT == GQ_Q4_K || QT == GQ_Q5_K) {
+                // the 4 header dwords of a block (d | dmin, 12 scale / min bytes assembled byte by byte) take a long path:
+                // in one index space every wave carries a few of them and all its lanes wait -- body dwords first (one
+                // uniform path), the headers in a pass of their own
+                constexpr int HD = 4, BD = NDW - HD;
+                for (int i = tid; i < nb * BD; i += 256) {
+                    const int b = i / BD, w = HD + i % BD;
+                    op32[b * NDW + w] = pack_dword<QT>(sq + b * 256, ss + b * NG, sm + b * NG, sd[b], sdm[b], w);
+                }
+                for (int i = tid; i < nb * HD; i += 256) {
+                    const int b = i / HD, w = i % HD;
+                    op32[b * NDW + w] = pack_dword<QT>(sq + b * 256, ss + b * NG, sm + b * NG, sd[b], sdm[b], w);
+                }
+            } else {
+                for (int i = tid; i < nb * NDW; i += 256) {
+                    const int b = i / NDW, w = i % NDW;
+                    op32[i] = pack_dword<QT>(sq + b * 256, ss + b * NG, sm + b * NG, sd[b], sdm[b], w);
+                }
             }
+            __syncthreads();
+            continue;
         }
+        // (r05) one pass per KIND of dword -- Q3_K: hmask 8 | qs 16 | scales 3 (byte-wise); Q6_K: ql 32 | qh 16 | scales 4 -- so that
+        // every wave runs one code path (in one index space each wave carried all kinds and its lanes waited for the longest)
+        constexpr int W1 = QT == GQ_Q3_K ? 8 : (QT == GQ_Q6_K ? 32 : NDW), W2 = QT == GQ_Q3_K ? 24 : (QT == GQ_Q6_K ? 48 : NDW);
+        auto pass = [&](int w0, int w1) {
+            const int nw = w1 - w0;
+            for (int i = tid; i < nb * nw; i += 256) {
+                const int b = i / nw, w = w0 + i % nw;
+                const uint32_t v = pack_dword<QT>(sq + b * 256, ss + b * NG, sm + b * NG, sd[b], sdm[b], w);
+                uint8_t* dst = so + b * TS + 4 * w;
+                if ((TS % 4 == 0) || !(b & 1)) {
+                    *reinterpret_cast<uint32_t*>(dst) = v;
+                } else {  // odd block of a 110- / 210-byte layout: 2-byte aligned
+                    reinterpret_cast<uint16_t*>(dst)[0] = (uint16_t)v;
+                    reinterpret_cast<uint16_t*>(dst)[1] = (uint16_t)(v >> 16);
+                }
+            }
+        };
+        pass(0, W1);
+        if constexpr (W1 < NDW) pass(W1, W2);
+        if constexpr (W2 < NDW) pass(W2, NDW);
         if constexpr (TS % 4 != 0) {
             if (tid < nb) *reinterpret_cast<uint16_t*>(so + tid * TS + 4 * NDW) = sd[tid];
         }

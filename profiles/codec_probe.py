@@ -16,7 +16,7 @@ def timeit(fn, n=20):
 torch.manual_seed(0)
 R, C = 4096, 14336
 W = (torch.randn(R, C, device="cuda") * 0.02).half()
-for t in (12, 10, 14):
+for t in (12, 10, 14, 11, 13):
     q, d, s, dmin, m = ops.rtn_quantize(W, t)
     G = 32 if t in (12, 13) else 16
     aux = R * (C // 256) * 4 + 2 * R * (C // G)                     # d, dmin fp16 + s, m bytes
