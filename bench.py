@@ -512,32 +512,42 @@ def cpu_baseline(wl, W16, keep):
         old_threads = torch.get_num_threads()
         torch.set_num_threads(threads)
         try:
-            Cs, Ls, ns = 4096, 2048, 8
+            # GPTQ.update measured at EVERY distinct width of the block (a few sequences each: ~1 s per width), scaled by the
+            # token count only; the chain at the narrowest width, scaled by C^3
             g = torch.Generator().manual_seed(0)
-            Xs = [torch.randn(Ls, Cs, generator=g).half() for _ in range(ns)]
-            H = torch.zeros(Cs, Cs)
-            t0 = time.perf_counter()
-            for i, x in enumerate(Xs):  # gptq.py:96-112 per calibration sample
-                xf = x.float()
-                H.addmm_(xf.T, xf, beta=i / (i + 1), alpha=2.0 / (i + 1))
-            t_h = time.perf_counter() - t0
-            H.diagonal().add_(0.01 * H.diagonal().mean())
-            t0 = time.perf_counter()
-            torch.linalg.cholesky(torch.cholesky_inverse(torch.linalg.cholesky(H)), upper=True)  # :318-320
-            t_c = time.perf_counter() - t0
+            Ls = 2048
+            widths = sorted({shapes[n][1] for n in names})
+            t_upd, upd_note = {}, []
+            for Cw in widths:
+                nsq = max(1, min(8, int(8 * (4096.0 / Cw) ** 2 + 0.5)))
+                Xs = [torch.randn(Ls, Cw, generator=g).half() for _ in range(nsq)]
+                H = torch.zeros(Cw, Cw)
+                t0 = time.perf_counter()
+                for i, x in enumerate(Xs):  # gptq.py:96-112 per calibration sample
+                    xf = x.float()
+                    H.addmm_(xf.T, xf, beta=i / (i + 1), alpha=2.0 / (i + 1))
+                t_upd[Cw] = (time.perf_counter() - t0) / (nsq * Ls)  # seconds per token at this width
+                upd_note.append(f"{nsq} x {Ls} tokens x {Cw} channels {t_upd[Cw] * nsq * Ls:.2f} s")
+                if Cw == widths[0]:
+                    Cs = Cw
+                    H.diagonal().add_(0.01 * H.diagonal().mean())
+                    t0 = time.perf_counter()
+                    torch.linalg.cholesky(torch.cholesky_inverse(torch.linalg.cholesky(H)), upper=True)  # :318-320
+                    t_c = time.perf_counter() - t0
+                del Xs, H
         finally:
             torch.set_num_threads(old_threads)
         T_full = wl["nseq"] * wl["L"]
-        h_scale = sum(float(T_full) * shapes[n][1] ** 2 for n in names) / (float(ns * Ls) * Cs ** 2)
+        t_h_total = sum(float(T_full) * t_upd[shapes[n][1]] for n in names)  # the reference accumulates one Hessian per Linear
         c_scale = sum(float(shapes[n][1]) ** 3 for n in names) / float(Cs) ** 3
-        est = {"update_s": t_h * h_scale, "prepare_chain_s": t_c * c_scale, "step_s": dt, "dequantize_pack_s": dt_codec}
+        est = {"update_s": t_h_total, "prepare_chain_s": t_c * c_scale, "step_s": dt, "dequantize_pack_s": dt_codec}
         total = sum(est.values())
         return {"value": round(tot / total / 1e6, 4), "unit": "Mparams/s", "cores": threads, "kind": "port",
                 "sample": f"full path of {len(names)} of the block's {len(shapes)} Linears ({'/'.join(names)}, {tot / 1e6:.1f} M "
                           f"params): GPTQ.step {dt:.1f} s and dequantize + pack {dt_codec:.1f} s measured in full (the oracle's C "
                           f"restatement; ints equal to the GPU's: {same / cnt:.6f}); GPTQ.update measured as the reference's "
-                          f"own fp32 addmm on {ns} x {Ls} tokens x {Cs} channels ({t_h:.2f} s) and scaled x{h_scale:.0f} by "
-                          f"flops to the block's {len(names)} Hessians of {T_full} tokens; the Cholesky chain measured as "
+                          f"own fp32 addmm at every width of the block ({'; '.join(upd_note)}) and scaled by TOKENS only to the "
+                          f"block's {len(names)} Hessians of {T_full} tokens; the Cholesky chain measured as "
                           f"the reference's torch calls at C = {Cs} ({t_c:.2f} s) and scaled x{c_scale:.1f} by C^3",
                 "stages_s_per_block": {k: round(v, 2) for k, v in est.items()},
                 "step_only": {"value": round(tot / dt / 1e6, 3), "unit": "Mparams/s",
