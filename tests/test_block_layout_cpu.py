@@ -228,3 +228,25 @@ def test_bench_compact_line_and_self_launch_refusal():
     if not __import__("torch").cuda.is_available():
         p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True)
         assert p.returncode != 0 and "RCCL needs one GPU per rank" in p.stderr and "{" not in p.stdout
+
+
+def test_gq_options_errors_fail_every_entry_point_without_abort():
+    """GQ_OPTIONS with an unknown name, a non-integer value or a value outside the option's range must not silently
+    become 0 / the default and must not abort() the host process: every entry point fails with GQ_E_UNSUPPORTED and a
+    message (here: gq_option_get; the compute entries run the same check first); gq_option_set validates ranges too."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from gptq_gguf_toolkit_amd import _cabi\n"
+            "try:\n    print('VALUE', _cabi.option_get('la'))\n"
+            "except _cabi.GQError as e:\n    print('ERR', e)\n") % ROOT
+    for env_val, want in (("la=abc", "not an integer"), ("far_wgs=", "not an integer"), ("la=3", "must be even"),
+                          ("la=64", "outside"), ("no_such=1", "unknown option"), ("la=4,syrk_ck=128", "VALUE 4")):
+        p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GQ_OPTIONS=env_val), capture_output=True, text=True)
+        assert p.returncode == 0 and want in p.stdout, (env_val, p.stdout, p.stderr[-500:])
+    from gptq_gguf_toolkit_amd import _cabi
+    with pytest.raises(_cabi.GQError, match="must be even"):
+        _cabi.option_set("la", 5)
+    with pytest.raises(_cabi.GQError, match="outside"):
+        _cabi.option_set("chol_planes", 7)
+    assert _cabi.option_default("syrk_ck") == 256 and _cabi.option_default("seg_pair") == 1
