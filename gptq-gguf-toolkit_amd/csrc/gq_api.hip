@@ -86,6 +86,15 @@ const char* opt_range_error(int i, int64_t v, char* buf, size_t n) {
         snprintf(buf, n, "option 'la' = %lld must be even", (long long)v);
         return buf;
     }
+    // a value the launcher would silently read as "no checkpoints" / an impossible super-tile is a typo, not a setting
+    if (i == OPT_syrk_ck && v != 0 && ((v & (v - 1)) || v < 16)) {
+        snprintf(buf, n, "option 'syrk_ck' = %lld must be 0 or a power of two >= 16", (long long)v);
+        return buf;
+    }
+    if (i == OPT_syrk_gw && (v & (v - 1))) {
+        snprintf(buf, n, "option 'syrk_gw' = %lld must be a power of two", (long long)v);
+        return buf;
+    }
     return nullptr;
 }
 void opt_init() {
@@ -190,6 +199,7 @@ int gq_option_set(const char* name, int64_t value, int64_t* previous) {
     const int i = name ? opt_index(name) : -1;
     if (i < 0) GQ_FAIL(GQ_E_UNSUPPORTED, "gq_option_set: unknown option '%s'", name ? name : "(null)");
     const int64_t old = opt((Opt)i);  // (also runs the one-time initialisation)
+    GQ_OPTIONS_OK();  // a GQ_OPTIONS that did not parse fails this entry point like every other
     char why[200];
     if (opt_range_error(i, value, why, sizeof(why))) GQ_FAIL(GQ_E_UNSUPPORTED, "gq_option_set: %s", why);
     g_opt[i].store(value, std::memory_order_relaxed);
@@ -278,16 +288,27 @@ int gq_obq_quantize(float* W, const float* U, int64_t R, int64_t C, int bits, in
 }
 
 int gq_w_prepare(const uint8_t* col_flags, float* W, int64_t R, int64_t C, int* mismatch, void* stream) {
+    GQ_OPTIONS_OK();
     return w_prepare(col_flags, W, R, C, mismatch, (hipStream_t)stream);
 }
 
-int gq_h_stage(void* dst, const void* src, int64_t nbytes, void* stream) { return h_stage(dst, src, nbytes, (hipStream_t)stream); }
+int gq_h_stage(void* dst, const void* src, int64_t nbytes, void* stream) {
+    GQ_OPTIONS_OK();
+    return h_stage(dst, src, nbytes, (hipStream_t)stream);
+}
 int gq_h_stage_many(void* dst, const void* const* srcs_host, const int64_t* nbytes_host, int n, void* ws, size_t ws_bytes,
                     void* stream) {
+    GQ_OPTIONS_OK();
     return h_stage_many(dst, srcs_host, nbytes_host, n, ws, ws_bytes, (hipStream_t)stream);
 }
-int gq_h_pack_upper(const float* H, int64_t C, float* buf, void* stream) { return h_pack_upper(H, C, buf, (hipStream_t)stream); }
-int gq_h_unpack_upper(const float* buf, int64_t C, float* H, void* stream) { return h_unpack_upper(buf, C, H, (hipStream_t)stream); }
+int gq_h_pack_upper(const float* H, int64_t C, float* buf, void* stream) {
+    GQ_OPTIONS_OK();
+    return h_pack_upper(H, C, buf, (hipStream_t)stream);
+}
+int gq_h_unpack_upper(const float* buf, int64_t C, float* H, void* stream) {
+    GQ_OPTIONS_OK();
+    return h_unpack_upper(buf, C, H, (hipStream_t)stream);
+}
 
 int gq_scale_search(const float* x, int64_t rows, int64_t ld, int q_type, const gq_search_t* p, uint16_t* d,
                     int64_t d_stride, uint8_t* s, int64_t s_ld, uint16_t* dmin, int64_t dmin_stride, uint8_t* m,
@@ -366,12 +387,14 @@ int gq_rtn_quantize(const void* W, int w_dtype, int64_t R, int64_t C, int q_type
 
 int gq_dequantize(int q_type, const uint8_t* qweight, const uint16_t* d, const uint8_t* s, const uint16_t* dmin,
                   const uint8_t* m, int64_t R, int64_t C, void* out, int out_dtype, void* stream) {
+    GQ_OPTIONS_OK();
     if (!qweight || !d || !s || !dmin || !m || !out) GQ_FAIL(GQ_E_NULL, "gq_dequantize: null pointer");
     return launch_dequantize(q_type, qweight, d, s, dmin, m, R, C, out, out_dtype, (hipStream_t)stream);
 }
 
 int gq_pack(int q_type, const uint8_t* qweight, const uint16_t* d, const uint8_t* s, const uint16_t* dmin,
             const uint8_t* m, int64_t R, int64_t C, uint8_t* out, void* stream) {
+    GQ_OPTIONS_OK();
     return launch_pack(q_type, qweight, d, s, dmin, m, R, C, out, (hipStream_t)stream);
 }
 
@@ -399,17 +422,21 @@ int gq_stage_to_host(void* host_dst, const void* src, int64_t nbytes, void* stre
 }
 
 int gq_fwd_rmsnorm(const void* x, const void* weight, void* out, int64_t tokens, int64_t C, float eps, int dtype, void* stream) {
+    GQ_OPTIONS_OK();
     return fwd_rmsnorm(x, weight, out, tokens, C, eps, dtype, (hipStream_t)stream);
 }
 int gq_fwd_rmsnorm_ordered(const void* x, const void* weight, void* out, int64_t tokens, int64_t C, float eps, int dtype,
                            float* stats, void* stream) {
+    GQ_OPTIONS_OK();
     return fwd_rmsnorm_ordered(x, weight, out, tokens, C, eps, dtype, stats, (hipStream_t)stream);
 }
 int gq_fwd_rope(const void* x, const void* cos_, const void* sin_, void* out, int64_t tokens, int heads, int head_dim, int dtype,
                 void* stream) {
+    GQ_OPTIONS_OK();
     return fwd_rope(x, cos_, sin_, out, tokens, heads, head_dim, dtype, (hipStream_t)stream);
 }
 int gq_fwd_silu_mul(const void* gate, const void* up, void* out, int64_t n, int dtype, void* stream) {
+    GQ_OPTIONS_OK();
     return fwd_silu_mul(gate, up, out, n, dtype, (hipStream_t)stream);
 }
 

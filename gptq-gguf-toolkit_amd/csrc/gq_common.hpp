@@ -48,6 +48,7 @@ extern thread_local char g_err[512];
     X(syrk_persist, 1, 0, 1)      /* 0: one tile per workgroup instead of the persistent launch with XCD rendezvous */            \
     X(syrk_wgs, 0, 0, 4096)          /* resident workgroups of the persistent launch (0: one per CU) */                           \
     X(syrk_ck, 256, 0, 65536)     /* half-stages between the soft XCD rendezvous inside a tile (a power of two >= 16; 0: none) */  \
+    X(syrk_gw, 4, 1, 32)          /* width in tiles of the super-tile an XCD's 32 workgroups share (1, 2, 4, 8, 16, 32; 32 / gw rows) */ \
     X(syrk_w4, 1, 0, 1)           /* 0: eight waves with 128x64 wave tiles (syrk16_256n_kernel) instead of four with 128x128 */   \
     /* K3 Cholesky chain */                                                                                                       \
     X(chol_3p_min, 1792, 0, 1048576)    /* smallest half of a recursion node that runs on the image GEMMs (0: never) */           \

@@ -1395,18 +1395,24 @@ static int syrk16_launch(int kind, const int* idx, int m, float* const* H, const
     std::vector<uint32_t> table;
     if (kind) {
         // Balanced schedule: the valid (ti <= tj) tiles of all problems, enumerated super-tile by super-tile
-        // (4 x 8 tiles share 12 operand panels), are cut into groups of 32 CONSECUTIVE tiles -- one group =
+        // (8 x 4 tiles share 12 operand panels), are cut into groups of 32 CONSECUTIVE tiles -- one group =
         // what the 32 CUs of an XCD run at the same time out of one L2 -- and the groups are dealt
         // round-robin to the 8 XCDs, so every XCD gets the same number of tiles (+-32) and no workgroup
         // exits early.  (An arithmetic id -> super-tile map leaves XCDs up to 30 % apart: diagonal
         // super-tiles are half empty.)
         std::vector<uint32_t> all;
+        // (option syrk_gw: the super-tile's width in tiles, 32 / gw rows.  r06 A/B of the fabric traffic on random operands at
+        // C = 14336, profiles/r06_syrk_traffic_ab.txt: 4 x 8 (r02-r05) 29.7 GB of L2-miss reads per launch, 1312 TFLOP/s; 2 x 16
+        // 41.5 GB, 1283; 1 x 32 51.3 GB, 1269; 8 x 4 (default since r06) 26.5 GB, 1332 -- and 89.3 against 90.2 ms per bench
+        // step in four alternating pairs.  Which tiles fall into the K-split round depends on the shape, so H moves within
+        // K1's tolerance class.)
+        const int gw = (int)opt(OPT_syrk_gw), gh = 32 / gw;
         for (int k = 0; k < m; ++k) {
-            const int nt = grp.p[k].nt, nsc = (nt + 7) / 8, nsr = (nt + 3) / 4;
+            const int nt = grp.p[k].nt, nsc = (nt + gw - 1) / gw, nsr = (nt + gh - 1) / gh;
             for (int sI = 0; sI < nsr; ++sI)
-                for (int sJ = (sI * 4) >> 3; sJ < nsc; ++sJ)
+                for (int sJ = (sI * gh) / gw; sJ < nsc; ++sJ)
                     for (int slot = 0; slot < 32; ++slot) {
-                        const int ti = sI * 4 + (slot >> 3), tj = sJ * 8 + (slot & 7);
+                        const int ti = sI * gh + slot / gw, tj = sJ * gw + slot % gw;
                         if (ti < nt && tj < nt && ti <= tj) all.push_back((uint32_t)k << 24 | (uint32_t)ti << 12 | (uint32_t)tj);
                     }
         }

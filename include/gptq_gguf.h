@@ -105,7 +105,8 @@ const char* gq_last_error(void);
      syrk_nosplit [0] no K-split of the last round | syrk_persist [1] persistent launch with XCD rendezvous |
      syrk_wgs [0 = one per CU] resident workgroups of that launch | syrk_ck [256] half-stages (32 tokens) between the soft XCD
      rendezvous inside a tile of that launch (power of two >= 16, 0: none; results do not depend on it) | syrk_w4 [1] four waves with 128x128 wave tiles, 0 = eight
-     waves with 128x64 (bit-identical)
+     waves with 128x64 (bit-identical) | syrk_gw [4] width in 256-tiles of the super-tile an XCD's 32 workgroups work on at a time
+     (a power of two <= 32; 32 / gw rows; moves the K-split round: H within the tolerance class)
      chol_3p_min [1792] smallest half-node on the image GEMMs (0: never; changes U within the tolerance class) |
      chol_planes [2] 2 = row-scaled fp16 x 2, 3 = bf16 x 3 (tolerance class) | chol_3b_min [1024] | chol_fp32 [0] fp32 MFMA only
      (tolerance class) | chol_no_pair [0] | chol_no_equil [0] | chol_poison [0] NaN-fill scratch that must not be read |

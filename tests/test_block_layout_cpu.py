@@ -241,7 +241,10 @@ def test_gq_options_errors_fail_every_entry_point_without_abort():
             "try:\n    print('VALUE', _cabi.option_get('la'))\n"
             "except _cabi.GQError as e:\n    print('ERR', e)\n") % ROOT
     for env_val, want in (("la=abc", "not an integer"), ("far_wgs=", "not an integer"), ("la=3", "must be even"),
-                          ("la=64", "outside"), ("no_such=1", "unknown option"), ("la=4,syrk_ck=128", "VALUE 4")):
+                          ("la=64", "outside"), ("no_such=1", "unknown option"), ("la=4,syrk_ck=128", "VALUE 4"),
+                          # a checkpoint distance the launcher would silently read as "none" is a typo
+                          ("syrk_ck=100", "power of two"), ("syrk_ck=8", "power of two"), ("syrk_gw=6", "power of two"),
+                          ("syrk_ck=0,chol_sub=16", "VALUE 8")):
         p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GQ_OPTIONS=env_val), capture_output=True, text=True)
         assert p.returncode == 0 and want in p.stdout, (env_val, p.stdout, p.stderr[-500:])
     from gptq_gguf_toolkit_amd import _cabi
@@ -249,4 +252,13 @@ def test_gq_options_errors_fail_every_entry_point_without_abort():
         _cabi.option_set("la", 5)
     with pytest.raises(_cabi.GQError, match="outside"):
         _cabi.option_set("chol_planes", 7)
+    with pytest.raises(_cabi.GQError, match="power of two"):
+        _cabi.option_set("syrk_ck", 48)
+    # with a GQ_OPTIONS that did not parse, gq_option_set fails like every other entry point
+    code2 = ("import sys; sys.path.insert(0, %r)\n"
+             "from gptq_gguf_toolkit_amd import _cabi\n"
+             "try:\n    _cabi.option_set('la', 4); print('SET')\n"
+             "except _cabi.GQError as e:\n    print('ERR', e)\n") % ROOT
+    p = subprocess.run([sys.executable, "-c", code2], env=dict(os.environ, GQ_OPTIONS="la=abc"), capture_output=True, text=True)
+    assert p.returncode == 0 and "ERR" in p.stdout and "not an integer" in p.stdout, (p.stdout, p.stderr[-500:])
     assert _cabi.option_default("syrk_ck") == 256 and _cabi.option_default("seg_pair") == 1
