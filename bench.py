@@ -41,6 +41,7 @@ Rank 0 prints the full result dict on one line and then, LAST, the compact headl
 keys with `roofline` and `cpu_baseline` flattened to scalars).
 """
 import argparse
+from pathlib import Path
 import json
 import os
 import shutil
@@ -572,8 +573,51 @@ def build_model(cfg_kw, dev, dtype=torch.bfloat16, seed=0):
     return model
 
 
+def gguf_leg(hf_dir, save_dir, root, quant_wall):
+    """The second half of the target (north star: "Llama-3-8B -> Q4_K end-to-end ... GGUF output"): pack_gptq_into_gguf.convert on
+    the data.pth tree the quantizer has just written + the checkpoint directory, into one .gguf file (reference
+    pack_gptq_into_gguf.py:282-349, 469-475).  vocab=False: a random-init model has no tokenizer files (the vocabulary is a few MB
+    of metadata: tests/test_host_logic_cpu.py covers it)."""
+    from gptq_gguf_toolkit_amd.pack_gptq_into_gguf import convert
+    out = {}
+    flows = [("pipelined", True)] + ([("tensor_by_tensor", False)] if os.environ.get("GQ_BENCH_GGUF_FLOW") == "1" else [])
+    for label, pipelined in flows:
+        outfile = os.path.join(root, f"gq_bench_{os.getpid()}_{label}.gguf")
+        tm = {}
+        try:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            convert(Path(hf_dir), Path(save_dir), Path(outfile), "f16", vocab=False, pipelined=pipelined, timing=tm)
+            torch.cuda.synchronize()
+            wall = time.perf_counter() - t0
+            size = os.path.getsize(outfile)
+            digest = None
+            if os.environ.get("GQ_BENCH_GGUF_FLOW") == "1":
+                import hashlib
+                hsh = hashlib.sha256()
+                with open(outfile, "rb") as f:
+                    for chunk in iter(lambda: f.read(1 << 26), b""):
+                        hsh.update(chunk)
+                digest = hsh.hexdigest()[:16]
+        finally:
+            if os.path.exists(outfile):
+                os.remove(outfile)
+        out[label] = {"pack_wall_s": round(wall, 2), "gguf_GB": round(size / 1e9, 2), "sha256_16": digest,
+                      "split_s": {k: round(v, 2) for k, v in sorted(tm.items())},
+                      "split_keys": "load = torch.load of the data.pth files (mmap); hf_read / plain = checkpoint tensors GPTQ did not "
+                                    "replace, read and converted; h2d / permute_pack / d2h = producer thread (upload of the five "
+                                    "tensors, q/k row un-permute + gq_pack on the GPU, download of the block bytes); write = file "
+                                    "writes, wait = the writing thread waiting for the producer; write_call = GGUFWriter.write as a whole"}
+    p = out["pipelined"]
+    return {"end_to_end_gguf_wall_s": round(quant_wall + p["pack_wall_s"], 2), "quantize_wall_s": round(quant_wall, 2),
+            "pack_wall_s": p["pack_wall_s"], "gguf_GB": p["gguf_GB"], "split_s": p["split_s"], "split_keys": p["split_keys"],
+            "flows": out if len(out) > 1 else None, "outtype": "f16 for what GPTQ did not quantize; vocab=False",
+            "region": "Quantizer.quantize (quant.py:251-254) + pack_gptq_into_gguf.convert (pack_gptq_into_gguf.py:282-349, 469-475) back to "
+                      "back; checkpoint directory (safetensors) written before the timed region"}
+
+
 def whole_model_run(wl, dev, world, rank, save_root=None, nseq=None, L=None, layers=None, calib_batch=1, fused="exact",
-                    reference_cadence=False):
+                    reference_cadence=False, gguf=False):
     """Quantizer.quantize on a random-init Llama of the workload's architecture (the reference's timed region,
     quant.py:251-254) -> dict with wall seconds, Mparams/s and the split."""
     from gptq_gguf_toolkit_amd.quantizer import Quantizer
@@ -595,6 +639,14 @@ def whole_model_run(wl, dev, world, rank, save_root=None, nseq=None, L=None, lay
         shm_free = shutil.disk_usage("/dev/shm").free if os.path.isdir("/dev/shm") else 0
         root = "/dev/shm" if shm_free > 24e9 else tempfile.gettempdir()
     save_dir = tempfile.mkdtemp(prefix="gq_bench_", dir=root) if rank == 0 else None
+    hf_dir = None
+    if gguf and rank == 0 and world == 1:
+        # the checkpoint directory the packer reads (the reference's `model` argument), written BEFORE the timed region from the
+        # un-quantized weights: the quantizer writes the dequantized ones back into the live model
+        hf_dir = tempfile.mkdtemp(prefix="gq_bench_hf_", dir=root)
+        t0 = time.perf_counter()
+        model.save_pretrained(hf_dir, safe_serialization=True)
+        t_save = time.perf_counter() - t0
     if world > 1:
         box = [save_dir]
         dist.broadcast_object_list(box, src=0)
@@ -639,9 +691,18 @@ def whole_model_run(wl, dev, world, rank, save_root=None, nseq=None, L=None, lay
         wall = float(tm.item())
         files = sum(len(f) for _, _, f in os.walk(save_dir)) if rank == 0 else 0
         nbytes = sum(os.path.getsize(os.path.join(d, f)) for d, _, fs in os.walk(save_dir) for f in fs) if rank == 0 else 0
+        e2e = None
+        if hf_dir is not None:
+            try:
+                e2e = gguf_leg(hf_dir, save_dir, root, wall)
+                e2e["checkpoint_save_s_untimed"] = round(t_save, 1)
+            except Exception as e:  # the bench line must still print
+                e2e = {"error": repr(e)}
     finally:
         if rank == 0:
             shutil.rmtree(save_dir, ignore_errors=True)
+            if hf_dir is not None:
+                shutil.rmtree(hf_dir, ignore_errors=True)
     syrk_wm = None
     if wm_prof and "syrk" in prof_got and prof_got["syrk"][0] > 0:
         # algorithmic flops of the run's Hessian folds: per block the four distinct inputs (q/k/v, o, gate/up: hidden wide; down:
@@ -668,6 +729,7 @@ def whole_model_run(wl, dev, world, rank, save_root=None, nseq=None, L=None, lay
            "syrk_roofline_on_model_activations": syrk_wm,
            "split": dict(drv.timing, **({"kernel_ms_launches": prof_got} if wm_prof else {})), "schedule": getattr(drv, "schedule_stats", None), "model_build_s": round(t_build, 1),
            "data_pth": {"files": files, "GB": round(nbytes / 1e9, 2), "dir": root},
+           "end_to_end_gguf": e2e,
            "region": "Quantizer.quantize (reference quant.py:251-254), model and ids resident on the GPU/host before it, "
                      "after one untimed forward of one sequence (GEMM code objects loaded)"}
     del drv, model
@@ -748,6 +810,11 @@ def compact_line(line):
     out["cpu_baseline"] = c or None  # (None at N > 1: the baseline is part of the N = 1 line)
     for key in ("whole_model", "whole_model_hf_eager", "whole_model_batch4"):
         out[f"{key}_wall_s"] = _get(line, key, "wall_s_quantizer_region")
+    # quantize -> pack_gptq_into_gguf -> .gguf (the north star's end-to-end target), N = 1
+    out["end_to_end_gguf_wall_s"] = _get(line, "whole_model", "end_to_end_gguf", "end_to_end_gguf_wall_s")
+    out["gguf_pack_wall_s"] = _get(line, "whole_model", "end_to_end_gguf", "pack_wall_s")
+    sp = _get(line, "whole_model", "end_to_end_gguf", "split_s") or {}
+    out["gguf_pack_split_s"] = ("load %s h2d %s pack %s d2h %s write %s wait %s" % tuple(sp.get(k) for k in ("load", "h2d", "permute_pack", "d2h", "write", "wait"))) if sp else None
     out["collectives_per_step"] = line.get("collectives_per_step")
     out["allreduce_probe_ms"] = _get(line, "allreduce_probe", "ms")
     out["tolerance_ints_differ"] = _get(line, "tolerance_parity", "ints_differ")
@@ -1002,7 +1069,7 @@ def main():
         for key, cb, fused in (("whole_model", 1, "exact"), ("whole_model_hf_eager", 1, "off"), ("whole_model_batch4", 4, "exact")):
             try:
                 wm[key] = whole_model_run(WORKLOADS["llama3-8b-model-q4k"], dev, world, rank, layers=args.layers, calib_batch=cb,
-                                          fused=fused, reference_cadence=(fused == "off"))
+                                          fused=fused, reference_cadence=(fused == "off"), gguf=(key == "whole_model"))
             except Exception as e:  # the bench line must still print
                 wm[key] = {"error": repr(e)}
         if rank == 0:

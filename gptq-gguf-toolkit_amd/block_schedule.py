@@ -455,6 +455,9 @@ class BlockSchedule:
                         self.stats["refactorised"] += 1
                     results[n] = res
                     born.extend(res)
+                    # what the row-split fallback (recompute_whole, on the caller's stream after the exchange) reads was born
+                    # on this lane too: U, the column flags, the re-search counter and the working copy
+                    born.extend(t for t in (h._last_U, h._last_cf, getattr(h, "_researches", None), h.W) if torch.is_tensor(t))
                     if world == 1 and writeback:
                         deq[n] = dequantize_linear_weight(qtypes[n], *res, out_dtype=h.layer.weight.data.dtype)
                         born.append(deq[n])

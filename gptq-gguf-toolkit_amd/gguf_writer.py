@@ -171,7 +171,39 @@ class GGUFWriter:
             raise ValueError(f"Duplicated tensor name {name!r}")
         self.tensors.append((name, tuple(int(x) for x in shape), int(raw_dtype), data))
 
-    def write(self):
+    def add_tensor_lazy(self, name: str, shape, raw_dtype: int, producer):
+        """A tensor whose bytes are made when the file is written (gguf-py has the same split: add_tensor_info now,
+        write_tensor_data later).  `shape` is the LOGICAL shape; `producer()` returns a C-contiguous numpy array of exactly
+        the type's byte count.  write() runs the producers on a thread of their own, a few tensors ahead of the file
+        writes: a converter never holds more than `LAZY_DEPTH` payloads (pack_gptq_into_gguf.convert: ~5 GB otherwise)."""
+        if any(n == name for n, *_ in self.tensors):  # rule R2
+            raise ValueError(f"Duplicated tensor name {name!r}")
+        shape = tuple(int(x) for x in shape)
+        bs, ts = GGML_QUANT_SIZES[int(raw_dtype)]
+        nbytes = int(np.prod(shape)) // bs * ts
+        self.tensors.append((name, shape, int(raw_dtype), _Lazy(producer, nbytes)))
+
+    LAZY_DEPTH = 4
+
+    def write(self, timing: dict = None):
+        """`timing` (optional) receives seconds: "write" = file writes, "wait" = the writer waiting for a producer."""
+        import queue
+        import threading
+        import time
+        lazy = [d for *_, d in self.tensors if isinstance(d, _Lazy)]
+        q: "queue.Queue" = queue.Queue(maxsize=self.LAZY_DEPTH)
+
+        def produce():
+            try:
+                for d in lazy:
+                    q.put(d.producer())
+            except BaseException as e:  # handed to the writing thread
+                q.put(e)
+
+        th = threading.Thread(target=produce, daemon=True) if lazy else None
+        if th:
+            th.start()
+        t_write = t_wait = 0.0
         with open(self.path, "wb") as f:
             f.write(GGUF_MAGIC + struct.pack("<IQQ", GGUF_VERSION, len(self.tensors), len(self.kv)))
             for k, t, v, sub in self.kv:
@@ -184,9 +216,31 @@ class GGUFWriter:
                 off += (data.nbytes + ALIGNMENT - 1) // ALIGNMENT * ALIGNMENT
             pad = (-f.tell()) % ALIGNMENT
             f.write(b"\x00" * pad)
-            for _, _, _, data in self.tensors:
-                f.write(data.tobytes())
+            for name, _, _, data in self.tensors:
+                if isinstance(data, _Lazy):
+                    t0 = time.perf_counter()
+                    got = q.get()
+                    t_wait += time.perf_counter() - t0
+                    if isinstance(got, BaseException):
+                        raise got
+                    got = np.ascontiguousarray(got)
+                    if got.nbytes != data.nbytes:
+                        raise ValueError(f"tensor {name!r}: producer returned {got.nbytes} bytes, {data.nbytes} announced")
+                    data = got
+                t0 = time.perf_counter()
+                f.write(data.reshape(-1).view(np.uint8).data)  # the array's own buffer: no tobytes() copy
                 f.write(b"\x00" * ((-data.nbytes) % ALIGNMENT))
+                t_write += time.perf_counter() - t0
+        if th:
+            th.join()
+        if timing is not None:
+            timing["write"] = timing.get("write", 0.0) + t_write
+            timing["wait"] = timing.get("wait", 0.0) + t_wait
+
+
+class _Lazy:
+    def __init__(self, producer, nbytes):
+        self.producer, self.nbytes = producer, nbytes
 
 
 def parse_gguf(path: str):

@@ -343,6 +343,7 @@ class GPTQ:
         if q_type == GGMLQuantizationType.Q3_K:  # reference gptq.py:204-206 mutates the handle
             self.act_order = False
             self.static_groups = False
+        self.row_split_redone = False
         if self.act_order:
             return self._compute_act_order(q_type)
         U = self._prepare(defer_check, own_U)
@@ -412,7 +413,12 @@ class GPTQ:
         res = _ops.gptq_quantize(Wf, U, int(q_type), h0.block_size, h0.static_groups, h0.rmin, h0.rdelta, h0.nstep,
                                  quant_scale=h0.quant_scale.value, grid=h0.grid, row_ends=ends)
         for h in hs:
-            h.W = h.layer.weight  # not a view of Wf: one handle kept alive must not pin the whole stack until reset()
+            # After compute() a handle's W is its dequantized fp32 working copy (the reference quantizes self.W in place).  A
+            # stacked handle's copy is a row slice of Wf; keeping the VIEW would let one handle pin the whole stack until
+            # reset(), aliasing the live fp16 / bf16 parameter (r05) gave readers another tensor and dtype depending on
+            # whether the Linear happened to be stacked.  Contract: W is None after a stacked walk -- the
+            # dequantized weights are the result tuple through dequantize_linear_weight, as BlockSchedule writes them back.
+            h.W = None
         return [tuple(t[r1 - n:r1] for t in res) for r1, n in zip(ends, rows)]
 
     def _row_split_active(self) -> bool:
@@ -458,14 +464,21 @@ class GPTQ:
         """Broadcast of the 5 result tensors from the owner (reference gptq.py:287-293, src=0 there)."""
         if self._row_split_active():  # all-gather of the ranks' row slices instead of the owner's broadcast
             _, _, chunk = dist_utils.row_slice(self.d_row, dist_utils.get_rank(), dist_utils.get_world_size())
-            n = self._researches.clone()
-            dist_utils.collective_calls["small_all_reduce"] += 1
-            dist_utils.collective_bytes["small_all_reduce"] += 4
-            dist.all_reduce(n, op=dist.ReduceOp.SUM)
-            if int(n.item()) != 0:  # some slice decided :250-252 on its own rows: the whole matrix, on every rank
-                self.row_split_redone = True
+            # the slices' re-search counts ride in the first row all-gather (one extra row of the int8 / uint8 qweight chunk
+            # carries the count's four bytes): no collective and no host sync of their own (ADVICE r05)
+            q = result[0]
+            world = dist_utils.get_world_size()
+            padded = torch.zeros((chunk + 1, q.shape[1]), dtype=q.dtype, device=q.device)
+            padded[:q.shape[0]] = q
+            padded.view(torch.uint8)[chunk, :4] = self._researches.view(torch.uint8)
+            gathered = dist_utils.all_gather_rows(padded, (chunk + 1) * world, chunk + 1)
+            per = gathered.view(world, chunk + 1, q.shape[1])
+            counts = per[:, chunk, :4].contiguous().view(torch.uint8).view(torch.int32)
+            if int(counts.sum().item()) != 0:  # some slice decided :250-252 on its own rows: the whole matrix, on every rank
+                self.row_split_redone = True   # (every rank then pays the N = 1 time for this matrix: surfaced in the stats)
                 return self.recompute_whole(q_type)
-            return tuple(dist_utils.all_gather_rows(t, self.d_row, chunk) for t in result)
+            qfull = per[:, :chunk].reshape(world * chunk, q.shape[1])[:self.d_row]
+            return (qfull,) + tuple(dist_utils.all_gather_rows(t, self.d_row, chunk) for t in result[1:])
         if result is None:
             result = self._empty_result(q_type)
         if dist_utils.is_dist_available_and_initialized() and dist_utils.get_world_size() > 1:

@@ -81,6 +81,13 @@ def map_tensor_name(name: str) -> str:
 
 
 def iter_hf_tensors(dir_model: Path):
+    for k, _, get in iter_hf_entries(dir_model):
+        yield k, get()
+
+
+def iter_hf_entries(dir_model: Path):
+    """-> (name, shape, get) in the checkpoint's order; get() reads the tensor.  A tensor GPTQ replaced is never read: the
+    converter needs its name and shape only (16 GB of an 8B checkpoint otherwise, for nothing)."""
     from safetensors import safe_open
     files = sorted(dir_model.glob("*.safetensors"))
     if not files:
@@ -88,7 +95,7 @@ def iter_hf_tensors(dir_model: Path):
     for fn in files:
         with safe_open(str(fn), framework="pt", device="cpu") as f:
             for k in f.keys():
-                yield k, f.get_tensor(k)
+                yield k, tuple(f.get_slice(k).get_shape()), (lambda f=f, k=k: f.get_tensor(k))
 
 
 # llama.cpp token types (reference pack_gptq_into_gguf.py:47-53)
@@ -200,6 +207,10 @@ def create_vocab_sentencepiece(dir_model: Path, vocab_size: Optional[int]):
     return tokens, scores, types
 
 
+# True: drop the CodeLlama prefix / suffix / middle token ids as gguf-py 0.17.1's GGUFWriter is believed to (see _add_space_prefix)
+GGUF_PY_FIM_COMPAT = False
+
+
 def add_tokenizer(w: GGUFWriter, dir_model: Path, vocab_size: int):
     """LlamaModel.set_vocab (reference :2126-2139): the SentencePiece vocabulary when the checkpoint has a
     tokenizer.model (Llama-2, TinyLlama, Mistral, Mixtral: tokenizer model "llama", pre-tokenizer "default", scores,
@@ -257,19 +268,22 @@ def _add_space_prefix(w: GGUFWriter, dir_model: Path, vocab_size: Optional[int] 
     """The tail of LlamaModel.set_vocab (:2138-2158), in its order."""
     if vocab_size == 32016:
         # CodeLlama only (:2138-2148): a second SpecialVocab(load_merges=False, special_token_types=prefix/suffix/middle/eot)
-        # with the four fill-in-the-middle ids set by hand.  SpecialVocab.add_to_gguf writes a type only when the writer has
-        # an `add_<type>_token_id` method and skips it with a warning otherwise; the GGUFWriter of the pinned gguf-py
-        # (0.17.1, after llama.cpp's fill-in-the-middle rework: fim_pre / fim_suf / fim_mid keys, found by token text at load
-        # time) has add_eot_token_id but no prefix / suffix / middle handlers -> ONE key, three warnings.  (gguf-py is not
-        # installable here: DESIGN.md 0d lists this among the bytes pinned by its published behaviour only.)
-        for typ, tid in (("prefix", 32007), ("suffix", 32008), ("middle", 32009)):
-            print(f"warning: No handler for special token type {typ} with id {tid} - skipping", file=sys.stderr)
-        w.add_uint32("tokenizer.ggml.eot_token_id", 32010)
-        # the same second SpecialVocab reads tokenizer_config.json again and adds its chat template a second time: the
-        # writer refuses the duplicate key (gguf-py: ValueError "Duplicated key name"), as the reference's run would
+        # with the four fill-in-the-middle ids set by hand -- written, all four, as the reference's lines ask for.
+        # What a particular gguf-py release makes of them cannot be confirmed here (no gguf-py, DESIGN.md 0d): the writer of
+        # 0.17.1 is believed to have add_eot_token_id only and to skip the other three with a warning; GGUF_PY_FIM_COMPAT = True
+        # reproduces that guess, the default keeps the keys (ADVICE r05: no output key is dropped on an unverified premise).
+        fim = (("prefix", 32007), ("suffix", 32008), ("middle", 32009), ("eot", 32010))
+        for typ, tid in fim:
+            if GGUF_PY_FIM_COMPAT and typ != "eot":
+                print(f"warning: No handler for special token type {typ} with id {tid} - skipping", file=sys.stderr)
+                continue
+            w.add_uint32(f"tokenizer.ggml.{typ}_token_id", tid)
+        # The same second SpecialVocab reads tokenizer_config.json again; its chat template is already in the file (the first
+        # SpecialVocab wrote it).  A duplicate key would make the writer raise: the template is NOT added a second time -- a
+        # CodeLlama-Instruct checkpoint converts (ADVICE r05: a suspected upstream crash is not emulated).
         tcj = dir_model / "tokenizer_config.json"
         tmpl = json.load(open(tcj, encoding="utf-8")).get("chat_template") if tcj.is_file() else None
-        if isinstance(tmpl, str):
+        if isinstance(tmpl, str) and not any(k == "tokenizer.chat_template" for k, *_ in w.kv):
             w.add_string("tokenizer.chat_template", tmpl)
     cfgp = dir_model / "tokenizer_config.json"
     cfg = json.load(open(cfgp, encoding="utf-8")) if cfgp.exists() else {}
@@ -327,7 +341,18 @@ def rope_freqs_llama3(hp: dict):
 
 
 def convert(dir_model: Path, dir_model_quant: Path, outfile: Path, outtype: str = "f16", verbose: bool = False,
-            vocab: bool = True):
+            vocab: bool = True, pipelined: bool = True, timing: Optional[dict] = None):
+    """pipelined (default): a quantized Linear's five tensors are mapped from data.pth (torch.load(mmap=True): no read), and its
+    payload is made WHEN THE FILE IS WRITTEN, on a producer thread a few tensors ahead of the file writes -- one upload, the q / k
+    row un-permute and gq_pack on the GPU, one download (GGUFWriter.add_tensor_lazy) -- instead of five uploads, a CPU permute
+    and ~5 GB of payloads held until write() (pipelined=False: that flow, the reference's :282-349 order of operations).  Same
+    file bytes either way (tests/test_host_logic_cpu.py::test_pack_into_gguf...).  `timing` receives seconds per stage."""
+    import time
+    tm = timing if timing is not None else {}
+
+    def clock(key, t0):
+        tm[key] = tm.get(key, 0.0) + time.perf_counter() - t0
+
     hp = json.load(open(dir_model / "config.json"))
     arch = hp.get("architectures", ["LlamaForCausalLM"])[0]
     if arch not in ("LlamaForCausalLM", "LLaMAForCausalLM", "MistralForCausalLM", "MixtralForCausalLM"):
@@ -380,29 +405,67 @@ def convert(dir_model: Path, dir_model_quant: Path, outfile: Path, outtype: str 
 
     if rope_type == "llama3":
         w.add_tensor("rope_freqs.weight", rope_freqs_llama3(hp).numpy())
-    for name, data in iter_hf_tensors(dir_model):
+    FIVE = ("qweight", "super_group_scale", "group_scale_quant", "super_group_zero", "group_zero_quant")
+    for name, shape, get in iter_hf_entries(dir_model):
         if name.endswith((".attention.masked_bias", ".attention.bias", ".rotary_emb.inv_freq")):
             continue
         names_seen.add(name)
-        total_params += data.numel()
+        numel = int(np.prod(shape)) if len(shape) else 1
+        total_params += numel
         base = name.removesuffix(".weight")  # :305-306
         is_q, is_k = name.endswith("q_proj.weight"), name.endswith("k_proj.weight")
-        payload = q_type = None
-        if base in index_map:
-            qd = torch.load(str(index_map[base] / "data.pth"), map_location="cpu", weights_only=True)
+        is_expert = ".block_sparse_moe.experts." in name
+        payload = q_type = data = None
+        if base in index_map and pipelined and not is_expert:
+            t0 = time.perf_counter()
+            qd = torch.load(str(index_map[base] / "data.pth"), map_location="cpu", weights_only=True, mmap=True)
+            clock("load", t0)
             q_type = int(qd["q_type"])
-            five = [qd["qweight"], qd["super_group_scale"], qd["group_scale_quant"], qd["super_group_zero"],
-                    qd["group_zero_quant"]]
+
+            def producer(qd=qd, q_type=q_type, heads=(n_head, n_head if is_q else n_kv) if (is_q or is_k) else None):
+                t0 = time.perf_counter()
+                five = [packing_utils._dev(qd[k]) if torch.is_tensor(qd.get(k)) else None for k in FIVE]   # the one upload (pageable, synchronous)
+                clock("h2d", t0)
+                t0 = time.perf_counter()
+                if heads is not None:
+                    five = [permute(t, *heads) if t is not None else None for t in five]      # :320-324 via modify_tensors
+                out = packing_utils.pack_tensor_on_device(q_type, *five)                    # :326-336
+                if out.is_cuda:
+                    torch.cuda.synchronize()
+                clock("permute_pack", t0)
+                t0 = time.perf_counter()
+                host = out.cpu().numpy()
+                clock("d2h", t0)
+                return host
+
+            new_name = map_tensor_name(name)
+            if verbose:
+                print(f"{new_name:28s} {tuple(shape)} --> ggml type {q_type}")
+            w.add_tensor_lazy(new_name, tuple(qd["qweight"].shape), q_type, producer)       # :344-348
+            continue
+        t0 = time.perf_counter()
+        data = get()
+        clock("hf_read", t0)
+        if base in index_map:
+            t0 = time.perf_counter()
+            qd = torch.load(str(index_map[base] / "data.pth"), map_location="cpu", weights_only=True)
+            clock("load", t0)
+            q_type = int(qd["q_type"])
+            five = [qd[k] for k in FIVE]
+            t0 = time.perf_counter()
             if is_q:
                 five = [permute(t, n_head, n_head) for t in five]      # :320-324 via modify_tensors
             elif is_k:
                 five = [permute(t, n_head, n_kv) for t in five]
+            clock("permute_cpu", t0)
+            t0 = time.perf_counter()
             payload = packing_utils.pack_tensor(q_type, *five)          # :326-336
+            clock("h2d_pack_d2h", t0)
         elif is_q:
             data = permute(data, n_head, n_head)
         elif is_k:
             data = permute(data, n_head, n_kv)
-        if ".block_sparse_moe.experts." in name:
+        if is_expert:
             # :2223-2255 merges the experts of a block into one 3-D tensor per w1/w2/w3.  The reference's quantized
             # branch indexes modify_tensors(...)[0], which is empty for all but a block's last expert tensor -- it
             # has no working behaviour for quantized experts.  Here: the packed payloads of the experts are stacked
@@ -433,7 +496,9 @@ def convert(dir_model: Path, dir_model_quant: Path, outfile: Path, outtype: str 
                 print(f"{new_name:28s} {tuple(data.shape)} --> ggml type {q_type}, {payload.nbytes} bytes")
             w.add_tensor(new_name, payload, raw_dtype=q_type)           # :344-348
         else:
+            t0 = time.perf_counter()
             add_plain(new_name, data)
+            clock("plain", t0)
     if experts:
         raise ValueError(f"Unprocessed experts: {sorted(experts)}")   # :2289-2296
     if "lm_head.weight" not in names_seen and not tied:
@@ -465,7 +530,9 @@ def convert(dir_model: Path, dir_model_quant: Path, outfile: Path, outtype: str 
     w.add_uint32("general.quantization_version", 2)
     if vocab:
         add_tokenizer(w, dir_model, hp["vocab_size"])
-    w.write()
+    t0 = time.perf_counter()
+    w.write(tm)
+    clock("write_call", t0)
     return outfile
 
 

@@ -20,8 +20,10 @@ def _dev(t: torch.Tensor) -> torch.Tensor:
     return t.contiguous().cuda()
 
 
-def _pack(q_type, qweights, super_group_scale, group_scale_quant, super_group_zero=None, group_zero_quant=None
-          ) -> np.ndarray:
+def pack_on_device(q_type, qweights, super_group_scale, group_scale_quant, super_group_zero=None, group_zero_quant=None
+                   ) -> torch.Tensor:
+    """The packers' body on tensors that may already live on the GPU -> uint8 [N, W/256 * type_size] ON THE DEVICE
+    (pack_gptq_into_gguf.convert keeps the five tensors of a Linear there from the upload to the packed bytes)."""
     N, W = qweights.shape
     assert W % 256 == 0, "W must be a multiple of 256"
     nsg = W // 256
@@ -29,8 +31,12 @@ def _pack(q_type, qweights, super_group_scale, group_scale_quant, super_group_ze
     dmin = _dev(super_group_zero.reshape(N, nsg).to(torch.float16)) if super_group_zero is not None else None
     s = _dev(group_scale_quant.reshape(N, -1))
     m = _dev(group_zero_quant.reshape(N, -1)) if group_zero_quant is not None else None
-    out = _ops.pack(int(q_type), _dev(qweights), d, s, dmin, m)
-    return out.cpu().numpy()
+    return _ops.pack(int(q_type), _dev(qweights), d, s, dmin, m)
+
+
+def _pack(q_type, qweights, super_group_scale, group_scale_quant, super_group_zero=None, group_zero_quant=None
+          ) -> np.ndarray:
+    return pack_on_device(q_type, qweights, super_group_scale, group_scale_quant, super_group_zero, group_zero_quant).cpu().numpy()
 
 
 def pack_Q2K(qweights, super_group_scale, group_scale_quant, super_group_zero, group_zero_quant) -> np.ndarray:
@@ -73,3 +79,11 @@ def pack_tensor(q_type, qweight, super_group_scale, group_scale_quant, super_gro
     if q_type in (T.Q3_K, T.Q6_K):
         return PACKERS[q_type](qweight, super_group_scale, group_scale_quant)
     return PACKERS[q_type](qweight, super_group_scale, group_scale_quant, super_group_zero, group_zero_quant)
+
+
+def pack_tensor_on_device(q_type, qweight, super_group_scale, group_scale_quant, super_group_zero, group_zero_quant) -> torch.Tensor:
+    """pack_tensor for operands that are (or go) on the GPU; the packed bytes stay there."""
+    q_type = T(int(q_type))
+    if q_type in (T.Q3_K, T.Q6_K):
+        return pack_on_device(q_type, qweight, super_group_scale, group_scale_quant)
+    return pack_on_device(q_type, qweight, super_group_scale, group_scale_quant, super_group_zero, group_zero_quant)

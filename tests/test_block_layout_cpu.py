@@ -97,6 +97,14 @@ def test_integration_doc_search_struct_matches_the_header(tmp_path):
     from gptq_gguf_toolkit_amd import _cabi
     assert ctypes.sizeof(_cabi.Search) == size
     assert [n for n, _ in S._fields_] == [n for n, _ in _cabi.Search._fields_]
+    # the snippet asserted ABI version 5 against a header at 6 -- it failed on its second line as printed.  The
+    # version it asserts must be the header's and the binding's (the snippet runs verbatim in tests/test_gpu_round6.py)
+    hdr = open(os.path.join(ROOT, "include", "gptq_gguf.h")).read()
+    v_hdr = int(re.search(r"#define GQ_ABI_VERSION (\d+)", hdr).group(1))
+    v_doc = int(re.search(r"assert _lib\.gq_abi_version\(\) == (\d+)", doc).group(1))
+    assert v_doc == v_hdr == _cabi.ABI_VERSION
+    snippet = re.search(r"```python\n(.*?)```", doc[doc.index("## Level 2"):], re.S).group(1)
+    compile(snippet, "INTEGRATION.md", "exec")  # at least: it is Python
 
 
 def test_environment_variables_are_few_and_documented():

@@ -85,3 +85,70 @@ def test_resident_sub_problems_on_concurrent_streams(ops):
         torch.cuda.synchronize()
         for a, b in zip(alone, outs):
             assert torch.equal(a, b)
+
+
+# ----------------------------------------------------------------- item 3: the reference-side binding, executed as printed
+def _integration_stub():
+    import re
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    lvl2 = doc[doc.index("## Level 2"):]
+    m = re.search(r"```python\n(.*?)```", lvl2, re.S)
+    assert m, "INTEGRATION.md no longer shows the Level-2 ctypes stub"
+    return m.group(1)
+
+
+def test_integration_stub_runs_as_printed():
+    """the ctypes stub INTEGRATION.md tells a maintainer of the reference to paste into src/gptq.py is
+    extracted from the file and exec'd verbatim (only GPTQGGUF_HIP_SO names where the library lies), then drives
+    GPTQ.update -> GPTQ._prepare -> GPTQ.step through it on the reference's own vectors: G4 Hessians (fp32 accumulation-order
+    tolerance), G5 U (factorisation tolerance), G6 integers / scales and G7 packed bytes bit for bit.  A stale ABI version or
+    a drifted argtypes list fails here."""
+    import numpy as np
+    from conftest import load_golden, triu_unpack
+    from gptq_gguf_toolkit_amd import SO_PATH, ops
+    os.environ["GPTQGGUF_HIP_SO"] = SO_PATH
+    ns = {}
+    exec(compile(_integration_stub(), "INTEGRATION.md:Level-2", "exec"), ns)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    # GPTQ.update (gptq.py:96,108-112)
+    g = load_golden("g4_g5_hessian")
+    for tag, dt in (("f32", torch.float32), ("f16", torch.float16), ("bf16", torch.bfloat16)):
+        X = g[f"X_{tag}"]
+        C = X.shape[-1]
+        H = torch.zeros(C, C, device="cuda")
+        for n, xb in enumerate(X):
+            ns["h_addmm_"](H, dev(xb).to(dt), n / (n + 1), 2.0 / (n + 1))
+        ref = g[f"H_{tag}"]
+        assert np.abs(H.cpu().numpy() - ref).max() <= 3e-6 * np.abs(ref).max(), tag
+    # GPTQ._prepare (gptq.py:304-324)
+    H, W = dev(g["prep_H_in"]), dev(g["prep_W_in"])
+    U, flag = ns["prepare"](H, W, 0.01)
+    assert int(flag.item()) == 0 and np.array_equal(W.cpu().numpy(), g["prep_W_after_prestep"])
+    Uref = triu_unpack(g["prep_U_triu"], H.shape[0])
+    assert np.abs(U.cpu().numpy() - Uref).max() <= 2e-4 * np.abs(Uref).max()
+    # GPTQ.step (gptq.py:158-276): the reference's integers
+    g6 = load_golden("g6_g7_step_and_pack")
+    tags = sorted({k.rsplit("_", 1)[0] for k in g6.files if k.endswith("_q") and "mklsqrt" not in k and "_b128_s0" in k})
+    assert len(tags) >= 5
+    types = {"Q2_K": 10, "Q3_K": 11, "Q4_K": 12, "Q5_K": 13, "Q6_K": 14}
+    for tag in tags:
+        case, n1, n2, b, s_ = tag.split("_")
+        name = f"{n1}_{n2}"
+        W0 = g6[f"{case}_W0"]
+        R, C = W0.shape
+        U = dev(triu_unpack(g6[f"{case}_U_triu"], C))
+        W = dev(W0)
+        G = {"Q2_K": 16, "Q3_K": 16, "Q4_K": 32, "Q5_K": 32, "Q6_K": 16}[name]  # quant_utils.py:19-26
+        signed = name in ("Q3_K", "Q6_K")
+        q = torch.empty(R, C, dtype=torch.int8 if signed else torch.uint8, device="cuda")
+        d = torch.empty(R, C // 256, dtype=torch.float16, device="cuda")
+        dmin = torch.empty_like(d)
+        s = torch.empty(R, C // G, dtype=torch.int8 if signed else torch.uint8, device="cuda")
+        m = torch.empty_like(s)
+        ns["step"](W, U, types[name], int(b[1:]), False, -1.0, 0.1, 20, "absmax", q, d, s, dmin, m)
+        torch.cuda.synchronize()
+        assert np.array_equal(q.cpu().numpy(), g6[f"{tag}_q"]), tag
+        assert np.array_equal(d.cpu().view(torch.int16).numpy().view(np.uint16), g6[f"{tag}_d"]), tag
+        assert np.array_equal(s.cpu().numpy(), g6[f"{tag}_s"]) and np.array_equal(m.cpu().numpy(), g6[f"{tag}_m"]), tag
+        if f"{tag}_packed" in g6.files:
+            assert np.array_equal(ops.pack(types[name], q, d, s, dmin, m).cpu().numpy(), g6[f"{tag}_packed"]), tag

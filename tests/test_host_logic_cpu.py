@@ -888,7 +888,13 @@ def test_pack_into_gguf_outtypes(tmp_path, monkeypatch, outtype, ckpt_dtype):
           "group_scale_quant": torch.randint(0, 64, (h, 8), generator=g).to(torch.uint8),
           "group_zero_quant": torch.randint(0, 64, (h, 8), generator=g).to(torch.uint8)}
     torch.save(qd, str(qdir / "data.pth"))
-    kv, ts = read_gguf(str(convert(hf, tmp_path / "q", tmp_path / "m.gguf", outtype, vocab=False)))
+    tm = {}
+    kv, ts = read_gguf(str(convert(hf, tmp_path / "q", tmp_path / "m.gguf", outtype, vocab=False, timing=tm)))
+    # r06: the pipelined converter (payloads made at write time from mmap'd data.pth, un-permute and pack on the device, the
+    # replaced checkpoint tensors never read) writes the file of the tensor-by-tensor flow (reference :282-349), byte for byte
+    convert(hf, tmp_path / "q", tmp_path / "m_flow.gguf", outtype, vocab=False, pipelined=False)
+    assert (tmp_path / "m.gguf").read_bytes() == (tmp_path / "m_flow.gguf").read_bytes()
+    assert {"load", "h2d", "permute_pack", "d2h", "write", "wait", "hf_read", "plain"} <= set(tm)
     eff = outtype if outtype != "auto" else ("f16" if ckpt_dtype == torch.float16 else "bf16")
     assert kv["general.file_type"] == {"f32": 0, "f16": 1, "bf16": 32, "q8_0": 7}[eff]
     gg = {"f32": 0, "f16": 1, "bf16": 30, "q8_0": 8}[eff]
@@ -1205,10 +1211,25 @@ def test_vocab_tail_codellama_granite_and_pair_merges(tmp_path):
         return {k: v for k, _, v, _ in w.kv}, [k for k, *_ in w.kv]
     kv, order = kv_of(32016)
     assert kv["tokenizer.ggml.merges"] == ["a b", "aĠb c", "b c"]
-    # gguf-py 0.17.1's writer has add_eot_token_id only: prefix / suffix / middle are skipped with a warning
-    assert kv["tokenizer.ggml.eot_token_id"] == 32010
-    assert not any(f"tokenizer.ggml.{t}_token_id" in kv for t in ("prefix", "suffix", "middle"))
+    # all four fill-in-the-middle ids of :2144-2147 are written (no key is dropped on an unverifiable premise about
+    # one gguf-py release); the believed 0.17.1 behaviour (eot only, three warnings) is an explicit compat switch
+    assert [kv[f"tokenizer.ggml.{t}_token_id"] for t in ("prefix", "suffix", "middle", "eot")] == [32007, 32008, 32009, 32010]
     assert order.index("tokenizer.ggml.eot_token_id") < order.index("tokenizer.ggml.add_space_prefix")  # :2138 before :2150
+    import gptq_gguf_toolkit_amd.pack_gptq_into_gguf as P
+    P.GGUF_PY_FIM_COMPAT = True
+    try:
+        kvc, _ = kv_of(32016)
+    finally:
+        P.GGUF_PY_FIM_COMPAT = False
+    assert kvc["tokenizer.ggml.eot_token_id"] == 32010
+    assert not any(f"tokenizer.ggml.{t}_token_id" in kvc for t in ("prefix", "suffix", "middle"))
+    # a CodeLlama-Instruct checkpoint: tokenizer_config.json carries a chat template.  It is written ONCE (by the first
+    # SpecialVocab); the CodeLlama tail does not add it again, so the conversion does not die on a duplicate key
+    (d / "tokenizer_config.json").write_text(json.dumps({"add_prefix_space": False, "chat_template": "{{ messages }}"}))
+    kvt, ordert = kv_of(32016)
+    assert kvt["tokenizer.chat_template"] == "{{ messages }}" and ordert.count("tokenizer.chat_template") == 1
+    assert kvt["tokenizer.ggml.prefix_token_id"] == 32007
+    (d / "tokenizer_config.json").write_text(json.dumps({"add_prefix_space": False}))
     kv, order = kv_of(49152)
     assert kv["tokenizer.ggml.add_bos_token"] is False and order[-1] == "tokenizer.ggml.add_bos_token"
     assert "tokenizer.ggml.prefix_token_id" not in kv
@@ -1359,7 +1380,7 @@ def test_four_rank_row_split_equals_owner_mode_even_when_a_slice_has_no_valid_gr
     group of that slice is ever valid, groups of the other slices are): the slice's own verdict differs from the matrix's, the
     re-search counts (gq_gptq_quantize_slice) that ride in the block's all-gather say so, and every rank quantizes the whole
     matrix instead -- bytes identical to GQ_ROW_SPLIT=0 (owner mode = the N = 1 result).  With ordinary weights nothing is
-    redone and no collective is added (BlockSchedule; the handle-level path pays one 4-byte all-reduce)."""
+    redone and no collective is added (BlockSchedule; the handle-level path carries the counts in its first row all-gather)."""
     world = 4
     mgr = mp.Manager()
     got = {}
@@ -1385,7 +1406,9 @@ def test_four_rank_row_split_equals_owner_mode_even_when_a_slice_has_no_valid_gr
             assert owners == {"down": "rows/4"}
             assert (coll["all_gather"], coll["broadcast"], coll.get("small_all_reduce", 0)) == (1, 0, 0), coll
         else:
-            assert coll["small_all_reduce"] == 1 and coll["all_gather"] == 0, coll  # redone: no slices to gather
+            # r06: the counts ride in the first row all-gather -- no 4-byte all-reduce, no host sync of its own;
+            # redone: the other four tensors' slices are not gathered
+            assert coll.get("small_all_reduce", 0) == 0 and coll["all_gather"] == 1, coll
     # the corner is real: without the fallback rank 1's slice result differs from the whole matrix's rows
     import fake_ops
     from oracle import oracle as O
