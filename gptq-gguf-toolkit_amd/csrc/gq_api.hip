@@ -447,7 +447,7 @@ const char* gq_prof_name(int tag) {
     static const char* names[PT_COUNT] = {"transpose16", "syrk", "prepare_elementwise", "diag_potrf_inv", "potrf_gemm32",
                                           "trtri_gemm32", "scale_search", "gptq_segment", "trailing_gemm32",
                                           "block_far_update", "dequantize", "rtn_quantize", "pack", "trailing_far_gemm32",
-                                          "chol_image_gemm", "chol_image_split", "chol_sub_resident"};
+                                          "chol_image_gemm", "chol_image_split"};
     return (tag >= 0 && tag < PT_COUNT) ? names[tag] : "?";
 }
 /* synchronises the recorded events; ms[tag], n[tag] accumulate; records are recycled.

@@ -533,7 +533,6 @@ __device__ __forceinline__ f32x16 mfma_nt_32(const float* Ap, int lda_, const fl
 
 }  // namespace gq
 #include "gq_diag5.hpp"
-#include "gq_cholsub.hpp"
 namespace gq {
 
 // ---- the top recursion levels on pre-split operand images (gq_gemm3p.hpp) ----
@@ -602,61 +601,7 @@ struct P3Run {  // per gq_h_prepare call
     float* partial = nullptr;
     unsigned* rmax = nullptr;     // NP == 2: [2][n/2] row maxima (bits) ...
     float* inv_scale = nullptr;   // ... and [2][n/2] epilogue scales
-    // resident sub-problem launches (gq_cholsub.hpp): the uploaded plans + counters, the next counter block
-    const csub::SubPlans* sub = nullptr;
-    uint32_t* sub_dev = nullptr;
-    int sub_next = 0;
 };
-// ---- the bottom of the recursion as resident launches (gq_cholsub.hpp) ----
-// A node is a sub-problem root when it has 2 .. chol_sub blocks and every product in its subtree is a plain gemm32 one
-// (no image node, no split-bf16 node): the executor then computes bit for bit what the launches would.
-static bool sub_plain(int64_t lo, int64_t hi) {
-    if (hi - lo == 1) return true;
-    const int64_t mid = (lo + hi) / 2, n1 = (mid - lo) * NB, n2 = (hi - mid) * NB;
-    if (p3_node(n1, n2)) return false;
-    const int64_t min3b = opt(OPT_chol_fp32) ? (int64_t)1 << 40 : opt(OPT_chol_3b_min);
-    if (n1 >= min3b && n2 >= min3b) return false;
-    return sub_plain(lo, mid) && sub_plain(mid, hi);
-}
-static bool sub_root(int64_t lo, int64_t hi) {
-    const int64_t mx = opt(OPT_chol_sub) < csub::MAX_BLOCKS ? opt(OPT_chol_sub) : csub::MAX_BLOCKS;
-    return hi - lo >= 2 && hi - lo <= mx && !opt(OPT_diag_ref) && sub_plain(lo, hi);
-}
-static int sub_wgs() { return (int)opt(OPT_chol_sub_wgs); }
-static void sub_collect(csub::SubPlans& sp, int64_t lo, int64_t hi) {
-    if (hi - lo == 1) return;
-    if (sub_root(lo, hi)) {
-        const int nb = (int)(hi - lo);
-        if (!sp.plan_at.count(nb)) {
-            const std::vector<uint32_t> w = csub::make_plan(nb, sub_wgs());
-            sp.plan_at[nb] = sp.words.size();
-            sp.words.insert(sp.words.end(), w.begin(), w.end());
-        }
-        ++sp.nsub;
-        return;
-    }
-    const int64_t mid = (lo + hi) / 2;
-    sub_collect(sp, lo, mid);
-    sub_collect(sp, mid, hi);
-}
-static std::shared_ptr<const csub::SubPlans> sub_plans_for(int64_t nblk) {
-    static std::mutex mu;
-    static std::map<std::vector<int64_t>, std::shared_ptr<const csub::SubPlans>> cache;
-    std::lock_guard<std::mutex> lk(mu);
-    const std::vector<int64_t> key{nblk, p3_min(), (int64_t)p3_planes(), opt(OPT_chol_3b_min), opt(OPT_chol_fp32),
-                                   opt(OPT_chol_sub), opt(OPT_chol_sub_wgs), opt(OPT_diag_ref)};
-    auto it = cache.find(key);
-    if (it != cache.end()) return it->second;
-    auto sp = std::make_shared<csub::SubPlans>();
-    sub_collect(*sp, 0, nblk);
-    sp->cnt_at = sp->words.size();
-    sp->words.resize(sp->words.size() + (size_t)sp->nsub * csub::CNT_STRIDE, 0u);  // the upload zeroes the counters
-    cache[key] = sp;
-    return sp;
-}
-// workspace reserve for the plans and counters (a bound that does not depend on the options)
-static size_t sub_ws_bytes(int64_t C) { return (size_t)64 * 1024 + (size_t)(C / NB + 1) * csub::CNT_STRIDE * 4 + 1024; }
-
 static size_t p3_image_bytes(int64_t C) { return (size_t)(C / 2) * (size_t)(C / 2) * 2 * (size_t)p3_planes(); }
 static bool p3_used(int64_t C) {
     const int64_t nblk = C / NB, mid = nblk / 2;
@@ -672,7 +617,7 @@ size_t h_prepare_workspace_bytes(int64_t R, int64_t C) {
         extra = 2 * (p3_image_bytes(C) + 256) + (size_t)P3_MAX_SLOTS * p3::TILE * p3::TILE * 4 + pl->words.size() * 4 +
                 4 * (size_t)C * 4 + 2048;
     }
-    return 2 * n2 + 2 * (size_t)C + 4 * (size_t)C + 1024 + extra + sub_ws_bytes(C);
+    return 2 * n2 + 2 * (size_t)C + 4 * (size_t)C + 1024 + extra;
 }
 
 // Recursive blocked Cholesky WITH inverse, all level-3 work on the fp32 matrix cores:
@@ -750,21 +695,6 @@ static int chol_inv_rec(float* A, float* X, float* Tmp, int* flag, int64_t n, in
             hipLaunchKernelGGL(diag_blk5_kernel, dim3(1), dim3(320), diag_lds, st, A + o, n, X + o, n, flag);
         else
             hipLaunchKernelGGL(diag_potrf_inv_kernel, dim3(1), dim3(256), diag_lds, st, A + o, n, X + o, n, flag);
-        GQ_LAUNCH_CHECK();
-        return GQ_OK;
-    }
-    if (run.sub && sub_root(lo, hi)) {
-        // the whole subtree as ONE resident launch (same tile functions, same results: gq_cholsub.hpp)
-        ProfScope ps(PT_CHOL_SUB, st);
-        const int64_t o = (lo * NB) * n + lo * NB;
-        const auto it = run.sub->plan_at.find((int)(hi - lo));
-        if (it == run.sub->plan_at.end() || run.sub_next >= run.sub->nsub) GQ_FAIL(GQ_E_UNSUPPORTED, "gq_h_prepare: sub-problem plan missing");
-        const uint32_t* plan = run.sub_dev + it->second;
-        uint32_t* cnt = run.sub_dev + run.sub->cnt_at + (size_t)run.sub_next++ * csub::CNT_STRIDE;
-        const unsigned ntask = run.sub->words[it->second + 1];
-        unsigned wgs = (unsigned)sub_wgs();
-        if (wgs > ntask) wgs = ntask;
-        hipLaunchKernelGGL(csub::chol_sub_kernel, dim3(wgs), dim3(320), csub::LDS_BYTES, st, A + o, X + o, Tmp + o, n, flag, plan, cnt);
         GQ_LAUNCH_CHECK();
         return GQ_OK;
     }
@@ -853,19 +783,6 @@ int h_prepare(float* H, float* W, int64_t R, int64_t C, float rel_damp, float* U
         run.words_dev = reinterpret_cast<const uint32_t*>(p);
         run.plans = plans.get();
     }
-    std::shared_ptr<const csub::SubPlans> subs;
-    if (opt(OPT_chol_sub) > 0) {
-        subs = sub_plans_for(nblk);
-        if (subs->nsub > 0) {
-            const size_t bytes = subs->words.size() * 4;
-            if (bytes + 512 > sub_ws_bytes(C)) GQ_FAIL(GQ_E_WORKSPACE, "gq_h_prepare: sub-problem plans of %zu bytes", bytes);
-            unsigned char* q = reinterpret_cast<unsigned char*>(
-                ((uintptr_t)ws + ws_bytes - sub_ws_bytes(C) + 255) & ~(uintptr_t)255);
-            GQ_HIP(hipMemcpyAsync(q, subs->words.data(), bytes, hipMemcpyHostToDevice, st));  // pageable: staged before return
-            run.sub = subs.get();
-            run.sub_dev = reinterpret_cast<uint32_t*>(q);
-        }
-    }
     GQ_HIP(hipMemsetAsync(not_invertible, 0, sizeof(int), st));
     float* eq_s = nullptr;
     {
@@ -907,8 +824,6 @@ int h_prepare(float* H, float* W, int64_t R, int64_t C, float rel_damp, float* U
                                    (int)((2 * NB * LDP + NB) * sizeof(float))));
         GQ_HIP(hipFuncSetAttribute((const void*)diag_blk5_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)DIAG5_LDS));
-        GQ_HIP(hipFuncSetAttribute((const void*)csub::chol_sub_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)csub::LDS_BYTES));
         attr_set = true;
     }
     if ((rc = chol_inv_rec(A, X, U, not_invertible, n, 0, nblk, diag_lds, st, run))) return rc;

@@ -59,8 +59,6 @@ extern thread_local char g_err[512];
     X(chol_no_equil, 0, 0, 1)     /* 1: no power-of-two equilibration */                                                          \
     X(chol_poison, 0, 0, 1)       /* 1: NaN-fill the scratch the chain must never read (tests) */                                 \
     X(diag_ref, 0, 0, 1)          /* 1: the column-by-column 128x128 leaf kernel (reference for tests) */                         \
-    X(chol_sub, 0, 0, 16)         /* widest sub-problem (128-blocks) that runs as ONE resident launch (0: launch by launch) */    \
-    X(chol_sub_wgs, 48, 1, 256)   /* workgroups of that launch */                                                                 \
     /* K5/K6 column loop */                                                                                                       \
     X(no_lookahead, 0, 0, 1)      /* 1: trailing update after every block, no chained far update */                               \
     X(la, 8, 2, 8)                /* blocks per look-ahead super-block (even, 2..8) */                                            \
@@ -153,7 +151,7 @@ __device__ __forceinline__ float dequantize1(float q, float ds, float dm) { retu
 enum ProfTag {
     PT_TRANSPOSE = 0, PT_SYRK, PT_PREP_ELEM, PT_DIAG_POTRF, PT_CHOL_GEMM, PT_TRTRI_GEMM, PT_SCALE_SEARCH,
     PT_GPTQ_SEGMENT, PT_TRAILING, PT_BLOCK_FAR, PT_DEQUANT, PT_RTN, PT_PACK, PT_TRAILING_FAR, PT_CHOL_IMG_GEMM,
-    PT_CHOL_SPLIT, PT_CHOL_SUB, PT_COUNT
+    PT_CHOL_SPLIT, PT_COUNT
 };
 extern unsigned g_prof_mask;
 void prof_begin(int tag, hipStream_t st);

@@ -210,10 +210,8 @@ __device__ __forceinline__ void d5_inverse(float (&x)[32], int i, unsigned lrowb
 
 #define D5_STAMP(k) (void)0
 
-// (a device function: the stand-alone kernel below and the persistent sub-problem kernel of gq_cholsub.hpp both run it;
-// a caller that runs it more than once puts a barrier between the calls)
-__device__ __forceinline__ void diag_blk5_body(float* __restrict__ A, int64_t lda, float* __restrict__ Xout, int64_t ldx,
-                                               int* __restrict__ flag_out) {
+__global__ __launch_bounds__(320) void diag_blk5_kernel(float* __restrict__ A, int64_t lda, float* __restrict__ Xout,
+                                                        int64_t ldx, int* __restrict__ flag_out) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* S = smem;                       // [NB][LDQ]  A (lower) -> L, zeros above the diagonal
     float* X = smem + NB * LDQ;            // [NB][LDQ]  L^-1 (lower), zeros above
@@ -391,11 +389,6 @@ __device__ __forceinline__ void diag_blk5_body(float* __restrict__ A, int64_t ld
         (void)sr;
     }
     if (wid == 0) D5_STAMP(11);
-}
-
-__global__ __launch_bounds__(320) void diag_blk5_kernel(float* __restrict__ A, int64_t lda, float* __restrict__ Xout,
-                                                        int64_t ldx, int* __restrict__ flag_out) {
-    diag_blk5_body(A, lda, Xout, ldx, flag_out);
 }
 
 }  // namespace gq

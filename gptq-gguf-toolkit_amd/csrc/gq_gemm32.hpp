@@ -128,10 +128,7 @@ __device__ __forceinline__ void g32_load_kn_full(float4 (&v)[NV], const float* B
 
 constexpr int G32_COMMIT_AT = 24;  // k position (of 32) where chunk t+1 is written to LDS: 3/4 through the MFMA block
 // one output tile (tile column bxr of gx, tile row byr of gy, in dispatch order) by the calling workgroup
-// XWAVE: the workgroup has waves beyond the NW that compute (the persistent Cholesky sub-problem kernel runs 5: its leaf
-// needs them); they only take part in the barriers.
-template <bool TRANS_B, int MODE, bool LOWER, int KR = 0, int CHAIN = 0, int TS = 128, bool FULL = false, int NW = 4,
-          bool XWAVE = false>
+template <bool TRANS_B, int MODE, bool LOWER, int KR = 0, int CHAIN = 0, int TS = 128, bool FULL = false, int NW = 4>
 __device__ __forceinline__ void gemm32_tile(float* Cmat, int64_t ldc, const float* A, int64_t lda, const float* B,
                                             int64_t ldb, int64_t M, int64_t N, int64_t K, unsigned bxr, unsigned byr,
                                             unsigned gx, unsigned gy) {
@@ -200,13 +197,6 @@ __device__ __forceinline__ void gemm32_tile(float* Cmat, int64_t ldc, const floa
     // Software pipeline: chunk t+1 is written to the other LDS buffer in the MIDDLE of the MFMA block of
     // chunk t (its loads were issued half a chunk + one barrier earlier) and the loads of chunk t+2 follow
     // it, so the LDS writes, the address arithmetic and the global loads all issue in the shadow of MFMAs.
-    if constexpr (XWAVE) {
-        if (tid >= NT) {  // wave-uniform: the same 1 + nk barriers, nothing else
-            __syncthreads();
-            for (int64_t t = 0; t < nk; ++t) __syncthreads();
-            return;
-        }
-    }
     if (nk > 0) {
         fetch(kb);
         commit(0);

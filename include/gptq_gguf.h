@@ -110,9 +110,7 @@ const char* gq_last_error(void);
      chol_3p_min [1792] smallest half-node on the image GEMMs (0: never; changes U within the tolerance class) |
      chol_planes [2] 2 = row-scaled fp16 x 2, 3 = bf16 x 3 (tolerance class) | chol_3b_min [1024] | chol_fp32 [0] fp32 MFMA only
      (tolerance class) | chol_no_pair [0] | chol_no_equil [0] | chol_poison [0] NaN-fill scratch that must not be read |
-     diag_ref [0] column-by-column leaf kernel (tolerance class) | chol_sub [0] widest sub-problem of the Cholesky recursion, in
-     128-blocks (<= 16), that runs as ONE resident launch instead of ~4 launches per block (0: launch by launch; bit-identical) |
-     chol_sub_wgs [48] workgroups of that launch
+     diag_ref [0] column-by-column leaf kernel (tolerance class)
      no_lookahead [0] | la [8] blocks per super-block | seg_pair [1] one column-loop launch per 256-column pair of blocks (0: per
      block) | near_classic [0] | near_quad [0] | near64_maxn [768] | far_sync [0] |
      far_async_max_rows [8192] | far_async_min_sb [8] | far_wgs [192] | far_bdma [1] far GEMM B operand by LDS-DMA (0: registers + ds_write) |

@@ -252,7 +252,7 @@ def test_gq_options_errors_fail_every_entry_point_without_abort():
                           ("la=64", "outside"), ("no_such=1", "unknown option"), ("la=4,syrk_ck=128", "VALUE 4"),
                           # a checkpoint distance the launcher would silently read as "none" is a typo
                           ("syrk_ck=100", "power of two"), ("syrk_ck=8", "power of two"), ("syrk_gw=6", "power of two"),
-                          ("syrk_ck=0,chol_sub=16", "VALUE 8")):
+                          ("syrk_ck=0,syrk_gw=8", "VALUE 8")):
         p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GQ_OPTIONS=env_val), capture_output=True, text=True)
         assert p.returncode == 0 and want in p.stdout, (env_val, p.stdout, p.stderr[-500:])
     from gptq_gguf_toolkit_amd import _cabi
