@@ -781,7 +781,7 @@ def compact_line(line):
     if isinstance(r.get("kernel"), str):
         r["kernel"] = r["kernel"][:118]
     if isinstance(t, dict) and t.get("GB_per_launch"):
-        # HBM-side bytes per launch from the separate --pmc pass (profiles/r05_syrk_traffic.json), GB
+        # HBM-side bytes per launch from the separate --pmc pass (profiles/r06_syrk_traffic.json), GB
         r["traffic"] = t["GB_per_launch"]
         r["traffic_unit"] = "GB/launch, L2-miss reads (--pmc pass)"
         if t.get("algorithmic_GB_per_launch"):
@@ -1006,7 +1006,7 @@ def main():
         if tfiles and args.workload == "llama3-8b-block-q4k" and world == 1 and not args.calib_seqs and not args.seq_len:
             tpath = tfiles[-1]
             try:
-                tj = json.load(open(tpath))  # written by profiles/collect_r05.sh
+                tj = json.load(open(tpath))  # written by profiles/collect_r06.sh
                 hsh = hashlib.sha256()
                 for fn in sorted(glob.glob(os.path.join(ROOT, "gptq-gguf-toolkit_amd", "csrc", "*.h*"))):
                     hsh.update(open(fn, "rb").read())

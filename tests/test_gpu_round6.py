@@ -1,5 +1,7 @@
 """Round 6 GPU tests (VERDICT r05 "next round" items)."""
+import json
 import os
+import subprocess
 import sys
 
 import pytest
@@ -91,3 +93,33 @@ def test_integration_stub_runs_as_printed():
         assert np.array_equal(s.cpu().numpy(), g6[f"{tag}_s"]) and np.array_equal(m.cpu().numpy(), g6[f"{tag}_m"]), tag
         if f"{tag}_packed" in g6.files:
             assert np.array_equal(ops.pack(types[name], q, d, s, dmin, m).cpu().numpy(), g6[f"{tag}_packed"]), tag
+
+
+# ----------------------------------------------------------------- item 7: the default line at 8 ranks, whole-model leg included
+def test_default_workload_at_eight_ranks_with_the_whole_model_leg():
+    """the first real 8-GPU lease must not run a code path for the first time.  The driver's command form
+    (`python3 bench.py --gpus 8 ...`) on the DEFAULT workload (llama3-8b-block-q4k: calibration shards, one collective per
+    distinct Hessian, LPT owners, the row-split down_proj, ONE all-gather per block) with 16 calibration sequences, INCLUDING
+    the whole-model leg (2 layers: Quantizer.quantize with sharded calibration, collectives inside the forward cadence, data.pth
+    files dealt to the ranks) -- 8 ranks share the GPU over gloo when the box has fewer than 8."""
+    n = 8
+    backend = [] if torch.cuda.device_count() >= n else ["--backend", "gloo"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), *backend, "--steps", "1", "--warmup", "1",
+           "--calib-seqs", "16", "--layers", "2"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 2
+    full, compact = lines
+    assert full["n_gpus"] == n and full["ranks_seen"] == n and full["value"] > 0
+    assert full["config"]["calib_seqs_per_rank"] == 2 and "llama3-8b-block-q4k" in full["config"]["workload"]
+    coll = full["collectives_per_step"]
+    assert coll["all_gather"] == 1 and coll["broadcast"] == 0 and coll["all_reduce"] + coll["reduce"] == 4  # one per distinct H
+    for key in ("whole_model", "whole_model_hf_eager", "whole_model_batch4"):
+        wm = full[key]
+        assert "error" not in wm, wm
+        assert wm["wall_s_quantizer_region"] > 0 and wm["data_pth"]["files"] == 2 * 7 + 2  # 2 blocks x 7 Linears + embed + lm_head
+        assert wm["end_to_end_gguf"] is None  # the packer leg belongs to the N = 1 line
+    assert compact["whole_model_wall_s"] == full["whole_model"]["wall_s_quantizer_region"] and compact["cpu_baseline"] is None
+    assert "Connection closed" not in json.dumps(full)
