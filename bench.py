@@ -774,16 +774,16 @@ def compact_line(line):
             "vs_baseline", "dtype", "data", "step_latency_ms", "ranks_seen", "collective_backend")
     out = {k: line.get(k) for k in keep if k in line}
     cfg = line.get("config", {})
-    out["config"] = {"workload": str(cfg.get("workload", ""))[:118], "parallelism": cfg.get("parallelism"),
+    out["config"] = {"workload": str(cfg.get("workload", ""))[:96], "parallelism": cfg.get("parallelism"),
                      "calib_seqs_per_rank": cfg.get("calib_seqs_per_rank")}
     r = dict(line.get("roofline") or {})
     t = r.pop("traffic", None)
     if isinstance(r.get("kernel"), str):
-        r["kernel"] = r["kernel"][:118]
+        r["kernel"] = r["kernel"][:64]
     if isinstance(t, dict) and t.get("GB_per_launch"):
         # HBM-side bytes per launch from the separate --pmc pass (profiles/r06_syrk_traffic.json), GB
         r["traffic"] = t["GB_per_launch"]
-        r["traffic_unit"] = "GB/launch, L2-miss reads (--pmc pass)"
+        r["traffic_unit"] = "GB/launch L2-miss reads"
         if t.get("algorithmic_GB_per_launch"):
             r["traffic_algorithmic"] = t["algorithmic_GB_per_launch"]
             r["traffic_ratio"] = round(t["GB_per_launch"] / t["algorithmic_GB_per_launch"], 2)
@@ -792,10 +792,10 @@ def compact_line(line):
     tu = line.get("trailing_update") or {}
     for k_out, path in (("trailing_far_alone_frac", ("far_alone", "frac")), ("trailing_whole_alone_frac", ("whole_alone", "frac")),
                         ("trailing_far_in_region_frac", ("far_in_region", "frac")),
-                        ("trailing_far_in_region_frac_over_busy_time", ("far_in_region", "frac_over_busy_time")),
+                        ("trailing_far_in_region_over_busy", ("far_in_region", "frac_over_busy_time")),
                         ("trailing_loop_ms_as_run", ("loop_ms", "as_run"))):
         r[k_out] = _get(tu, *path)
-    r["trailing_peak_TFLOPs_f32"] = PEAK_F32_MFMA_TFLOPS
+    r["trailing_peak_f32"] = PEAK_F32_MFMA_TFLOPS
     r["frac_on_model_forward_activations"] = _get(line, "whole_model", "syrk_roofline_on_model_activations", "frac")
     r["column_loop_ns_per_step"] = _get(line, "column_loop", "ns_per_step")
     r["encoders_frac_of_hbm"] = _get(line, "encoders", "frac")
@@ -804,7 +804,7 @@ def compact_line(line):
     if c:
         st = c.pop("stages_s_per_block", None) or {}
         so = c.pop("step_only", None) or {}
-        c["sample"] = str(c.get("sample", ""))[:90]
+        c["sample"] = str(c.get("sample", ""))[:60]
         c.update({f"stage_{k}": v for k, v in st.items()})
         c["step_only_value"] = so.get("value")
     out["cpu_baseline"] = c or None  # (None at N > 1: the baseline is part of the N = 1 line)
@@ -817,8 +817,9 @@ def compact_line(line):
     out["gguf_pack_split_s"] = ("load %s h2d %s pack %s d2h %s write %s wait %s" % tuple(sp.get(k) for k in ("load", "h2d", "permute_pack", "d2h", "write", "wait"))) if sp else None
     out["collectives_per_step"] = line.get("collectives_per_step")
     out["allreduce_probe_ms"] = _get(line, "allreduce_probe", "ms")
-    out["tolerance_ints_differ"] = _get(line, "tolerance_parity", "ints_differ")
-    out["tolerance_noise_floor"] = _get(line, "tolerance_parity", "ulp_noise_floor", "ints_differ")
+    rnd = lambda v: round(v, 5) if isinstance(v, float) else v  # noqa: E731
+    out["tolerance_ints_differ"] = rnd(_get(line, "tolerance_parity", "ints_differ"))
+    out["tolerance_noise_floor"] = rnd(_get(line, "tolerance_parity", "ulp_noise_floor", "ints_differ"))
     out["detail"] = "previous stdout line"
     return out
 

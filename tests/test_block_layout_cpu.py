@@ -166,12 +166,47 @@ def test_committed_r05_bench_lines():
     d = json.loads(open(os.path.join(ROOT, "profiles", "r05_bench_llama3-8b-block-q4k_compact.json")).read())
     assert d["roofline"]["traffic"] > d["roofline"]["traffic_algorithmic"] > 0 and d["roofline"]["frac_on_model_forward_activations"] > 0.4
     assert d["whole_model_wall_s"] < d["whole_model_hf_eager_wall_s"]
-    tj = json.load(open(os.path.join(ROOT, "profiles", "r05_syrk_traffic.json")))
+    # (profiles/r05_syrk_traffic.json names r05's kernel sources; the pin on the CURRENT sources is round 6's: below)
+    assert len(json.load(open(os.path.join(ROOT, "profiles", "r05_syrk_traffic.json")))["kernel_sources_sha256"]) == 16
+
+
+def test_committed_r06_bench_lines():
+    """Round 6's five collections (profiles/collect_r06.sh): full dict + compact headline per BASELINE config that fits one GPU; the
+    compact line keeps the driver contract under 2 KB with room to spare and now carries the end-to-end figures (VERDICT r05 next
+    #2: quantize -> pack_gptq_into_gguf -> .gguf); the traffic figure belongs to the kernel sources of THIS tree."""
+    import glob
+    import hashlib
+    import json
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r06_bench_*_compact.json")))
+    assert len(files) == 5
+    for f in files:
+        raw = open(f).read().strip()
+        assert len(raw) <= 1980, (f, len(raw))
+        c = json.loads(raw)
+        full = json.loads(open(f.replace("_compact.json", ".json")).read())
+        for k, t in (("metric", str), ("value", (int, float)), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                     ("ms_per_step", (int, float)), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str)):
+            assert isinstance(c[k], t) and c[k] == full[k], (f, k)
+        assert c["vs_baseline"] is None and "workload" in c["config"] and "model" not in c["config"]
+        r = c["roofline"]
+        assert r["bound"] == "mfma" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["trailing_far_alone_frac"] > 0.5
+        assert all(not isinstance(v, (dict, list)) for v in r.values())
+        assert c["cpu_baseline"]["kind"] == "port" and c["cpu_baseline"]["cores"] >= 1 and c["cpu_baseline"]["value"] > 0
+    d = json.loads(open(os.path.join(ROOT, "profiles", "r06_bench_llama3-8b-block-q4k_compact.json")).read())
+    assert d["roofline"]["traffic"] > d["roofline"]["traffic_algorithmic"] > 0 and d["roofline"]["frac_on_model_forward_activations"] > 0.4
+    assert d["whole_model_wall_s"] < d["whole_model_hf_eager_wall_s"]
+    # the target end to end: the packer costs less than the quantizer (VERDICT r05's bar) and the sum is what the line says
+    assert 0 < d["gguf_pack_wall_s"] < d["whole_model_wall_s"]
+    assert abs(d["end_to_end_gguf_wall_s"] - d["whole_model_wall_s"] - d["gguf_pack_wall_s"]) < 0.02 and "write" in d["gguf_pack_split_s"]
+    full = json.loads(open(os.path.join(ROOT, "profiles", "r06_bench_llama3-8b-block-q4k.json")).read())
+    e2e = full["whole_model"]["end_to_end_gguf"]
+    assert 4.0 < e2e["gguf_GB"] < 5.5 and set(e2e["split_s"]) >= {"load", "h2d", "permute_pack", "d2h", "write", "wait"}
+    tj = json.load(open(os.path.join(ROOT, "profiles", "r06_syrk_traffic.json")))
     h = hashlib.sha256()
     for fn in sorted(glob.glob(os.path.join(ROOT, "gptq-gguf-toolkit_amd", "csrc", "*.h*"))):
         h.update(open(fn, "rb").read())
-    # (a later edit of a kernel source makes bench.py report traffic = null until collect_r05.sh is run again: say so here)
-    assert tj["kernel_sources_sha256"] == h.hexdigest()[:16], "csrc changed after the traffic pass: re-run profiles/collect_r05.sh"
+    # (a later edit of a kernel source makes bench.py report traffic = null until collect_r06.sh is run again: say so here)
+    assert tj["kernel_sources_sha256"] == h.hexdigest()[:16], "csrc changed after the traffic pass: re-run profiles/collect_r06.sh"
 
 
 def test_committed_bench_lines_keep_the_driver_contract():
