@@ -174,8 +174,8 @@ class GGUFWriter:
     def add_tensor_lazy(self, name: str, shape, raw_dtype: int, producer):
         """A tensor whose bytes are made when the file is written (gguf-py has the same split: add_tensor_info now,
         write_tensor_data later).  `shape` is the LOGICAL shape; `producer()` returns a C-contiguous numpy array of exactly
-        the type's byte count.  write() runs the producers on a thread of their own, a few tensors ahead of the file
-        writes: a converter never holds more than `LAZY_DEPTH` payloads (pack_gptq_into_gguf.convert: ~5 GB otherwise)."""
+        the type's byte count.  write() runs the producers on threads of their own (LAZY_WORKERS at a time, results in tensor
+        order), a few tensors ahead of the file writes: a converter never holds more than `LAZY_DEPTH` payloads (pack_gptq_into_gguf.convert: ~5 GB otherwise)."""
         if any(n == name for n, *_ in self.tensors):  # rule R2
             raise ValueError(f"Duplicated tensor name {name!r}")
         shape = tuple(int(x) for x in shape)
@@ -184,6 +184,7 @@ class GGUFWriter:
         self.tensors.append((name, shape, int(raw_dtype), _Lazy(producer, nbytes)))
 
     LAZY_DEPTH = 4
+    LAZY_WORKERS = 3
 
     def write(self, timing: dict = None):
         """`timing` (optional) receives seconds: "write" = file writes, "wait" = the writer waiting for a producer."""
@@ -194,9 +195,18 @@ class GGUFWriter:
         q: "queue.Queue" = queue.Queue(maxsize=self.LAZY_DEPTH)
 
         def produce():
+            # LAZY_WORKERS producers run at a time (a payload's upload is a pageable copy bound by ONE host core: two or three
+            # of them overlap), their results are handed over in tensor order, at most LAZY_DEPTH ahead of the file writes
+            from concurrent.futures import ThreadPoolExecutor
             try:
-                for d in lazy:
-                    q.put(d.producer())
+                with ThreadPoolExecutor(max_workers=self.LAZY_WORKERS) as pool:
+                    pending = []
+                    for d in lazy:
+                        pending.append(pool.submit(d.producer))
+                        if len(pending) >= self.LAZY_WORKERS:
+                            q.put(pending.pop(0).result())
+                    for f in pending:
+                        q.put(f.result())
             except BaseException as e:  # handed to the writing thread
                 q.put(e)
 

@@ -347,11 +347,15 @@ def convert(dir_model: Path, dir_model_quant: Path, outfile: Path, outtype: str 
     row un-permute and gq_pack on the GPU, one download (GGUFWriter.add_tensor_lazy) -- instead of five uploads, a CPU permute
     and ~5 GB of payloads held until write() (pipelined=False: that flow, the reference's :282-349 order of operations).  Same
     file bytes either way (tests/test_host_logic_cpu.py::test_pack_into_gguf...).  `timing` receives seconds per stage."""
+    import threading
     import time
     tm = timing if timing is not None else {}
+    tm_lock = threading.Lock()
 
-    def clock(key, t0):
-        tm[key] = tm.get(key, 0.0) + time.perf_counter() - t0
+    def clock(key, t0):  # (producers run on several threads: their seconds add up per stage, wall time is the caller's)
+        dt = time.perf_counter() - t0
+        with tm_lock:
+            tm[key] = tm.get(key, 0.0) + dt
 
     hp = json.load(open(dir_model / "config.json"))
     arch = hp.get("architectures", ["LlamaForCausalLM"])[0]
