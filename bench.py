@@ -637,15 +637,26 @@ def whole_model_run(wl, dev, world, rank, save_root=None, nseq=None, L=None, lay
     root = save_root
     if root is None:
         shm_free = shutil.disk_usage("/dev/shm").free if os.path.isdir("/dev/shm") else 0
-        root = "/dev/shm" if shm_free > 24e9 else tempfile.gettempdir()
+        # (with the packer leg: + 2 B/param of checkpoint + 0.57 B/param of .gguf)
+        root = "/dev/shm" if shm_free > (64e9 if gguf else 24e9) else tempfile.gettempdir()
     save_dir = tempfile.mkdtemp(prefix="gq_bench_", dir=root) if rank == 0 else None
     hf_dir = None
     if gguf and rank == 0 and world == 1:
         # the checkpoint directory the packer reads (the reference's `model` argument), written BEFORE the timed region from the
         # un-quantized weights: the quantizer writes the dequantized ones back into the live model
-        hf_dir = tempfile.mkdtemp(prefix="gq_bench_hf_", dir=root)
         t0 = time.perf_counter()
-        model.save_pretrained(hf_dir, safe_serialization=True)
+        try:
+            need = 2.7 * sum(p.numel() for p in model.parameters())
+            if shutil.disk_usage(root).free < 1.5 * need:
+                raise OSError(f"{root}: not enough room for the checkpoint directory and the .gguf file")
+            hf_dir = tempfile.mkdtemp(prefix="gq_bench_hf_", dir=root)
+            model.save_pretrained(hf_dir, safe_serialization=True)
+        except Exception as e:  # the quantizer leg must still run: the packer leg reports why it did not
+            if hf_dir is not None:
+                shutil.rmtree(hf_dir, ignore_errors=True)
+            hf_dir, gguf_skip = None, repr(e)
+        else:
+            gguf_skip = None
         t_save = time.perf_counter() - t0
     if world > 1:
         box = [save_dir]
@@ -691,7 +702,7 @@ def whole_model_run(wl, dev, world, rank, save_root=None, nseq=None, L=None, lay
         wall = float(tm.item())
         files = sum(len(f) for _, _, f in os.walk(save_dir)) if rank == 0 else 0
         nbytes = sum(os.path.getsize(os.path.join(d, f)) for d, _, fs in os.walk(save_dir) for f in fs) if rank == 0 else 0
-        e2e = None
+        e2e = {"error": gguf_skip} if (gguf and rank == 0 and world == 1 and hf_dir is None) else None
         if hf_dir is not None:
             try:
                 e2e = gguf_leg(hf_dir, save_dir, root, wall)
