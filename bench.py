@@ -605,9 +605,10 @@ def gguf_leg(hf_dir, save_dir, root, quant_wall):
         out[label] = {"pack_wall_s": round(wall, 2), "gguf_GB": round(size / 1e9, 2), "sha256_16": digest,
                       "split_s": {k: round(v, 2) for k, v in sorted(tm.items())},
                       "split_keys": "load = torch.load of the data.pth files (mmap); hf_read / plain = checkpoint tensors GPTQ did not "
-                                    "replace, read and converted; h2d / permute_pack / d2h = producer thread (upload of the five "
-                                    "tensors, q/k row un-permute + gq_pack on the GPU, download of the block bytes); write = file "
-                                    "writes, wait = the writing thread waiting for the producer; write_call = GGUFWriter.write as a whole"}
+                                    "replace, read and converted; h2d / permute_pack / d2h = producer threads, seconds ADDED UP over the "
+                                    "GGUFWriter.LAZY_WORKERS = 3 that run at a time (upload of the five tensors, q/k row un-permute + gq_pack "
+                                    "on the GPU incl. waiting for the other producers' work on the stream, download of the block bytes); write = "
+                                    "file writes, wait = the writing thread waiting for a producer; write_call = GGUFWriter.write as a whole (wall)"}
     p = out["pipelined"]
     return {"end_to_end_gguf_wall_s": round(quant_wall + p["pack_wall_s"], 2), "quantize_wall_s": round(quant_wall, 2),
             "pack_wall_s": p["pack_wall_s"], "gguf_GB": p["gguf_GB"], "split_s": p["split_s"], "split_keys": p["split_keys"],
