@@ -1485,3 +1485,41 @@ def test_gguf_writer_makes_gguf_pys_choices_where_the_spec_is_open(tmp_path):
     # dims innermost first (R5): the Q4_K tensor's info holds ne = [256, 2]
     j = buf.index(b"a_first_in_name_order.weight") + len(b"a_first_in_name_order.weight")
     assert struct.unpack_from("<IQQIQ", buf, j) == (2, 256, 2, GGMLType.Q4_K, 64)
+
+
+def test_gguf_writer_lazy_tensors_are_written_in_order_and_errors_surface(tmp_path):
+    """r06: GGUFWriter.add_tensor_lazy (gguf-py's add_tensor_info / write_tensor_data split): payloads are produced while the file
+    is written -- several producers at a time, handed over in tensor order -- and the file equals the eager writer's byte for
+    byte; a producer that returns the wrong number of bytes, or raises, fails write() instead of leaving a silent bad file."""
+    import time
+    from gptq_gguf_toolkit_amd.gguf_writer import GGMLType, GGUFWriter
+    rng = np.random.default_rng(0)
+    blobs = [rng.integers(0, 256, (4 + i, 144), dtype=np.uint8) for i in range(9)]
+    plain = rng.standard_normal((3, 5)).astype(np.float32)
+
+    def build(path, lazy):
+        w = GGUFWriter(str(path), "llama")
+        w.add_uint32("x.count", 9)
+        w.add_tensor("first", plain)
+        for i, b in enumerate(blobs):
+            if lazy:
+                # later tensors finish EARLIER: the hand-over order must still be the tensor order
+                w.add_tensor_lazy(f"t{i}", (b.shape[0], 256), GGMLType.Q4_K, (lambda b=b, i=i: (time.sleep(0.02 * (9 - i)), b)[1]))
+            else:
+                w.add_tensor(f"t{i}", b, raw_dtype=GGMLType.Q4_K)
+        w.add_tensor("last", plain.astype(np.float16))
+        return w
+    build(tmp_path / "eager.gguf", False).write()
+    tm = {}
+    build(tmp_path / "lazy.gguf", True).write(tm)
+    assert (tmp_path / "eager.gguf").read_bytes() == (tmp_path / "lazy.gguf").read_bytes() and tm["write"] >= 0 and tm["wait"] > 0
+    w = GGUFWriter(str(tmp_path / "bad.gguf"), "llama")
+    w.add_tensor_lazy("t", (4, 256), GGMLType.Q4_K, lambda: blobs[1])  # 5 rows announced as 4
+    with pytest.raises(ValueError, match="announced"):
+        w.write()
+    w = GGUFWriter(str(tmp_path / "bad2.gguf"), "llama")
+    w.add_tensor_lazy("t", (4, 256), GGMLType.Q4_K, lambda: (_ for _ in ()).throw(RuntimeError("upload failed")))
+    with pytest.raises(RuntimeError, match="upload failed"):
+        w.write()
+    with pytest.raises(ValueError, match="Duplicated tensor name"):
+        w.add_tensor_lazy("t", (4, 256), GGMLType.Q4_K, lambda: blobs[0])
